@@ -1,0 +1,162 @@
+/*
+ * rua.h — C ABI of librua_hip.so: MI355X (gfx950) ragged-sequence row kernels.
+ *
+ * This is the drop-in boundary for the hot path of speedcell4/torchrua 0.5.1
+ * (layout conversion cat/pack/left/right, select head/last/roll/rev/trunc,
+ * segmented + scatter reduce).  The reference has no FFI of its own: its
+ * boundary is the set of Python methods it monkey-patches onto the four layout
+ * types.  Every entry point below cites the reference method(s) whose ATen
+ * composition it replaces (paths relative to the reference checkout).
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + sizes, no torch types; all index vectors int64
+ *     (the reference's index dtype everywhere);
+ *   - never allocates, never synchronises, never throws; work is enqueued on
+ *     `stream` (a hipStream_t passed as void*); scratch is caller-provided;
+ *   - returns 0 on success, a positive hipError_t if the HIP runtime refused
+ *     the launch, or a negative RUA_E* code for a rejected argument;
+ *   - stateless and re-entrant.
+ */
+#ifndef RUA_H_
+#define RUA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RUA_ABI_VERSION 1
+
+/* argument errors (negative so they cannot collide with hipError_t) */
+#define RUA_EINVAL   (-1)  /* bad enum / null pointer / negative size      */
+#define RUA_EALIGN   (-2)  /* pointer or row size not aligned as required   */
+#define RUA_ERANGE   (-3)  /* size exceeds what the launch geometry covers  */
+
+/* ---- layouts -------------------------------------------------------------
+ * Logical coordinate of a token: (b, t), 0 <= t < len[b].  Flat storage row:
+ *   CAT    row = off[b] + t                       core/get.py:25-26, layout/cat.py:79-81
+ *   LEFT   row = b*T_phys + t                     core/get.py:41-42, layout/left.py:73-77
+ *   PACK   row = boff[t] + unsorted[b]            core/get.py:57-58, layout/pack.py:43-45
+ *   RIGHT  row = b*T_phys + (T_log - len[b]) + t  core/get.py:73-74, layout/right.py:74-79
+ *   LIST   (destination only) row j holds token (bptr[j], tptr[j])   core/get.py tuple keys
+ * Enumeration order of a layout's rows (= the order of X.ptr()):
+ *   CAT/LEFT/RIGHT: for b: for t < len[b]         layout/cat.py:68-71
+ *   PACK:           for t: for r < bsz[t]: (sorted[r], t)            layout/pack.py:23-27
+ */
+enum rua_kind { RUA_CAT = 0, RUA_LEFT = 1, RUA_PACK = 2, RUA_RIGHT = 3, RUA_LIST = 4 };
+
+typedef struct rua_layout {
+  int32_t kind;            /* enum rua_kind */
+  int32_t reserved;
+  int64_t n_rows;          /* storage rows: CAT/PACK: sum(len); LEFT/RIGHT: B*T_phys; LIST: M */
+  int64_t B;               /* number of sequences */
+  int64_t T_phys;          /* LEFT/RIGHT: rows per sequence in storage (data.size(1)) */
+  int64_t T_log;           /* RIGHT: the T used for right alignment (reference: token_sizes.max()) */
+  const int64_t* lens;     /* [B] or NULL                                   */
+  int64_t len_add;         /* len[b] = (lens ? lens[b] : 0) + len_add       */
+  const int64_t* off;      /* CAT: exclusive scan of lens, [B] (NULL when lens is NULL);
+                              effective offset = off[b] + b*len_add         */
+  const int64_t* boff;     /* PACK: exclusive scan of batch_sizes, [T]      */
+  int64_t T;               /* PACK: number of time steps                    */
+  const int64_t* sorted;   /* PACK: sorted_indices [B]                      */
+  const int64_t* unsorted; /* PACK: unsorted_indices [B]                    */
+  const int64_t* bptr;     /* LIST: [M]                                     */
+  const int64_t* tptr;     /* LIST: [M]                                     */
+} rua_layout;
+
+/* ---- per-sequence token maps: t_src = f(t_dst) ---------------------------- */
+enum rua_tmap {
+  RUA_T_SHIFT = 0,  /* t + arg            identity (arg=0), trunc (select/trunc.py:9-62)       */
+  RUA_T_ROLL  = 1,  /* (t - arg) mod slen select/roll.py:6-13                                  */
+  RUA_T_REV_S = 2,  /* slen - 1 - t       select/rev.py:6-41; last = REV_S with dlen = 1 (select/last.py:7-13) */
+  RUA_T_REV_D = 3,  /* dlen - 1 - t       adjoint of REV_S (backward of last)                  */
+  RUA_T_ZERO  = 4   /* 0                  broadcast one row per sequence (backward of sum)     */
+};
+
+#define RUA_MOVE_SCATTER 1  /* flags: enumerate `dst` layout rows as the SOURCE rows and write
+                               them to the rows computed from `src` layout (core/set.py)        */
+
+/* K1. Exclusive prefix sum of n int64 (wavefront scan).  out[i] = sum(in[0..i)).
+ * `ws` must hold rua_scan_ws_elems(n) int64.  If total != NULL, *total (device) = sum(in).
+ * Replaces get_offsets, utils.py:16-19 (cumsum + roll + [0]=0). */
+int64_t rua_scan_ws_elems(int64_t n);
+int rua_exclusive_scan_i64(const int64_t* in, int64_t* out, int64_t* total, int64_t n,
+                           int64_t* ws, void* stream);
+
+/* K3. PackedSequence metadata from lengths + the (host-sorted) descending order.
+ *   unsorted[sorted[r]] = r                       utils.py:22-26 (invert_permutation)
+ *   bsz[t] = #{b : len[b] > t}, t < T             core/view.py:47-58 (get_mask(..).sum(dim=0))
+ * without materialising the B x T int64 mask (core/view.py:11-18). */
+int rua_pack_meta(const int64_t* lens, const int64_t* sorted, int64_t B, int64_t T,
+                  int64_t* unsorted, int64_t* bsz, void* stream);
+
+/* K3b. token_sizes of a PackedSequence in original batch order:
+ *   len[b] = #{t : bsz[t] > unsorted[b]}          core/view.py:21-25 (get_mask(P).sum(dim=1)) */
+int rua_lens_from_pack(const int64_t* bsz, int64_t T, const int64_t* unsorted, int64_t B,
+                       int64_t* lens, void* stream);
+
+/* K2. Enumerate a layout's rows in ptr() order.  Any of the outputs may be NULL.
+ *   batch_ptr[j], token_ptr[j]                    utils.py:7-13 (major_sizes_to_ptr), X.ptr()
+ *   flat[j] = storage row of token j              layout/left.py:73-77, right.py:74-79 (X.idx()) */
+int rua_enum_rows(const rua_layout* lay, int64_t n_tokens, int64_t* batch_ptr, int64_t* token_ptr,
+                  int64_t* flat, void* stream);
+
+/* get_mask / mask: out[b, t] = (t < len[b]) ? one : zero over a B x T grid of elem_bytes-wide
+ * elements (1, 2, 4 or 8).  core/view.py:11-18, mask.py:6-14. */
+int rua_mask(const int64_t* lens, int64_t B, int64_t T, void* out, int32_t elem_bytes,
+             uint64_t zero_bits, uint64_t one_bits, void* stream);
+
+/* K4/K5/K6/K7. The row mover.  For every storage row j of `dst` (token (b,t), or padding):
+ *     ts = tmap(t);  if 0 <= ts < slen[b]: dst_row(j) = src_row(b, ts)  else  dst_row(j) = fill
+ * Replaces every conversion in core/cast.py:8-71 (+ the new_full pre-fill of core/view.py:34-38,
+ * 67-71: padding and payload are written in ONE pass), core/get.py / core/set.py tuple-key
+ * indexing, select/head.py, select/last.py, select/roll.py, select/rev.py, select/trunc.py.
+ * `fill16` is the fill element replicated to 16 bytes. Rows are row_bytes wide on both sides. */
+int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32_t tmap, int64_t tmap_arg,
+                  void* dst_data, const void* src_data, int64_t row_bytes,
+                  const void* fill16, int32_t flags, void* stream);
+
+/* ---- reductions ------------------------------------------------------------ */
+enum rua_dtype { RUA_F32 = 0, RUA_BF16 = 1, RUA_F16 = 2, RUA_F64 = 3 };
+enum rua_op {
+  RUA_SUM = 0, RUA_MEAN = 1, RUA_MAX = 2, RUA_MIN = 3, RUA_PROD = 4, RUA_LOGSUMEXP = 5
+};
+
+/* K8/K9/K10/K11. out[b, :] = op over t < len[b] of data[row(b, t), :], accumulating in fp32
+ * (fp64 for RUA_F64), for the sequences of `lay` in ANY layout:
+ *   CAT   = torch.segment_reduce(data, op, lengths=lens)      reduce.py:34-61
+ *   PACK  = the same over a PackedSequence without P.cat()     (core/cast.py:8-10 + reduce.py:44)
+ *   LEFT/RIGHT = over the valid rows of a padded batch          segment.py:16-25, 38-47
+ * `perm` (may be NULL) indirects CAT rows: row = perm[off[b]+t] — the sorted-by-destination
+ * form of scatter_* (reduce.py:6-31).
+ * Empty sequence -> `empty_bits` (the reference's `initial`: 0, 1, or the global min/max).
+ * If `extreme` != NULL (MAX/MIN only) the kernel also folds every element it reads into
+ * *extreme (f32/f64 by dtype, pre-initialised by the caller) so that the reference's
+ * `initial = tensor.min()` (reduce.py:35,40) costs no extra pass; rua_fill_empty then
+ * patches the empty segments.
+ * include_self: `out` already holds values that take part in the reduction (scatter_*). */
+int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* data, void* out,
+                       int64_t H, int32_t dtype, int32_t op, int32_t include_self,
+                       uint64_t empty_bits, void* extreme, void* stream);
+
+/* Patch rows of empty sequences with *extreme after rua_segment_reduce (MAX/MIN), and poison
+ * every row with NaN when *extreme is NaN (the reference's initial=NaN behaviour). */
+int rua_fill_empty(const rua_layout* lay, void* out, int64_t H, int32_t dtype, int32_t op,
+                   const void* extreme, void* stream);
+
+/* Counting sort of `index` (values in [0,S)) giving for every destination its contribution
+ * rows in ascending source order (deterministic): counts[S], off[S] (exclusive scan),
+ * perm[M].  `ws` holds rua_scan_ws_elems(S) + S + M int64.  Feeds rua_segment_reduce(perm=..)
+ * for scatter_* (reduce.py:6-31). */
+int rua_index_buckets(const int64_t* index, int64_t M, int64_t S, int64_t* counts, int64_t* off,
+                      int64_t* perm, int64_t* ws, void* stream);
+
+/* Introspection: ABI version and the gfx target the code objects were built for. */
+int rua_abi_version(void);
+const char* rua_build_target(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUA_H_ */

@@ -1,0 +1,115 @@
+"""ctypes binding of librua_hip.so (the C ABI declared in include/rua.h).
+
+The product path has no CPU fallback: if the shared library is missing, or an op is handed a
+tensor that does not live on a HIP device, we raise.  PyTorch is used only for device memory and
+streams; every kernel is launched through the plain-pointer C ABI on torch's current stream.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_uint64, c_void_p
+
+import torch  # noqa: F401  (must be imported first: maps the HIP runtime our library binds to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'librua_hip.so')
+
+# enum rua_kind
+CAT, LEFT, PACK, RIGHT, LIST = 0, 1, 2, 3, 4
+# enum rua_tmap
+T_SHIFT, T_ROLL, T_REV_S, T_REV_D, T_ZERO = 0, 1, 2, 3, 4
+MOVE_SCATTER = 1
+# enum rua_dtype / rua_op
+F32, BF16, F16, F64 = 0, 1, 2, 3
+SUM, MEAN, MAX, MIN, PROD, LOGSUMEXP = 0, 1, 2, 3, 4, 5
+
+DTYPES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16, torch.float64: F64}
+
+
+class RuaLayout(Structure):
+    """struct rua_layout (include/rua.h)."""
+    _fields_ = [
+        ('kind', c_int32), ('reserved', c_int32),
+        ('n_rows', c_int64), ('B', c_int64), ('T_phys', c_int64), ('T_log', c_int64),
+        ('lens', c_void_p), ('len_add', c_int64), ('off', c_void_p),
+        ('boff', c_void_p), ('T', c_int64), ('sorted', c_void_p), ('unsorted', c_void_p),
+        ('bptr', c_void_p), ('tptr', c_void_p),
+    ]
+
+
+class RuaError(RuntimeError):
+    pass
+
+
+# every symbol include/rua.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    'rua_scan_ws_elems': (c_int64, [c_int64]),
+    'rua_exclusive_scan_i64': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    'rua_pack_meta': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    'rua_lens_from_pack': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
+    'rua_enum_rows': (c_int, [POINTER(RuaLayout), c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rua_mask': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int32, c_uint64, c_uint64, c_void_p]),
+    'rua_move_rows': (c_int, [POINTER(RuaLayout), POINTER(RuaLayout), c_int32, c_int64, c_void_p, c_void_p,
+                              c_int64, c_void_p, c_int32, c_void_p]),
+    'rua_segment_reduce': (c_int, [POINTER(RuaLayout), c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
+                                   c_int32, c_uint64, c_void_p, c_void_p]),
+    'rua_fill_empty': (c_int, [POINTER(RuaLayout), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    'rua_index_buckets': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rua_abi_version': (c_int, []),
+    'rua_build_target': (c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load librua_hip.so (once).  Raises RuaError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuaError(
+            f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'or `make -C torchrua_amd/csrc`. torchrua_amd has no CPU/eager fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and this table disagree
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.rua_abi_version() != 1:
+        raise RuaError(f'ABI mismatch: library reports {lib.rua_abi_version()}, binding expects 1')
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code == 0:
+        return
+    if code < 0:
+        names = {-1: 'RUA_EINVAL', -2: 'RUA_EALIGN', -3: 'RUA_ERANGE'}
+        raise RuaError(f'{what}: rejected argument ({names.get(code, code)})')
+    raise RuaError(f'{what}: HIP error {code}')
+
+
+def stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_device(*tensors) -> torch.device:
+    """All tensors must sit on one HIP device; there is no host path."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuaError(
+                'torchrua_amd runs on MI355X only: got a tensor on '
+                f'{t.device}; move it to a HIP device (there is no CPU fallback by design)')
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuaError(f'tensors on different devices: {dev} vs {t.device}')
+    return dev
+
+
+def ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()

@@ -1,0 +1,104 @@
+// rua_dev.h — device-side helpers shared by the gfx950 kernels of librua_hip.so.
+// Row-map closed forms follow SURVEY.md §3 / the reference's core/get.py; see include/rua.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rua.h"
+
+#define RUA_WAVE 64          // gfx950 wavefront
+#define RUA_BLOCK 256        // 4 waves per workgroup everywhere
+#define RUA_WAVES_PER_BLOCK (RUA_BLOCK / RUA_WAVE)
+
+namespace rua {
+
+__device__ __forceinline__ int64_t seq_len(const rua_layout& L, int64_t b) {
+  return (L.lens ? L.lens[b] : 0) + L.len_add;
+}
+
+// exclusive offset of sequence b in a CAT-ordered enumeration
+__device__ __forceinline__ int64_t cat_off(const rua_layout& L, int64_t b) {
+  return (L.off ? L.off[b] : 0) + b * L.len_add;
+}
+
+// largest b in [0, B) with cat_off(b) <= j   (requires cat_off(0) <= j)
+__device__ __forceinline__ int64_t search_cat(const rua_layout& L, int64_t j) {
+  int64_t lo = 0, hi = L.B;
+  if (!L.off) {  // constant length: closed form
+    int64_t n = L.len_add;
+    return n > 0 ? j / n : 0;
+  }
+  while (hi - lo > 1) {
+    int64_t mid = (lo + hi) >> 1;
+    if (cat_off(L, mid) <= j) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// largest t in [0, T) with boff[t] <= j
+__device__ __forceinline__ int64_t search_boff(const int64_t* __restrict__ boff, int64_t T, int64_t j) {
+  int64_t lo = 0, hi = T;
+  while (hi - lo > 1) {
+    int64_t mid = (lo + hi) >> 1;
+    if (boff[mid] <= j) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// storage row j of layout D -> token (b, t); returns false for a padding row
+__device__ __forceinline__ bool row_to_token(const rua_layout& D, int64_t j, int64_t& b, int64_t& t) {
+  switch (D.kind) {
+    case RUA_CAT:
+      b = search_cat(D, j);
+      t = j - cat_off(D, b);
+      return true;
+    case RUA_PACK: {
+      t = search_boff(D.boff, D.T, j);
+      int64_t r = j - D.boff[t];
+      b = D.sorted ? D.sorted[r] : r;
+      return true;
+    }
+    case RUA_LEFT:
+      b = j / D.T_phys;
+      t = j - b * D.T_phys;
+      return t < seq_len(D, b);
+    case RUA_RIGHT: {
+      b = j / D.T_phys;
+      int64_t len = seq_len(D, b);
+      t = (j - b * D.T_phys) - (D.T_log - len);
+      return t >= 0 && t < len;
+    }
+    case RUA_LIST:
+      b = D.bptr[j];
+      t = D.tptr[j];
+      return true;
+  }
+  return false;
+}
+
+// token (b, t) -> storage row of layout S
+__device__ __forceinline__ int64_t token_to_row(const rua_layout& S, int64_t b, int64_t t, int64_t slen) {
+  switch (S.kind) {
+    case RUA_CAT:   return cat_off(S, b) + t;
+    case RUA_PACK:  return S.boff[t] + (S.unsorted ? S.unsorted[b] : b);
+    case RUA_LEFT:  return b * S.T_phys + t;
+    case RUA_RIGHT: return b * S.T_phys + (S.T_log - slen) + t;
+  }
+  return -1;
+}
+
+__device__ __forceinline__ int64_t apply_tmap(int32_t tmap, int64_t arg, int64_t t, int64_t slen, int64_t dlen) {
+  switch (tmap) {
+    case RUA_T_SHIFT: return t + arg;
+    case RUA_T_ROLL: {
+      if (slen <= 0) return -1;
+      int64_t m = (t - arg) % slen;   // C remainder: sign of dividend
+      return m < 0 ? m + slen : m;
+    }
+    case RUA_T_REV_S: return slen - 1 - t;
+    case RUA_T_REV_D: return dlen - 1 - t;
+    case RUA_T_ZERO:  return 0;
+  }
+  return -1;
+}
+
+}  // namespace rua

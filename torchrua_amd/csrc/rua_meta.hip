@@ -1,0 +1,259 @@
+// rua_meta.hip — index-generation kernels (int64, bit-exact): prefix scan, PackedSequence
+// metadata, row enumeration (ptr/idx) and masks.  gfx950, wave64.  See include/rua.h.
+#include "rua_dev.h"
+
+namespace rua {
+
+// ------------------------------------------------------------------ wave / block scan
+__device__ __forceinline__ int64_t wave_inclusive_scan(int64_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < RUA_WAVE; d <<= 1) {
+    int64_t o = __shfl_up(v, d, RUA_WAVE);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+__device__ __forceinline__ int64_t wave_sum(int64_t v) {
+#pragma unroll
+  for (int d = RUA_WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, RUA_WAVE);
+  return v;
+}
+
+// exclusive scan of one value per thread across the 256-thread block; *block_total = sum
+__device__ __forceinline__ int64_t block_exclusive_scan(int64_t v, int64_t* block_total) {
+  __shared__ int64_t s_wave[RUA_WAVES_PER_BLOCK];
+  const int lane = threadIdx.x & (RUA_WAVE - 1), wave = threadIdx.x >> 6;
+  int64_t inc = wave_inclusive_scan(v, lane);
+  if (lane == RUA_WAVE - 1) s_wave[wave] = inc;
+  __syncthreads();
+  int64_t pre = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < RUA_WAVES_PER_BLOCK; ++w) {
+    int64_t x = s_wave[w];
+    if (w < wave) pre += x;
+    tot += x;
+  }
+  __syncthreads();  // s_wave reusable by the caller's next call
+  *block_total = tot;
+  return pre + inc - v;
+}
+
+constexpr int SCAN_ITEMS = 8;                       // int64 per thread
+constexpr int SCAN_TILE = RUA_BLOCK * SCAN_ITEMS;   // 2048 per block
+
+// pass A: per-tile totals
+__global__ __launch_bounds__(RUA_BLOCK) void scan_partials_kernel(const int64_t* __restrict__ in, int64_t n,
+                                                                  int64_t* __restrict__ part) {
+  __shared__ int64_t s_wave[RUA_WAVES_PER_BLOCK];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+  int64_t s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    int64_t i = base + (int64_t)k * RUA_BLOCK + threadIdx.x;  // coalesced
+    if (i < n) s += in[i];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t t = 0;
+    for (int w = 0; w < RUA_WAVES_PER_BLOCK; ++w) t += s_wave[w];
+    part[blockIdx.x] = t;
+  }
+}
+
+// pass B: one block turns the nb tile totals into exclusive prefixes (in place)
+__global__ __launch_bounds__(RUA_BLOCK) void scan_spine_kernel(int64_t* __restrict__ part, int64_t nb,
+                                                               int64_t* __restrict__ total) {
+  int64_t carry = 0;
+  for (int64_t c = 0; c < nb; c += RUA_BLOCK) {
+    int64_t i = c + threadIdx.x;
+    int64_t v = i < nb ? part[i] : 0;
+    int64_t tot;
+    int64_t ex = block_exclusive_scan(v, &tot);
+    if (i < nb) part[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0 && total) *total = carry;
+}
+
+// pass C: scan inside the tile, offset by the tile prefix.  Thread k owns SCAN_ITEMS
+// consecutive elements so the per-thread partial order is the global order.
+__global__ __launch_bounds__(RUA_BLOCK) void scan_apply_kernel(const int64_t* __restrict__ in, int64_t n,
+                                                               const int64_t* __restrict__ part,
+                                                               int64_t* __restrict__ out,
+                                                               int64_t* __restrict__ total_single) {
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int64_t v[SCAN_ITEMS];
+  int64_t s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    v[k] = (base + k < n) ? in[base + k] : 0;
+    s += v[k];
+  }
+  int64_t tot;
+  int64_t run = block_exclusive_scan(s, &tot) + (part ? part[blockIdx.x] : 0);
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    if (base + k < n) out[base + k] = run;
+    run += v[k];
+  }
+  if (total_single && threadIdx.x == 0) *total_single = tot;
+}
+
+// ------------------------------------------------------------------ PackedSequence metadata
+__global__ __launch_bounds__(RUA_BLOCK) void pack_meta_kernel(const int64_t* __restrict__ lens,
+                                                              const int64_t* __restrict__ sorted, int64_t B,
+                                                              int64_t T, int64_t* __restrict__ unsorted,
+                                                              int64_t* __restrict__ bsz) {
+  const int64_t i = (int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x;
+  if (i < B && unsorted) unsorted[sorted[i]] = i;
+  if (i < T && bsz) {
+    // lens[sorted[r]] is non-increasing in r: count r with lens[sorted[r]] > i
+    int64_t lo = 0, hi = B;  // first r in [lo, hi] with key <= i
+    while (lo < hi) {
+      int64_t mid = (lo + hi) >> 1;
+      if (lens[sorted[mid]] > i) lo = mid + 1; else hi = mid;
+    }
+    bsz[i] = lo;
+  }
+}
+
+__global__ __launch_bounds__(RUA_BLOCK) void lens_from_pack_kernel(const int64_t* __restrict__ bsz, int64_t T,
+                                                                   const int64_t* __restrict__ unsorted,
+                                                                   int64_t B, int64_t* __restrict__ lens) {
+  const int64_t b = (int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x;
+  if (b >= B) return;
+  const int64_t r = unsorted ? unsorted[b] : b;
+  int64_t lo = 0, hi = T;  // bsz non-increasing: count t with bsz[t] > r
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (bsz[mid] > r) lo = mid + 1; else hi = mid;
+  }
+  lens[b] = lo;
+}
+
+// ------------------------------------------------------------------ ptr() / idx()
+__global__ __launch_bounds__(RUA_BLOCK) void enum_rows_kernel(rua_layout L, int64_t n, int64_t* __restrict__ bp,
+                                                              int64_t* __restrict__ tp,
+                                                              int64_t* __restrict__ flat) {
+  const int64_t j = (int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x;
+  if (j >= n) return;
+  int64_t b, t, row;
+  if (L.kind == RUA_PACK) {
+    t = search_boff(L.boff, L.T, j);
+    int64_t r = j - L.boff[t];
+    b = L.sorted ? L.sorted[r] : r;
+    row = j;
+  } else {  // CAT / LEFT / RIGHT enumerate tokens batch-major
+    b = search_cat(L, j);
+    t = j - cat_off(L, b);
+    row = L.kind == RUA_CAT ? j : token_to_row(L, b, t, seq_len(L, b));
+  }
+  if (bp) bp[j] = b;
+  if (tp) tp[j] = t;
+  if (flat) flat[j] = row;
+}
+
+// ------------------------------------------------------------------ masks
+template <typename E>
+__global__ __launch_bounds__(RUA_BLOCK) void mask_kernel(const int64_t* __restrict__ lens, int64_t B, int64_t T,
+                                                         E* __restrict__ out, E zero, E one) {
+  const int64_t i = (int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x;
+  if (i >= B * T) return;
+  const int64_t b = i / T, t = i - b * T;
+  out[i] = t < lens[b] ? one : zero;
+}
+
+static inline unsigned grid_for(int64_t n) { return (unsigned)((n + RUA_BLOCK - 1) / RUA_BLOCK); }
+
+}  // namespace rua
+
+using namespace rua;
+
+extern "C" {
+
+int64_t rua_scan_ws_elems(int64_t n) { return n <= 0 ? 1 : (n + SCAN_TILE - 1) / SCAN_TILE + 1; }
+
+int rua_exclusive_scan_i64(const int64_t* in, int64_t* out, int64_t* total, int64_t n, int64_t* ws,
+                           void* stream) {
+  if (n < 0 || (n > 0 && (!in || !out))) return RUA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    if (total) return (int)hipMemsetAsync(total, 0, sizeof(int64_t), s);
+    return 0;
+  }
+  const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  if (nb > 0x7fffffffLL) return RUA_ERANGE;
+  if (nb == 1) {
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(1), dim3(RUA_BLOCK), 0, s, in, n, (const int64_t*)nullptr, out,
+                       total);
+    return (int)hipGetLastError();
+  }
+  if (!ws) return RUA_EINVAL;
+  hipLaunchKernelGGL(scan_partials_kernel, dim3((unsigned)nb), dim3(RUA_BLOCK), 0, s, in, n, ws);
+  hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(RUA_BLOCK), 0, s, ws, nb, total);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(RUA_BLOCK), 0, s, in, n, (const int64_t*)ws, out,
+                     (int64_t*)nullptr);
+  return (int)hipGetLastError();
+}
+
+int rua_pack_meta(const int64_t* lens, const int64_t* sorted, int64_t B, int64_t T, int64_t* unsorted,
+                  int64_t* bsz, void* stream) {
+  if (B < 0 || T < 0 || (B > 0 && (!lens || !sorted))) return RUA_EINVAL;
+  const int64_t n = B > T ? B : T;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(pack_meta_kernel, dim3(grid_for(n)), dim3(RUA_BLOCK), 0, (hipStream_t)stream, lens, sorted, B,
+                     T, unsorted, bsz);
+  return (int)hipGetLastError();
+}
+
+int rua_lens_from_pack(const int64_t* bsz, int64_t T, const int64_t* unsorted, int64_t B, int64_t* lens,
+                       void* stream) {
+  if (B < 0 || T < 0 || (B > 0 && !lens) || (T > 0 && !bsz)) return RUA_EINVAL;
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(lens_from_pack_kernel, dim3(grid_for(B)), dim3(RUA_BLOCK), 0, (hipStream_t)stream, bsz, T,
+                     unsorted, B, lens);
+  return (int)hipGetLastError();
+}
+
+int rua_enum_rows(const rua_layout* lay, int64_t n_tokens, int64_t* batch_ptr, int64_t* token_ptr, int64_t* flat,
+                  void* stream) {
+  if (!lay || n_tokens < 0) return RUA_EINVAL;
+  if (lay->kind == RUA_PACK) {
+    if (n_tokens > 0 && (!lay->boff || lay->T <= 0)) return RUA_EINVAL;
+  } else if (lay->kind == RUA_CAT || lay->kind == RUA_LEFT || lay->kind == RUA_RIGHT) {
+    if (n_tokens > 0 && lay->B <= 0) return RUA_EINVAL;
+    if (lay->lens && !lay->off) return RUA_EINVAL;
+  } else {
+    return RUA_EINVAL;
+  }
+  if (n_tokens == 0) return 0;
+  hipLaunchKernelGGL(enum_rows_kernel, dim3(grid_for(n_tokens)), dim3(RUA_BLOCK), 0, (hipStream_t)stream, *lay,
+                     n_tokens, batch_ptr, token_ptr, flat);
+  return (int)hipGetLastError();
+}
+
+int rua_mask(const int64_t* lens, int64_t B, int64_t T, void* out, int32_t elem_bytes, uint64_t zero_bits,
+             uint64_t one_bits, void* stream) {
+  if (B < 0 || T < 0) return RUA_EINVAL;
+  const int64_t n = B * T;
+  if (n == 0) return 0;
+  if (!lens || !out) return RUA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 g(grid_for(n)), blk(RUA_BLOCK);
+  switch (elem_bytes) {
+    case 1: hipLaunchKernelGGL(mask_kernel<uint8_t>, g, blk, 0, s, lens, B, T, (uint8_t*)out, (uint8_t)zero_bits, (uint8_t)one_bits); break;
+    case 2: hipLaunchKernelGGL(mask_kernel<uint16_t>, g, blk, 0, s, lens, B, T, (uint16_t*)out, (uint16_t)zero_bits, (uint16_t)one_bits); break;
+    case 4: hipLaunchKernelGGL(mask_kernel<uint32_t>, g, blk, 0, s, lens, B, T, (uint32_t*)out, (uint32_t)zero_bits, (uint32_t)one_bits); break;
+    case 8: hipLaunchKernelGGL(mask_kernel<uint64_t>, g, blk, 0, s, lens, B, T, (uint64_t*)out, (uint64_t)zero_bits, (uint64_t)one_bits); break;
+    default: return RUA_EINVAL;
+  }
+  return (int)hipGetLastError();
+}
+
+int rua_abi_version(void) { return RUA_ABI_VERSION; }
+const char* rua_build_target(void) { return "gfx950"; }
+
+}  // extern "C"

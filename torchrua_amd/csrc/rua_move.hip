@@ -1,0 +1,175 @@
+// rua_move.hip — the row mover: every layout conversion / select of the hot path as ONE
+// two-phase kernel (gfx950, wave64, HBM-bound; no MFMA — this is byte movement).
+//
+//   phase 1 (index generation, one lane per row): for the tile's 256 destination rows, turn
+//            row j -> token (b,t) -> source row with the closed forms of rua_dev.h; the
+//            (load_row, store_row) pairs are staged in LDS.  Integer work happens once per ROW.
+//   phase 2 (payload, one lane per 16 bytes): the 4 waves stream the tile, each wave
+//            instruction moving 1 KiB (64 lanes x dwordx4), 4 loads in flight per lane,
+//            addresses = LDS row index * row_bytes + column.  Padding rows store the fill
+//            pattern without loading, so padded outputs are written exactly once.
+//
+// Tiles are contiguous in the DESTINATION storage, so stores are perfectly coalesced and every
+// tile carries the same number of bytes (no ragged load imbalance); loads are row-granular
+// gathers (>= 128 B lines, 1 KiB at the north-star shape).
+#include "rua_dev.h"
+
+namespace rua {
+
+constexpr int TILE_ROWS = 256;  // == RUA_BLOCK: one lane per row in phase 1
+constexpr int UNROLL = 4;       // row groups in flight per wave in phase 2
+
+template <int VEC> struct vec_of;
+template <> struct vec_of<16> { using type = uint4; };
+template <> struct vec_of<8>  { using type = uint2; };
+template <> struct vec_of<4>  { using type = uint32_t; };
+template <> struct vec_of<2>  { using type = uint16_t; };
+template <> struct vec_of<1>  { using type = uint8_t; };
+
+template <int VEC> __device__ __forceinline__ typename vec_of<VEC>::type fill_of(uint4 p);
+template <> __device__ __forceinline__ uint4    fill_of<16>(uint4 p) { return p; }
+template <> __device__ __forceinline__ uint2    fill_of<8>(uint4 p)  { return make_uint2(p.x, p.y); }
+template <> __device__ __forceinline__ uint32_t fill_of<4>(uint4 p)  { return p.x; }
+template <> __device__ __forceinline__ uint16_t fill_of<2>(uint4 p)  { return (uint16_t)p.x; }
+template <> __device__ __forceinline__ uint8_t  fill_of<1>(uint4 p)  { return (uint8_t)p.x; }
+
+// lpr      : lanes (VEC-byte columns) per row = ceil(row_bytes / VEC)
+// lp_log2  : log2 of lanes a wave gives one row per instruction (<= 6); rows narrower than
+//            1 KiB share a wave instruction (64 >> lp_log2 rows at a time)
+// cpr      : 64-lane column chunks per row (1 unless row_bytes > 64*VEC)
+template <int VEC, bool SCATTER>
+__global__ __launch_bounds__(RUA_BLOCK) void move_rows_kernel(rua_layout D, rua_layout S, int32_t tmap,
+                                                              int64_t targ, char* __restrict__ dst,
+                                                              const char* __restrict__ src, int64_t row_bytes,
+                                                              int64_t lpr, int lp_log2, int cpr, uint4 fillpat) {
+  using V = typename vec_of<VEC>::type;
+  __shared__ int64_t s_ld[TILE_ROWS];
+  __shared__ int64_t s_st[TILE_ROWS];
+
+  const int64_t tile0 = (int64_t)blockIdx.x * TILE_ROWS;
+  const int64_t left = D.n_rows - tile0;
+  const int nrows = left < TILE_ROWS ? (int)left : TILE_ROWS;
+
+  // ---- phase 1: one lane per destination row
+  {
+    const int i = threadIdx.x;
+    if (i < nrows) {
+      const int64_t j = tile0 + i;
+      int64_t b, t, other = -1;
+      if (row_to_token(D, j, b, t)) {
+        const int64_t slen = seq_len(S, b);
+        const int64_t dlen = D.kind == RUA_LIST ? slen : seq_len(D, b);
+        const int64_t ts = apply_tmap(tmap, targ, t, slen, dlen);
+        if (ts >= 0 && ts < slen) other = token_to_row(S, b, ts, slen);
+      }
+      if (SCATTER) { s_ld[i] = j; s_st[i] = other; }   // enumerated rows are the source
+      else         { s_ld[i] = other; s_st[i] = j; }   // enumerated rows are the destination
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: stream the payload
+  const int lane = threadIdx.x & (RUA_WAVE - 1), wave = threadIdx.x >> 6;
+  const int rpw = RUA_WAVE >> lp_log2;           // rows per wave instruction
+  const int rsub = lane >> lp_log2;              // which of those rows this lane serves
+  const int64_t col0 = lane & ((1 << lp_log2) - 1);
+  const V fillv = fill_of<VEC>(fillpat);
+
+  for (int g0 = wave; g0 * rpw < nrows; g0 += RUA_WAVES_PER_BLOCK * UNROLL) {
+    for (int c = 0; c < cpr; ++c) {
+      const int64_t col = col0 + (int64_t)c * RUA_WAVE;
+      const bool colok = col < lpr;
+      V val[UNROLL];
+      int64_t st[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const int r = (g0 + u * RUA_WAVES_PER_BLOCK) * rpw + rsub;
+        st[u] = -1;
+        val[u] = fillv;
+        if (colok && r < nrows) {
+          const int64_t ld = s_ld[r];
+          st[u] = s_st[r];
+          if (ld >= 0 && st[u] >= 0) val[u] = *reinterpret_cast<const V*>(src + ld * row_bytes + col * VEC);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u)
+        if (st[u] >= 0) *reinterpret_cast<V*>(dst + st[u] * row_bytes + col * VEC) = val[u];
+    }
+  }
+}
+
+static int check_layout(const rua_layout* L, bool is_dst) {
+  if (!L) return RUA_EINVAL;
+  if (L->B < 0 || L->n_rows < 0) return RUA_EINVAL;
+  switch (L->kind) {
+    case RUA_CAT:
+      if (L->lens && !L->off) return RUA_EINVAL;
+      return 0;
+    case RUA_LEFT:
+    case RUA_RIGHT:
+      return L->T_phys >= 0 ? 0 : RUA_EINVAL;
+    case RUA_PACK:
+      if (L->T > 0 && !L->boff) return RUA_EINVAL;
+      return 0;
+    case RUA_LIST:
+      if (!is_dst) return RUA_EINVAL;
+      if (L->n_rows > 0 && (!L->bptr || !L->tptr)) return RUA_EINVAL;
+      return 0;
+  }
+  return RUA_EINVAL;
+}
+
+template <bool SCATTER>
+static int launch_move(int vec, unsigned grid, hipStream_t s, const rua_layout& D, const rua_layout& S, int32_t tmap,
+                       int64_t targ, char* dst, const char* src, int64_t row_bytes, uint4 fp) {
+  const int64_t lpr = (row_bytes + vec - 1) / vec;
+  int lp_log2 = 0;
+  while ((1 << lp_log2) < lpr && lp_log2 < 6) ++lp_log2;
+  const int cpr = (int)((lpr + RUA_WAVE - 1) / RUA_WAVE);
+  const dim3 g(grid), b(RUA_BLOCK);
+#define RUA_LAUNCH(VEC) \
+  hipLaunchKernelGGL((move_rows_kernel<VEC, SCATTER>), g, b, 0, s, D, S, tmap, targ, dst, src, row_bytes, lpr, lp_log2, cpr, fp)
+  switch (vec) {
+    case 16: RUA_LAUNCH(16); break;
+    case 8:  RUA_LAUNCH(8); break;
+    case 4:  RUA_LAUNCH(4); break;
+    case 2:  RUA_LAUNCH(2); break;
+    default: RUA_LAUNCH(1); break;
+  }
+#undef RUA_LAUNCH
+  return (int)hipGetLastError();
+}
+
+}  // namespace rua
+
+using namespace rua;
+
+extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32_t tmap, int64_t tmap_arg,
+                             void* dst_data, const void* src_data, int64_t row_bytes, const void* fill16,
+                             int32_t flags, void* stream) {
+  int e;
+  if ((e = check_layout(dst, true)) != 0) return e;
+  if ((e = check_layout(src, false)) != 0) return e;
+  if (tmap < RUA_T_SHIFT || tmap > RUA_T_ZERO || row_bytes < 0) return RUA_EINVAL;
+  if (dst->n_rows == 0 || row_bytes == 0) return 0;
+  if (!dst_data || !src_data) return RUA_EINVAL;
+  const int64_t ntiles = (dst->n_rows + TILE_ROWS - 1) / TILE_ROWS;
+  if (ntiles > 0x7fffffffLL) return RUA_ERANGE;
+
+  // widest power-of-two access that divides the row size and both base addresses
+  const uint64_t mix = (uint64_t)row_bytes | (uint64_t)(uintptr_t)dst_data | (uint64_t)(uintptr_t)src_data | 16u;
+  const int vec = (int)(mix & (~mix + 1));
+
+  uint4 fp = make_uint4(0, 0, 0, 0);
+  if (fill16) {
+    const uint32_t* f = (const uint32_t*)fill16;
+    fp = make_uint4(f[0], f[1], f[2], f[3]);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (flags & RUA_MOVE_SCATTER)
+    return launch_move<true>(vec, (unsigned)ntiles, s, *dst, *src, tmap, tmap_arg, (char*)dst_data,
+                             (const char*)src_data, row_bytes, fp);
+  return launch_move<false>(vec, (unsigned)ntiles, s, *dst, *src, tmap, tmap_arg, (char*)dst_data,
+                            (const char*)src_data, row_bytes, fp);
+}

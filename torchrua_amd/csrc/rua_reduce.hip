@@ -1,0 +1,347 @@
+// rua_reduce.hip — segmented reductions over the sequences of ANY layout (gfx950, wave64).
+//
+// One wave owns one (sequence, 64-lane column chunk): lanes are spread over the hidden
+// dimension with 16-byte loads (8 x bf16 / 4 x f32 per lane), rows of the sequence are walked
+// in t with UNROLL_T rows in flight, accumulation is fp32 (fp64 for f64) in registers, and the
+// result is rounded ONCE on the way out.  Rows narrower than 1 KiB share a wave instruction
+// (several t per instruction) and are combined with a butterfly at the end.  No atomics on the
+// data path, no LDS traffic: the kernel is a pure HBM stream of N*H*e bytes + S*H*e out.
+//
+// Row addressing per layout (include/rua.h): CAT off[b]+t (contiguous), PACK boff[t]+rank[b]
+// (stride varies with t), LEFT/RIGHT b*T+t(+pad), and CAT+perm for the bucketed scatter_*.
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include "rua_dev.h"
+
+namespace rua {
+
+constexpr int UNROLL_T = 8;
+constexpr int EXTREME_SLOTS = 64;  // contention spreading for the global min/max tracker
+
+// ---------------------------------------------------------------- element conversion
+template <typename T> struct elem;
+template <> struct elem<float> {
+  using acc = float;
+  static __device__ __forceinline__ float up(float v) { return v; }
+  static __device__ __forceinline__ float down(float v) { return v; }
+};
+template <> struct elem<double> {
+  using acc = double;
+  static __device__ __forceinline__ double up(double v) { return v; }
+  static __device__ __forceinline__ double down(double v) { return v; }
+};
+template <> struct elem<__hip_bfloat16> {
+  using acc = float;
+  static __device__ __forceinline__ float up(__hip_bfloat16 v) { return __bfloat162float(v); }
+  static __device__ __forceinline__ __hip_bfloat16 down(float v) { return __float2bfloat16(v); }
+};
+template <> struct elem<__half> {
+  using acc = float;
+  static __device__ __forceinline__ float up(__half v) { return __half2float(v); }
+  static __device__ __forceinline__ __half down(float v) { return __float2half(v); }
+};
+
+template <typename A> __device__ __forceinline__ A acc_inf();
+template <> __device__ __forceinline__ float acc_inf<float>() { return __builtin_inff(); }
+template <> __device__ __forceinline__ double acc_inf<double>() { return __builtin_inf(); }
+
+// NaN-propagating max/min (torch.segment_reduce / index_reduce semantics)
+template <typename A> __device__ __forceinline__ A nmax(A a, A b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
+template <typename A> __device__ __forceinline__ A nmin(A a, A b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
+
+__device__ __forceinline__ float fexp(float x) { return __expf(x); }
+__device__ __forceinline__ double fexp(double x) { return exp(x); }
+__device__ __forceinline__ float flog(float x) { return logf(x); }
+__device__ __forceinline__ double flog(double x) { return log(x); }
+
+// order-preserving map float -> unsigned so integer atomics give float min/max
+__device__ __forceinline__ uint64_t ordered_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? (uint32_t)~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ uint64_t ordered_bits(double f) {
+  uint64_t u = (uint64_t)__double_as_longlong(f);
+  return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ float unordered_f32(uint64_t o) {
+  uint32_t u = (uint32_t)o;
+  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ double unordered_f64(uint64_t u) {
+  u = (u & 0x8000000000000000ull) ? (u & 0x7fffffffffffffffull) : ~u;
+  return __longlong_as_double((long long)u);
+}
+
+// ---------------------------------------------------------------- the kernel
+// EPL: elements per lane per load (16 B / sizeof(T) on the vector path, 1 on the scalar path)
+template <typename T, int EPL, int OP>
+__global__ __launch_bounds__(RUA_BLOCK) void seg_reduce_kernel(rua_layout L, const int64_t* __restrict__ perm,
+                                                               const T* __restrict__ data, T* __restrict__ out,
+                                                               int64_t H, int lp_log2, int64_t n_chunks,
+                                                               int include_self, T empty_val,
+                                                               unsigned long long* __restrict__ extreme) {
+  using A = typename elem<T>::acc;
+  struct alignas(sizeof(T) * EPL) Pack { T v[EPL]; };
+
+  const int lane = threadIdx.x & (RUA_WAVE - 1), wave = threadIdx.x >> 6;
+  const int64_t wid = (int64_t)blockIdx.x * RUA_WAVES_PER_BLOCK + wave;
+  const int64_t b = wid / n_chunks;
+  if (b >= L.B) return;  // wave-uniform
+  const int64_t chunk = wid - b * n_chunks;
+
+  const int rpw = RUA_WAVE >> lp_log2;
+  const int rsub = lane >> lp_log2;
+  const int64_t col = (chunk * RUA_WAVE + (lane & ((1 << lp_log2) - 1))) * EPL;
+  const bool colok = col < H;
+
+  const int64_t len = seq_len(L, b);
+  // row(t) = base + (tbl ? tbl[tb + t] : t)
+  int64_t base = 0, tb = 0;
+  const int64_t* __restrict__ tbl = nullptr;
+  switch (L.kind) {
+    case RUA_CAT:
+      if (perm) { tbl = perm; tb = cat_off(L, b); } else base = cat_off(L, b);
+      break;
+    case RUA_PACK:  tbl = L.boff; base = L.unsorted ? L.unsorted[b] : b; break;
+    case RUA_LEFT:  base = b * L.T_phys; break;
+    case RUA_RIGHT: base = b * L.T_phys + (L.T_log - len); break;
+  }
+
+  A acc[EPL], aux[EPL];  // aux: running sum for LOGSUMEXP (acc holds the running max)
+  A ext = (OP == RUA_MAX || OP == RUA_LOGSUMEXP) ? acc_inf<A>() : -acc_inf<A>();
+  bool ext_nan = false;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    acc[e] = (OP == RUA_PROD) ? (A)1 : (OP == RUA_MAX || OP == RUA_LOGSUMEXP) ? -acc_inf<A>()
+           : (OP == RUA_MIN) ? acc_inf<A>() : (A)0;
+    aux[e] = (A)0;
+  }
+
+  for (int64_t t0 = 0; t0 < len; t0 += (int64_t)rpw * UNROLL_T) {
+    int64_t row[UNROLL_T];
+    Pack p[UNROLL_T];
+#pragma unroll
+    for (int u = 0; u < UNROLL_T; ++u) {
+      const int64_t t = t0 + (int64_t)u * rpw + rsub;
+      row[u] = -1;
+      if (colok && t < len) row[u] = base + (tbl ? tbl[tb + t] : t);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL_T; ++u)
+      if (row[u] >= 0) p[u] = *reinterpret_cast<const Pack*>(data + row[u] * H + col);
+#pragma unroll
+    for (int u = 0; u < UNROLL_T; ++u) {
+      if (row[u] < 0) continue;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        const A x = elem<T>::up(p[u].v[e]);
+        if (OP == RUA_SUM || OP == RUA_MEAN) acc[e] += x;
+        else if (OP == RUA_PROD) acc[e] *= x;
+        else if (OP == RUA_MAX) acc[e] = nmax(acc[e], x);
+        else if (OP == RUA_MIN) acc[e] = nmin(acc[e], x);
+        else {  // online logsumexp: acc = running max m, aux = sum exp(x - m)
+          if (x > acc[e]) { aux[e] = aux[e] * fexp(acc[e] - x) + (A)1; acc[e] = x; }
+          else if (x == x) aux[e] += fexp(x - acc[e]);
+          else { acc[e] = x; aux[e] = x; }  // NaN poisons
+        }
+        if (OP == RUA_MAX || OP == RUA_LOGSUMEXP) { ext = x < ext ? x : ext; ext_nan |= (x != x); }
+        if (OP == RUA_MIN) { ext = x > ext ? x : ext; ext_nan |= (x != x); }
+      }
+    }
+  }
+
+  // combine the rpw row-groups of the wave (lanes that differ in the bits above lp_log2)
+  for (int d = 1 << lp_log2; d < RUA_WAVE; d <<= 1) {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      const A o = __shfl_xor(acc[e], d, RUA_WAVE);
+      if (OP == RUA_SUM || OP == RUA_MEAN) acc[e] += o;
+      else if (OP == RUA_PROD) acc[e] *= o;
+      else if (OP == RUA_MAX) acc[e] = nmax(acc[e], o);
+      else if (OP == RUA_MIN) acc[e] = nmin(acc[e], o);
+      else {
+        const A os = __shfl_xor(aux[e], d, RUA_WAVE);
+        const A m = nmax(acc[e], o);
+        if (m == -acc_inf<A>()) { aux[e] = aux[e] + os; }       // both empty so far
+        else { aux[e] = aux[e] * fexp(acc[e] - m) + os * fexp(o - m); }
+        acc[e] = m;
+      }
+    }
+  }
+
+  // include_self: 0 = overwrite (empty sequence -> empty_val), 1 = fold the old out[b] in,
+  //               2 = leave out[b] untouched when the sequence is empty (index_reduce semantics)
+  const bool keep = include_self == 2 && len <= 0;
+  include_self = include_self == 1;
+  if (colok && rsub == 0 && !keep) {
+    T* o = out + b * H + col;
+    const int64_t cnt = len + (include_self ? 1 : 0);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      A r = acc[e];
+      if (OP == RUA_LOGSUMEXP) {
+        if (include_self) {  // fold exp(self) in
+          const A x = elem<T>::up(o[e]);
+          const A m = nmax(r, x);
+          aux[e] = aux[e] * fexp(r - m) + fexp(x - m);
+          r = m;
+        }
+        r = flog(aux[e]) + r;
+      } else if (include_self) {
+        const A x = elem<T>::up(o[e]);
+        if (OP == RUA_SUM || OP == RUA_MEAN) r += x;
+        else if (OP == RUA_PROD) r *= x;
+        else if (OP == RUA_MAX) r = nmax(r, x);
+        else if (OP == RUA_MIN) r = nmin(r, x);
+      }
+      if (OP == RUA_MEAN && cnt > 0) r = r / (A)cnt;
+      o[e] = (cnt == 0) ? empty_val : elem<T>::down(r);
+    }
+  }
+
+  if (extreme && (OP == RUA_MAX || OP == RUA_MIN || OP == RUA_LOGSUMEXP)) {
+    // wave-level fold, then ONE no-return integer atomic per wave into a hashed slot
+#pragma unroll
+    for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {
+      const A o = __shfl_xor(ext, d, RUA_WAVE);
+      if (OP == RUA_MIN) ext = o > ext ? o : ext; else ext = o < ext ? o : ext;
+    }
+    const bool any_nan = __any(ext_nan);
+    if (lane == 0 && len > 0) {
+      const int slot = (int)(wid & (EXTREME_SLOTS - 1));
+      if (OP == RUA_MIN) atomicMax(&extreme[slot], (unsigned long long)ordered_bits(ext));
+      else atomicMin(&extreme[slot], (unsigned long long)ordered_bits(ext));
+      if (any_nan) atomicOr(&extreme[EXTREME_SLOTS], 1ull);
+    }
+  }
+}
+
+// extreme scratch: [0..63] hashed ordered-bit slots, [64] NaN flag
+__global__ void extreme_init_kernel(unsigned long long* ext, int want_max_of_data) {
+  const int i = threadIdx.x;
+  if (i < EXTREME_SLOTS) ext[i] = want_max_of_data ? 0ull : ~0ull;
+  if (i == EXTREME_SLOTS) ext[i] = 0ull;
+}
+
+template <typename T>
+__global__ __launch_bounds__(RUA_BLOCK) void fill_empty_kernel(rua_layout L, T* __restrict__ out, int64_t H,
+                                                               int want_max_of_data,
+                                                               const unsigned long long* __restrict__ ext) {
+  using A = typename elem<T>::acc;
+  // decode the tracked extreme (all threads, 65 cached loads)
+  unsigned long long best = ext[0];
+  for (int i = 1; i < EXTREME_SLOTS; ++i) {
+    const unsigned long long v = ext[i];
+    best = want_max_of_data ? (v > best ? v : best) : (v < best ? v : best);
+  }
+  const bool poison = ext[EXTREME_SLOTS] != 0ull;
+  A val;
+  if (sizeof(A) == 8) val = (A)unordered_f64(best); else val = (A)unordered_f32(best);
+  if (poison) val = val - val + (A)__builtin_nanf("");
+  const T tv = elem<T>::down(val);
+
+  const int64_t i = (int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x;
+  if (i >= L.B * H) return;
+  const int64_t b = i / H;
+  if (poison || seq_len(L, b) <= 0) out[i] = tv;
+}
+
+static inline unsigned grid_for(int64_t n) { return (unsigned)((n + RUA_BLOCK - 1) / RUA_BLOCK); }
+
+template <typename T, int EPL>
+static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout& L, const int64_t* perm,
+                         const void* data, void* out, int64_t H, int lp_log2, int64_t n_chunks, int include_self,
+                         uint64_t empty_bits, void* extreme) {
+  T ev;
+  __builtin_memcpy(&ev, &empty_bits, sizeof(T));
+  const dim3 g(grid), b(RUA_BLOCK);
+#define RUA_LAUNCH(OP)                                                                                          \
+  hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP>), g, b, 0, s, L, perm, (const T*)data, (T*)out, H, lp_log2, \
+                     n_chunks, include_self, ev, (unsigned long long*)extreme)
+  switch (op) {
+    case RUA_SUM: RUA_LAUNCH(RUA_SUM); break;
+    case RUA_MEAN: RUA_LAUNCH(RUA_MEAN); break;
+    case RUA_MAX: RUA_LAUNCH(RUA_MAX); break;
+    case RUA_MIN: RUA_LAUNCH(RUA_MIN); break;
+    case RUA_PROD: RUA_LAUNCH(RUA_PROD); break;
+    case RUA_LOGSUMEXP: RUA_LAUNCH(RUA_LOGSUMEXP); break;
+    default: return RUA_EINVAL;
+  }
+#undef RUA_LAUNCH
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,
+                           void* out, int64_t H, int include_self, uint64_t empty_bits, void* extreme) {
+  constexpr int FULL = 16 / sizeof(T);
+  const bool vec_ok = (H % FULL == 0) && (((uintptr_t)data | (uintptr_t)out) % 16 == 0);
+  const int epl = vec_ok ? FULL : 1;
+  const int64_t lpr = (H + epl - 1) / epl;  // lanes per row
+  int lp_log2 = 0;
+  while ((1 << lp_log2) < lpr && lp_log2 < 6) ++lp_log2;
+  const int64_t n_chunks = (lpr + RUA_WAVE - 1) / RUA_WAVE;
+  const int64_t waves = L.B * n_chunks;
+  const int64_t blocks = (waves + RUA_WAVES_PER_BLOCK - 1) / RUA_WAVES_PER_BLOCK;
+  if (blocks > 0x7fffffffLL) return RUA_ERANGE;
+  if (vec_ok)
+    return launch_reduce<T, FULL>(op, (unsigned)blocks, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
+                                  empty_bits, extreme);
+  return launch_reduce<T, 1>(op, (unsigned)blocks, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
+                             empty_bits, extreme);
+}
+
+}  // namespace rua
+
+using namespace rua;
+
+extern "C" {
+
+int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* data, void* out, int64_t H,
+                       int32_t dtype, int32_t op, int32_t include_self, uint64_t empty_bits, void* extreme,
+                       void* stream) {
+  if (!lay || H < 0 || lay->B < 0) return RUA_EINVAL;
+  if (lay->kind != RUA_CAT && lay->kind != RUA_PACK && lay->kind != RUA_LEFT && lay->kind != RUA_RIGHT)
+    return RUA_EINVAL;
+  if (lay->kind == RUA_CAT && lay->lens && !lay->off) return RUA_EINVAL;
+  if (lay->kind == RUA_PACK && lay->T > 0 && !lay->boff) return RUA_EINVAL;
+  if (perm && lay->kind != RUA_CAT) return RUA_EINVAL;
+  if (lay->B == 0 || H == 0) return 0;
+  if (!out || (lay->n_rows > 0 && !data)) return RUA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (extreme && (op == RUA_MAX || op == RUA_MIN || op == RUA_LOGSUMEXP)) {
+    hipLaunchKernelGGL(extreme_init_kernel, dim3(1), dim3(128), 0, s, (unsigned long long*)extreme,
+                       op == RUA_MIN ? 1 : 0);
+  }
+  switch (dtype) {
+    case RUA_F32: return dispatch_reduce<float>(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme);
+    case RUA_BF16: return dispatch_reduce<__hip_bfloat16>(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme);
+    case RUA_F16: return dispatch_reduce<__half>(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme);
+    case RUA_F64: return dispatch_reduce<double>(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme);
+  }
+  return RUA_EINVAL;
+}
+
+int rua_fill_empty(const rua_layout* lay, void* out, int64_t H, int32_t dtype, int32_t op, const void* extreme,
+                   void* stream) {
+  if (!lay || H < 0 || !extreme) return RUA_EINVAL;
+  if (op != RUA_MAX && op != RUA_MIN && op != RUA_LOGSUMEXP) return RUA_EINVAL;
+  const int64_t n = lay->B * H;
+  if (n == 0) return 0;
+  if (!out) return RUA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 g(grid_for(n)), b(RUA_BLOCK);
+  const int wmax = op == RUA_MIN ? 1 : 0;
+  const unsigned long long* e = (const unsigned long long*)extreme;
+  switch (dtype) {
+    case RUA_F32: hipLaunchKernelGGL(fill_empty_kernel<float>, g, b, 0, s, *lay, (float*)out, H, wmax, e); break;
+    case RUA_BF16: hipLaunchKernelGGL(fill_empty_kernel<__hip_bfloat16>, g, b, 0, s, *lay, (__hip_bfloat16*)out, H, wmax, e); break;
+    case RUA_F16: hipLaunchKernelGGL(fill_empty_kernel<__half>, g, b, 0, s, *lay, (__half*)out, H, wmax, e); break;
+    case RUA_F64: hipLaunchKernelGGL(fill_empty_kernel<double>, g, b, 0, s, *lay, (double*)out, H, wmax, e); break;
+    default: return RUA_EINVAL;
+  }
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"
