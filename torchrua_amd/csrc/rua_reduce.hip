@@ -76,19 +76,24 @@ __device__ __forceinline__ double unordered_f64(uint64_t u) {
 // ---------------------------------------------------------------- the kernel
 // EPL: elements per lane per load (16 B / sizeof(T) on the vector path, 1 on the scalar path)
 template <typename T, int EPL, int OP>
-__global__ __launch_bounds__(RUA_BLOCK) void seg_reduce_kernel(rua_layout L, const int64_t* __restrict__ perm,
-                                                               const T* __restrict__ data, T* __restrict__ out,
-                                                               int64_t H, int lp_log2, int64_t n_chunks,
-                                                               int include_self, T empty_val,
-                                                               unsigned long long* __restrict__ extreme) {
+__global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, const int64_t* __restrict__ perm,
+                                                              const T* __restrict__ data, T* __restrict__ out,
+                                                              int64_t H, int lp_log2, int64_t n_chunks,
+                                                              int include_self, T empty_val,
+                                                              unsigned long long* __restrict__ extreme) {
   using A = typename elem<T>::acc;
   struct alignas(sizeof(T) * EPL) Pack { T v[EPL]; };
 
-  const int lane = threadIdx.x & (RUA_WAVE - 1), wave = threadIdx.x >> 6;
-  const int64_t wid = (int64_t)blockIdx.x * RUA_WAVES_PER_BLOCK + wave;
-  const int64_t b = wid / n_chunks;
-  if (b >= L.B) return;  // wave-uniform
-  const int64_t chunk = wid - b * n_chunks;
+  // ONE wave per workgroup: sequences differ in length, and a multi-wave workgroup would hold
+  // its CU slots until its longest sequence is done.
+  const int lane = threadIdx.x;
+  const int64_t wid = blockIdx.x;
+  const int64_t q = wid / n_chunks;          // sequence slot
+  if (q >= L.B) return;
+  const int64_t chunk = wid - q * n_chunks;
+  // PACK is walked in rank order (longest first = LPT schedule; neighbouring workgroups read
+  // neighbouring rows of every time step), everything else in batch order.
+  const int64_t b = (L.kind == RUA_PACK && L.sorted) ? L.sorted[q] : q;
 
   const int rpw = RUA_WAVE >> lp_log2;
   const int rsub = lane >> lp_log2;
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(RUA_BLOCK) void seg_reduce_kernel(rua_layout L, con
     case RUA_CAT:
       if (perm) { tbl = perm; tb = cat_off(L, b); } else base = cat_off(L, b);
       break;
-    case RUA_PACK:  tbl = L.boff; base = L.unsorted ? L.unsorted[b] : b; break;
+    case RUA_PACK:  tbl = L.boff; base = L.sorted ? q : (L.unsorted ? L.unsorted[b] : b); break;
     case RUA_LEFT:  base = b * L.T_phys; break;
     case RUA_RIGHT: base = b * L.T_phys + (L.T_log - len); break;
   }
@@ -118,37 +123,48 @@ __global__ __launch_bounds__(RUA_BLOCK) void seg_reduce_kernel(rua_layout L, con
     aux[e] = (A)0;
   }
 
-  for (int64_t t0 = 0; t0 < len; t0 += (int64_t)rpw * UNROLL_T) {
-    int64_t row[UNROLL_T];
-    Pack p[UNROLL_T];
+  // the row table (boff / perm) is fetched 64 entries at a time with one coalesced load and
+  // handed to the lanes by ds_bpermute; the next block's entries are in flight while this
+  // block's payload streams.
+  int64_t tv = (tbl && lane < len) ? tbl[tb + lane] : 0;
+  for (int64_t tblk = 0; tblk < len; tblk += RUA_WAVE) {
+    const int64_t nxt = tblk + RUA_WAVE + lane;
+    const int64_t tv_next = (tbl && nxt < len) ? tbl[tb + nxt] : 0;
+    const int nblk = (len - tblk) < RUA_WAVE ? (int)(len - tblk) : RUA_WAVE;
+    for (int k = 0; k < nblk; k += rpw * UNROLL_T) {
+      int64_t row[UNROLL_T];
+      Pack p[UNROLL_T];
 #pragma unroll
-    for (int u = 0; u < UNROLL_T; ++u) {
-      const int64_t t = t0 + (int64_t)u * rpw + rsub;
-      row[u] = -1;
-      if (colok && t < len) row[u] = base + (tbl ? tbl[tb + t] : t);
-    }
+      for (int u = 0; u < UNROLL_T; ++u) {
+        const int tl = k + u * rpw + rsub;
+        const int64_t tabv = __shfl(tv, tl & (RUA_WAVE - 1), RUA_WAVE);
+        row[u] = -1;
+        if (colok && tl < nblk) row[u] = base + (tbl ? tabv : tblk + tl);
+      }
 #pragma unroll
-    for (int u = 0; u < UNROLL_T; ++u)
-      if (row[u] >= 0) p[u] = *reinterpret_cast<const Pack*>(data + row[u] * H + col);
+      for (int u = 0; u < UNROLL_T; ++u)
+        if (row[u] >= 0) p[u] = *reinterpret_cast<const Pack*>(data + row[u] * H + col);
 #pragma unroll
-    for (int u = 0; u < UNROLL_T; ++u) {
-      if (row[u] < 0) continue;
+      for (int u = 0; u < UNROLL_T; ++u) {
+        if (row[u] < 0) continue;
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) {
-        const A x = elem<T>::up(p[u].v[e]);
-        if (OP == RUA_SUM || OP == RUA_MEAN) acc[e] += x;
-        else if (OP == RUA_PROD) acc[e] *= x;
-        else if (OP == RUA_MAX) acc[e] = nmax(acc[e], x);
-        else if (OP == RUA_MIN) acc[e] = nmin(acc[e], x);
-        else {  // online logsumexp: acc = running max m, aux = sum exp(x - m)
-          if (x > acc[e]) { aux[e] = aux[e] * fexp(acc[e] - x) + (A)1; acc[e] = x; }
-          else if (x == x) aux[e] += fexp(x - acc[e]);
-          else { acc[e] = x; aux[e] = x; }  // NaN poisons
+        for (int e = 0; e < EPL; ++e) {
+          const A x = elem<T>::up(p[u].v[e]);
+          if (OP == RUA_SUM || OP == RUA_MEAN) acc[e] += x;
+          else if (OP == RUA_PROD) acc[e] *= x;
+          else if (OP == RUA_MAX) acc[e] = nmax(acc[e], x);
+          else if (OP == RUA_MIN) acc[e] = nmin(acc[e], x);
+          else {  // online logsumexp: acc = running max m, aux = sum exp(x - m)
+            if (x > acc[e]) { aux[e] = aux[e] * fexp(acc[e] - x) + (A)1; acc[e] = x; }
+            else if (x == x) aux[e] += fexp(x - acc[e]);
+            else { acc[e] = x; aux[e] = x; }  // NaN poisons
+          }
+          if (OP == RUA_MAX || OP == RUA_LOGSUMEXP) { ext = x < ext ? x : ext; ext_nan |= (x != x); }
+          if (OP == RUA_MIN) { ext = x > ext ? x : ext; ext_nan |= (x != x); }
         }
-        if (OP == RUA_MAX || OP == RUA_LOGSUMEXP) { ext = x < ext ? x : ext; ext_nan |= (x != x); }
-        if (OP == RUA_MIN) { ext = x > ext ? x : ext; ext_nan |= (x != x); }
       }
     }
+    tv = tv_next;
   }
 
   // combine the rpw row-groups of the wave (lanes that differ in the bits above lp_log2)
@@ -255,7 +271,7 @@ static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout&
                          uint64_t empty_bits, void* extreme) {
   T ev;
   __builtin_memcpy(&ev, &empty_bits, sizeof(T));
-  const dim3 g(grid), b(RUA_BLOCK);
+  const dim3 g(grid), b(RUA_WAVE);
 #define RUA_LAUNCH(OP)                                                                                          \
   hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP>), g, b, 0, s, L, perm, (const T*)data, (T*)out, H, lp_log2, \
                      n_chunks, include_self, ev, (unsigned long long*)extreme)
@@ -282,8 +298,7 @@ static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int
   int lp_log2 = 0;
   while ((1 << lp_log2) < lpr && lp_log2 < 6) ++lp_log2;
   const int64_t n_chunks = (lpr + RUA_WAVE - 1) / RUA_WAVE;
-  const int64_t waves = L.B * n_chunks;
-  const int64_t blocks = (waves + RUA_WAVES_PER_BLOCK - 1) / RUA_WAVES_PER_BLOCK;
+  const int64_t blocks = L.B * n_chunks;  // one wave per workgroup
   if (blocks > 0x7fffffffLL) return RUA_ERANGE;
   if (vec_ok)
     return launch_reduce<T, FULL>(op, (unsigned)blocks, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
