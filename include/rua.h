@@ -61,7 +61,8 @@ typedef struct rua_layout {
   int64_t T;               /* PACK: number of time steps                    */
   const int64_t* sorted;   /* PACK: sorted_indices [B]                      */
   const int64_t* unsorted; /* PACK: unsorted_indices [B]                    */
-  const int64_t* bptr;     /* LIST: [M]                                     */
+  const int64_t* bptr;     /* LIST: [M]; NULL = all zeros (tptr then indexes ONE sequence,
+                              e.g. a flat row gather `data[key]` against LEFT{B=1})      */
   const int64_t* tptr;     /* LIST: [M]                                     */
 } rua_layout;
 
@@ -112,10 +113,13 @@ int rua_mask(const int64_t* lens, int64_t B, int64_t T, void* out, int32_t elem_
  * Replaces every conversion in core/cast.py:8-71 (+ the new_full pre-fill of core/view.py:34-38,
  * 67-71: padding and payload are written in ONE pass), core/get.py / core/set.py tuple-key
  * indexing, select/head.py, select/last.py, select/roll.py, select/rev.py, select/trunc.py.
- * `fill16` is the fill element replicated to 16 bytes. Rows are row_bytes wide on both sides. */
+ * `fill16` is the fill element replicated to 16 bytes. Rows are row_bytes wide on both sides.
+ * `pad_row` >= 0 makes PADDING rows of a LEFT/RIGHT destination copies of that source storage
+ * row instead of `fill16` (select/roll.py:19-23,33-37: the reference pads its index tensor with
+ * 0, so its padding rows come out as copies of storage row 0); -1 = use the fill. */
 int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32_t tmap, int64_t tmap_arg,
                   void* dst_data, const void* src_data, int64_t row_bytes,
-                  const void* fill16, int32_t flags, void* stream);
+                  const void* fill16, int64_t pad_row, int32_t flags, void* stream);
 
 /* ---- reductions ------------------------------------------------------------ */
 enum rua_dtype { RUA_F32 = 0, RUA_BF16 = 1, RUA_F16 = 2, RUA_F64 = 3 };

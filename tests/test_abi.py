@@ -1,0 +1,89 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol include/rua.h
+declares, the Python surface carries the reference's names, and nothing computes off-GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import torchrua_amd as ta
+from torchrua_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, 'include', 'rua.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(rua_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _header_functions()
+    assert len(names) >= 12
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in include/rua.h but not exported'
+    assert sorted(_lib.SYMBOLS) == names, 'ctypes table and header disagree'
+    loaded = _lib.load()
+    assert loaded.rua_abi_version() == 1
+    assert loaded.rua_build_target() == b'gfx950'
+    assert loaded.rua_scan_ws_elems(1) >= 1 and loaded.rua_scan_ws_elems(1 << 20) >= 512
+
+
+def test_layout_struct_matches_header_size():
+    # 15 fields, all 8-byte aligned after the two int32s
+    assert ctypes.sizeof(_lib.RuaLayout) == 8 + 13 * 8
+
+
+def test_reference_surface_is_present():
+    """symbols a replacement must export."""
+    for n in ('C L P R T Z CattedSequence LeftAlignedSequence RightAlignedSequence PackedSequence '
+              'major_sizes_to_ptr get_offsets invert_permutation get_mask compose '
+              'segment_max segment_min segment_sum segment_mean segment_prod segment_logsumexp segment_head '
+              'segment_last scatter_max scatter_min scatter_sum scatter_mean scatter_prod scatter_logsumexp').split():
+        assert hasattr(ta, n), n
+    methods = ('new cat left pack right cat_view left_view pack_view right_view size ptr idx offsets raw '
+               '__getitem__ __setitem__ head last roll rev trunc seg mask bmask fmask split tolist').split()
+    for cls in (ta.C, ta.L, ta.P, ta.R):
+        for m in methods:
+            assert hasattr(cls, m), f'{cls.__name__}.{m}'
+    for cls in (ta.C, ta.L, ta.R):
+        for m in 'to double float half long int short char byte cpu cuda detach'.split():
+            assert hasattr(cls, m), f'{cls.__name__}.{m}'
+    assert ta.C._fields == ('data', 'token_sizes') == ta.L._fields == ta.R._fields
+    assert ta.P is torch.nn.utils.rnn.PackedSequence
+
+
+def test_no_cpu_fallback():
+    """The product path fails loudly off-GPU instead of computing on the host."""
+    seqs = [torch.randn(3, 2), torch.randn(2, 2)]
+    c = ta.C.new(seqs)                      # construction is plain torch.cat
+    assert c.data.shape == (5, 2) and c.token_sizes.tolist() == [3, 2]
+    for call in (c.pack, c.left, c.right, lambda: c.roll(1), c.last, lambda: c.head(1), c.ptr,
+                 lambda: ta.segment_sum(c.data, c.token_sizes),
+                 lambda: ta.scatter_sum(torch.zeros(2, 2), torch.tensor([0, 1, 1, 0, 0]), c.data),
+                 lambda: ta.get_offsets(c.token_sizes)):
+        with pytest.raises(ta.RuaError):
+            call()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'torchrua_amd')
+    for name in os.listdir(pkg):
+        if name.endswith('.py'):
+            text = open(os.path.join(pkg, name)).read()
+            assert 'oracle' not in text.replace('the oracle', ''), f'{name} mentions the oracle'
+
+
+def test_host_metadata_helpers():
+    from torchrua_amd import _meta as M
+    lens = torch.tensor([2, 4, 1, 3])
+    assert M.batch_sizes_from_host_lens(lens, 4).tolist() == [4, 3, 2, 1]
+    assert M.batch_sizes_from_host_lens(torch.tensor([3, 3]), 3).tolist() == [2, 2, 2]
+    t = torch.zeros(3)
+    M._memo_put(t, 'k', 7)
+    assert M._memo_get(t, 'k') == 7
+    t.add_(1)                                # in-place edit invalidates what was derived from it
+    assert M._memo_get(t, 'k') is None

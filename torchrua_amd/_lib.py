@@ -49,7 +49,7 @@ SYMBOLS = {
     'rua_enum_rows': (c_int, [POINTER(RuaLayout), c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rua_mask': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int32, c_uint64, c_uint64, c_void_p]),
     'rua_move_rows': (c_int, [POINTER(RuaLayout), POINTER(RuaLayout), c_int32, c_int64, c_void_p, c_void_p,
-                              c_int64, c_void_p, c_int32, c_void_p]),
+                              c_int64, c_void_p, c_int64, c_int32, c_void_p]),
     'rua_segment_reduce': (c_int, [POINTER(RuaLayout), c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                                    c_int32, c_uint64, c_void_p, c_void_p]),
     'rua_fill_empty': (c_int, [POINTER(RuaLayout), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),

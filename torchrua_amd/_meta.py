@@ -1,0 +1,233 @@
+"""Host-side bookkeeping for the kernels: derived index vectors (offsets, batch offsets, lengths of
+a PackedSequence), host mirrors of length vectors, and `rua_layout` descriptors.
+
+Derived vectors are produced by the HIP kernels (K1/K3/K3b in include/rua.h) and memoised ON THE
+TENSOR OBJECT they were derived from (guarded by the tensor's `_version`), so a chain like
+`c.pack().roll(1).cat()` — forward and backward — scans each length vector once.  Nothing here
+touches payload bytes.
+"""
+import ctypes
+from typing import List, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from torchrua_amd import _lib as L
+
+
+# ------------------------------------------------------------------ per-tensor memo
+def _memo_get(t: Tensor, key: str):
+    memo = t.__dict__.get('_rua_memo')
+    if memo is None:
+        return None
+    hit = memo.get(key)
+    if hit is None or hit[0] != t._version:
+        return None
+    return hit[1]
+
+
+def _memo_put(t: Tensor, key: str, value):
+    memo = t.__dict__.get('_rua_memo')
+    if memo is None:
+        memo = {}
+        t.__dict__['_rua_memo'] = memo
+    memo[key] = (t._version, value)
+    return value
+
+
+def forget(t: Tensor) -> None:
+    """Drop everything memoised on `t` (bench.py uses this so that no step reuses the last one's work)."""
+    t.__dict__.pop('_rua_memo', None)
+
+
+# ------------------------------------------------------------------ raw kernel wrappers (int64 metadata)
+def exclusive_scan(x: Tensor, want_total: bool = False):
+    """K1 rua_exclusive_scan_i64 — reference utils.py:16-19 (get_offsets)."""
+    dev = L.require_device(x)
+    lib = L.load()
+    n = x.numel()
+    out = torch.empty(n, dtype=torch.long, device=dev)
+    total = torch.empty(1, dtype=torch.long, device=dev) if want_total else None
+    ws = torch.empty(lib.rua_scan_ws_elems(n), dtype=torch.long, device=dev)
+    L.check(lib.rua_exclusive_scan_i64(L.ptr(x), L.ptr(out), L.ptr(total), n, L.ptr(ws), L.stream_ptr(dev)),
+            'rua_exclusive_scan_i64')
+    return (out, total) if want_total else out
+
+
+def _as_lens(t: Tensor) -> Tensor:
+    if t.dtype != torch.long or not t.is_contiguous():
+        t = t.to(torch.long).contiguous()
+    return t
+
+
+def host_lens(token_sizes: Tensor) -> Tensor:
+    """CPU copy of a length vector.  Free when the vector was built from host data
+    (C.new attaches the mirror); otherwise ONE blocking D2H, then memoised.
+    The reference pays a sync of this kind in every size() (layout/cat.py:61-66)."""
+    if not token_sizes.is_cuda:
+        return token_sizes
+    hit = _memo_get(token_sizes, 'host')
+    if hit is not None:
+        return hit
+    return _memo_put(token_sizes, 'host', token_sizes.detach().cpu())
+
+
+def attach_host(token_sizes: Tensor, host: Tensor) -> None:
+    _memo_put(token_sizes, 'host', host)
+
+
+def max_len(token_sizes: Tensor) -> int:
+    h = host_lens(token_sizes)
+    hit = _memo_get(token_sizes, 'max')
+    if hit is not None:
+        return hit
+    return _memo_put(token_sizes, 'max', int(h.max()) if h.numel() else 0)
+
+
+def total_len(token_sizes: Tensor) -> int:
+    hit = _memo_get(token_sizes, 'sum')
+    if hit is not None:
+        return hit
+    return _memo_put(token_sizes, 'sum', int(host_lens(token_sizes).sum()))
+
+
+def dev_off(token_sizes: Tensor) -> Tensor:
+    """Exclusive offsets of a device length vector (K1), memoised."""
+    hit = _memo_get(token_sizes, 'off')
+    if hit is not None:
+        return hit
+    return _memo_put(token_sizes, 'off', exclusive_scan(_as_lens(token_sizes)))
+
+
+# ------------------------------------------------------------------ PackedSequence metadata
+def pack_B(p) -> int:
+    return int(p.batch_sizes[0]) if p.batch_sizes.numel() else 0
+
+
+def pack_boff(p) -> Tensor:
+    """Device exclusive offsets of batch_sizes (reference pack.py:43-45 redoes H2D + cumsum per call)."""
+    dev = p.data.device
+    key = f'boff:{dev}'
+    hit = _memo_get(p.batch_sizes, key)
+    if hit is not None:
+        return hit
+    bsz = p.batch_sizes.to(device=dev, dtype=torch.long, non_blocking=True)
+    _memo_put(p.batch_sizes, f'dev:{dev}', bsz)
+    return _memo_put(p.batch_sizes, key, exclusive_scan(bsz))
+
+
+def pack_bsz_dev(p) -> Tensor:
+    pack_boff(p)
+    return _memo_get(p.batch_sizes, f'dev:{p.data.device}')
+
+
+def pack_lens(p) -> Tensor:
+    """token_sizes of a PackedSequence in batch order (K3b) — reference core/view.py:21-25."""
+    anchor = p.unsorted_indices if p.unsorted_indices is not None else p.batch_sizes
+    key = f'lens:{id(p.batch_sizes)}:{p.batch_sizes._version}'
+    hit = _memo_get(anchor, key)
+    if hit is not None:
+        return hit
+    dev = L.require_device(p.data)
+    lib = L.load()
+    B, T = pack_B(p), p.batch_sizes.numel()
+    bsz = pack_bsz_dev(p)
+    lens = torch.empty(B, dtype=torch.long, device=dev)
+    L.check(lib.rua_lens_from_pack(L.ptr(bsz), T, L.ptr(p.unsorted_indices), B, L.ptr(lens), L.stream_ptr(dev)),
+            'rua_lens_from_pack')
+    # T and sum are known on the host for free
+    _memo_put(lens, 'max', T)
+    _memo_put(lens, 'sum', int(p.data.size(0)))
+    return _memo_put(anchor, key, lens)
+
+
+def adopt_pack(p, lens: Tensor, boff: Tensor, bsz_dev: Tensor) -> None:
+    """Record what pack() already computed so later ops on `p` do not recompute it."""
+    dev = p.data.device
+    _memo_put(p.batch_sizes, f'boff:{dev}', boff)
+    _memo_put(p.batch_sizes, f'dev:{dev}', bsz_dev)
+    anchor = p.unsorted_indices if p.unsorted_indices is not None else p.batch_sizes
+    _memo_put(anchor, f'lens:{id(p.batch_sizes)}:{p.batch_sizes._version}', lens)
+
+
+def batch_sizes_from_host_lens(h: Tensor, T: int) -> Tensor:
+    """batch_sizes[t] = #{b: len[b] > t} as the CPU int64 tensor PackedSequence mandates
+    (reference core/view.py:55: get_mask(self).sum(dim=0).cpu())."""
+    B = h.numel()
+    if T == 0:
+        return torch.zeros(0, dtype=torch.long)
+    cnt = torch.bincount(h, minlength=T + 1)
+    return B - torch.cumsum(cnt, 0)[:T]
+
+
+# ------------------------------------------------------------------ rua_layout descriptors
+class Lay:
+    """A rua_layout plus the tensors its pointers borrow (kept alive with it)."""
+    __slots__ = ('c', 'keep', 'kind', 'n_rows', 'B')
+
+    def __init__(self, keep: List[Optional[Tensor]], **fields):
+        self.c = L.RuaLayout(**fields)
+        self.keep = keep
+        self.kind = fields['kind']
+        self.n_rows = fields['n_rows']
+        self.B = fields['B']
+
+    def ref(self):
+        return ctypes.byref(self.c)
+
+
+def lay_cat(lens: Optional[Tensor], B: int, n_rows: int, len_add: int = 0) -> Lay:
+    """CAT rows; `lens=None` means every sequence has exactly `len_add` rows."""
+    if lens is None:
+        return Lay([], kind=L.CAT, n_rows=n_rows, B=B, len_add=len_add)
+    lens = _as_lens(lens)
+    off = dev_off(lens)
+    return Lay([lens, off], kind=L.CAT, n_rows=n_rows, B=B, lens=L.ptr(lens), len_add=len_add, off=L.ptr(off))
+
+
+def lay_padded(kind: int, lens: Optional[Tensor], B: int, T_phys: int, T_log: int, len_add: int = 0,
+               with_off: bool = False) -> Lay:
+    keep: List[Optional[Tensor]] = []
+    f = dict(kind=kind, n_rows=B * T_phys, B=B, T_phys=T_phys, T_log=T_log, len_add=len_add)
+    if lens is not None:
+        lens = _as_lens(lens)
+        keep.append(lens)
+        f['lens'] = L.ptr(lens)
+        if with_off:  # needed only to ENUMERATE tokens (ptr()/idx())
+            off = dev_off(lens)
+            keep.append(off)
+            f['off'] = L.ptr(off)
+    return Lay(keep, **f)
+
+
+def lay_pack(p, lens: Optional[Tensor] = None, len_add: int = 0, boff: Optional[Tensor] = None,
+             T: Optional[int] = None, n_rows: Optional[int] = None) -> Lay:
+    lens = pack_lens(p) if lens is None else _as_lens(lens)
+    boff = pack_boff(p) if boff is None else boff
+    T = p.batch_sizes.numel() if T is None else T
+    n_rows = int(p.data.size(0)) if n_rows is None else n_rows
+    return Lay([lens, boff, p.sorted_indices, p.unsorted_indices], kind=L.PACK, n_rows=n_rows, B=pack_B(p),
+               lens=L.ptr(lens), len_add=len_add, boff=L.ptr(boff), T=T, sorted=L.ptr(p.sorted_indices),
+               unsorted=L.ptr(p.unsorted_indices))
+
+
+def lay_list(bptr: Optional[Tensor], tptr: Tensor) -> Lay:
+    tptr = _as_lens(tptr)
+    bptr = None if bptr is None else _as_lens(bptr)
+    return Lay([bptr, tptr], kind=L.LIST, n_rows=tptr.numel(), B=0, bptr=L.ptr(bptr), tptr=L.ptr(tptr))
+
+
+def lay_flat(n_rows: int) -> Lay:
+    """A storage of n_rows rows seen as ONE left-aligned sequence (target of flat row gathers)."""
+    return Lay([], kind=L.LEFT, n_rows=n_rows, B=1, T_phys=n_rows, T_log=n_rows, len_add=n_rows)
+
+
+def hidden_of(data: Tensor, lead: int) -> Tuple[int, ...]:
+    return tuple(data.shape[lead:])
+
+
+def row_bytes(data: Tensor, lead: int) -> int:
+    n = 1
+    for d in data.shape[lead:]:
+        n *= d
+    return n * data.element_size()

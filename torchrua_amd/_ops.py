@@ -1,0 +1,188 @@
+"""Kernel launches with autograd: the row mover and the segmented reduce.
+
+Backward of a move is the adjoint move (layouts swapped, token map inverted, zero fill for rows
+nothing maps to) — the same kernel.  Backward of a reduce broadcasts the cotangent back through a
+move (token map ZERO) and, for max/min/prod/logsumexp, finishes with elementwise torch ops on the
+result (SURVEY.md §8f rank 3 allows composing v0 backward this way; forward is kernel-only).
+"""
+import struct
+from typing import Callable, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from torchrua_amd import _lib as L
+from torchrua_amd import _meta as M
+
+# optional hook bench.py installs to bracket named kernels with HIP events on the launch stream
+_kernel_hook: Optional[Callable[[str, bool], None]] = None
+
+
+def set_kernel_hook(fn) -> None:
+    global _kernel_hook
+    _kernel_hook = fn
+
+
+def _fill16(value, dtype: torch.dtype) -> bytes:
+    """The fill element replicated to 16 bytes (as the kernel's uint4 pattern)."""
+    raw = value if isinstance(value, bytes) else torch.tensor([value], dtype=dtype).view(torch.uint8).numpy().tobytes()
+    if len(raw) > 16:
+        raise L.RuaError(f'fill element wider than 16 bytes ({dtype})')
+    return (raw * (16 // len(raw)))[:16]
+
+
+class MovePlan:
+    """Everything one rua_move_rows launch needs except the payload pointers."""
+    __slots__ = ('dst', 'src', 'tmap', 'arg', 'out_shape', 'fill', 'pad_row', 'flags', 'name')
+
+    def __init__(self, dst: M.Lay, src: M.Lay, out_shape: Sequence[int], tmap: int = L.T_SHIFT, arg: int = 0,
+                 fill=0, pad_row: int = -1, flags: int = 0, name: str = 'move'):
+        self.dst, self.src, self.tmap, self.arg = dst, src, tmap, arg
+        self.out_shape, self.fill, self.pad_row, self.flags, self.name = tuple(out_shape), fill, pad_row, flags, name
+
+    def adjoint(self, src_shape: Sequence[int]) -> 'MovePlan':
+        inv = {L.T_SHIFT: (L.T_SHIFT, -self.arg), L.T_ROLL: (L.T_ROLL, -self.arg), L.T_REV_S: (L.T_REV_D, 0),
+               L.T_REV_D: (L.T_REV_S, 0)}
+        if self.tmap not in inv or self.dst.kind == L.LIST or self.flags:
+            raise L.RuaError('this move has no adjoint move')
+        tmap, arg = inv[self.tmap]
+        return MovePlan(self.src, self.dst, src_shape, tmap, arg, fill=0, name=self.name + '_bwd')
+
+
+def launch_move(plan: MovePlan, src_data: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    dev = L.require_device(src_data)
+    lib = L.load()
+    src_data = src_data.contiguous()
+    if out is None:
+        out = torch.empty(plan.out_shape, dtype=src_data.dtype, device=dev)
+    elif not out.is_contiguous() or out.dtype != src_data.dtype:
+        raise L.RuaError('move target must be contiguous and of the payload dtype')
+    # rows are equally wide on both sides; size them on the side the layout `dst` enumerates
+    enumerated = src_data if (plan.flags & L.MOVE_SCATTER) else out
+    rb = (enumerated.numel() // plan.dst.n_rows) * enumerated.element_size() if plan.dst.n_rows else 0
+    fill = _fill16(plan.fill, src_data.dtype)
+    if _kernel_hook:
+        _kernel_hook(plan.name, True)
+    L.check(lib.rua_move_rows(plan.dst.ref(), plan.src.ref(), plan.tmap, plan.arg, L.ptr(out), L.ptr(src_data), rb,
+                              fill, plan.pad_row, plan.flags, L.stream_ptr(dev)), 'rua_move_rows')
+    if _kernel_hook:
+        _kernel_hook(plan.name, False)
+    return out
+
+
+class _Move(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src_data: Tensor, plan: MovePlan):
+        ctx.plan = plan
+        ctx.src_shape = tuple(src_data.shape)
+        return launch_move(plan, src_data)
+
+    @staticmethod
+    def backward(ctx, grad: Tensor):
+        return _Move.apply(grad.contiguous(), ctx.plan.adjoint(ctx.src_shape)), None
+
+
+def move(src_data: Tensor, plan: MovePlan) -> Tensor:
+    if src_data.requires_grad and torch.is_grad_enabled():
+        return _Move.apply(src_data, plan)
+    return launch_move(plan, src_data.detach() if src_data.requires_grad else src_data)
+
+
+class _ListGather(torch.autograd.Function):
+    """X[batch_ptr, token_ptr] (core/get.py tuple keys): rows may repeat, so the adjoint accumulates."""
+
+    @staticmethod
+    def forward(ctx, src_data: Tensor, plan: MovePlan, flat_fn):
+        ctx.flat_fn = flat_fn
+        ctx.src_shape = tuple(src_data.shape)
+        return launch_move(plan, src_data)
+
+    @staticmethod
+    def backward(ctx, grad: Tensor):
+        flat = ctx.flat_fn()
+        g = torch.zeros(ctx.src_shape, dtype=grad.dtype, device=grad.device)
+        lead = len(ctx.src_shape) - (grad.dim() - 1)
+        g.flatten(0, lead - 1).index_add_(0, flat, grad.contiguous()) if lead > 1 else g.index_add_(0, flat, grad)
+        return g, None, None
+
+
+# ------------------------------------------------------------------ reductions
+_EMPTY = {L.SUM: 0.0, L.MEAN: 0.0, L.PROD: 1.0, L.MAX: 0.0, L.MIN: 0.0, L.LOGSUMEXP: float('-inf')}
+
+
+def _bits(value: float, dtype: torch.dtype) -> int:
+    raw = _fill16(value, dtype)[:torch.empty((), dtype=dtype).element_size()]
+    return int.from_bytes(raw, 'little')
+
+
+def launch_reduce(lay: M.Lay, data: Tensor, op: int, out: Optional[Tensor] = None, include_self: int = 0,
+                  perm: Optional[Tensor] = None, hidden: Tuple[int, ...] = (), reference_initial: bool = True,
+                  name: str = 'reduce') -> Tensor:
+    """rua_segment_reduce (+ rua_fill_empty for the reference's global-extreme `initial`)."""
+    dev = L.require_device(data)
+    lib = L.load()
+    if data.dtype not in L.DTYPES:
+        raise L.RuaError(f'reductions support {list(L.DTYPES)}; got {data.dtype}')
+    data = data.contiguous()
+    H = 1
+    for d in hidden:
+        H *= d
+    if out is None:
+        out = torch.empty((lay.B,) + tuple(hidden), dtype=data.dtype, device=dev)
+    extreme = None
+    if reference_initial and op in (L.MAX, L.MIN, L.LOGSUMEXP) and include_self == 0:
+        extreme = torch.empty(65, dtype=torch.long, device=dev)  # initialised by the library
+    if _kernel_hook:
+        _kernel_hook(name, True)
+    L.check(lib.rua_segment_reduce(lay.ref(), L.ptr(perm), L.ptr(data), L.ptr(out), H, L.DTYPES[data.dtype], op,
+                                   include_self, _bits(_EMPTY[op], data.dtype), L.ptr(extreme), L.stream_ptr(dev)),
+            'rua_segment_reduce')
+    if _kernel_hook:
+        _kernel_hook(name, False)
+    if extreme is not None:
+        L.check(lib.rua_fill_empty(lay.ref(), L.ptr(out), H, L.DTYPES[data.dtype], op, L.ptr(extreme),
+                                   L.stream_ptr(dev)), 'rua_fill_empty')
+    return out
+
+
+def broadcast_rows(rows: Tensor, lay: M.Lay, out_shape: Sequence[int]) -> Tensor:
+    """out[row(b,t)] = rows[b] for every token of `lay` (padding rows 0): the adjoint of a sum."""
+    B = lay.B
+    src = M.lay_padded(L.LEFT, None, B, 1, 1, len_add=1)
+    return launch_move(MovePlan(lay, src, out_shape, L.T_ZERO, 0, fill=0, name='broadcast'), rows.contiguous())
+
+
+class _Reduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, data: Tensor, lay: M.Lay, op: int, hidden, lens: Optional[Tensor]):
+        out = launch_reduce(lay, data, op, hidden=hidden)
+        ctx.lay, ctx.op, ctx.lens = lay, op, lens
+        ctx.save_for_backward(data, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad: Tensor):
+        data, out = ctx.saved_tensors
+        lay, op = ctx.lay, ctx.op
+        shape = tuple(data.shape)
+        grad = grad.contiguous()
+        if op == L.SUM:
+            g = broadcast_rows(grad, lay, shape)
+        elif op == L.MEAN:
+            lens = ctx.lens.clamp_min(1).to(grad.dtype).view((-1,) + (1,) * (grad.dim() - 1))
+            g = broadcast_rows(grad / lens, lay, shape)
+        elif op in (L.MAX, L.MIN):
+            hit = (data == broadcast_rows(out, lay, shape)).to(grad.dtype)
+            ties = launch_reduce(lay, hit, L.SUM, hidden=tuple(out.shape[1:])).clamp_min(1)
+            g = broadcast_rows(grad / ties, lay, shape) * hit      # ties share the gradient equally
+        elif op == L.PROD:
+            g = broadcast_rows(grad * out, lay, shape) / data
+        else:  # LOGSUMEXP
+            g = broadcast_rows(grad, lay, shape) * (data - broadcast_rows(out, lay, shape)).exp()
+        return g, None, None, None, None
+
+
+def reduce(data: Tensor, lay: M.Lay, op: int, hidden, lens: Optional[Tensor]) -> Tensor:
+    if data.requires_grad and torch.is_grad_enabled():
+        return _Reduce.apply(data, lay, op, tuple(hidden), lens)
+    return launch_reduce(lay, data.detach() if data.requires_grad else data, op, hidden=tuple(hidden))

@@ -1,0 +1,312 @@
+"""Views, indexing, casts and constructors — mirror of torchrua.core (reference core/view.py,
+core/get.py, core/set.py, core/cast.py, core/__init__.py).
+
+Every conversion between the four layouts is ONE launch of the row mover (rua_move_rows): the
+destination rows are enumerated in storage order, each row finds its source row in closed form, and
+padding is written in the same pass (the reference pre-fills with new_full and then scatters:
+core/view.py:34-38 + core/cast.py:19-23).
+"""
+from numbers import Number
+from typing import Any, List, Tuple, Union
+
+import torch
+from torch import Tensor
+
+from torchrua_amd import _lib as K
+from torchrua_amd import _meta as M
+from torchrua_amd import _ops as O
+from torchrua_amd.layout import C, L, P, R, T, Z, describe, lens_of
+
+__all__ = ['get_mask']
+
+Key = Union[int, Tensor, Tuple[Tensor, Tensor], Z]
+
+
+def _to_self(self: Any, *_, **__) -> Any:
+    return self
+
+
+# ------------------------------------------------------------------ core/view.py
+def get_mask(self: Z) -> Tensor:
+    """core/view.py:11-18: [b, t] int64 grid of 0/1 — one kernel, no (batch_ptr, token_ptr) scatter."""
+    b, t = self.size()[:2]
+    return _mask_grid(lens_of(self), b, t, 0, 1, torch.long)
+
+
+def _mask_grid(lens: Tensor, b: int, t: int, zero, one, dtype: torch.dtype) -> Tensor:
+    dev = K.require_device(lens)
+    lib = K.load()
+    out = torch.empty((b, t), dtype=dtype, device=dev)
+    es = out.element_size()
+    if es not in (1, 2, 4, 8):
+        raise K.RuaError(f'mask dtype {dtype} not supported')
+    zb = int.from_bytes(O._fill16(zero, dtype)[:es], 'little')
+    ob = int.from_bytes(O._fill16(one, dtype)[:es], 'little')
+    K.check(lib.rua_mask(K.ptr(M._as_lens(lens)), b, t, K.ptr(out), es, zb, ob, K.stream_ptr(dev)), 'rua_mask')
+    return out
+
+
+def _cat_view(self: Union[L, P, R], **kwargs) -> C:
+    """core/view.py:21-25."""
+    return C(data=self.data, token_sizes=lens_of(self))
+
+
+def _padded_view(cls):
+    def view(self, fill_value: Number, dtype: torch.dtype = None):
+        """core/view.py:34-38 / 67-71."""
+        data = self.data.new_full(self.size(), fill_value=fill_value, dtype=dtype)
+        return cls(data=data, token_sizes=lens_of(self))
+    return view
+
+
+def _sorted_indices(token_sizes: Tensor) -> Tuple[Tensor, Tensor]:
+    """The reference's order: a HOST torch.sort(descending=True) on the lengths (core/view.py:48).
+    Its tie order is implementation-defined, so bit-exact parity means making the identical call
+    (SURVEY.md §8a note).  Returns (host lengths, sorted_indices on the host)."""
+    host = M.host_lens(token_sizes)
+    _, index = torch.sort(host.detach(), descending=True)
+    return host, index
+
+
+def _pack_meta(token_sizes: Tensor, dev: torch.device):
+    """sorted/unsorted indices (device), batch_sizes (CPU, as PackedSequence mandates), and the
+    device-side boff — K3 + K1.  One host sort, no B x T mask (core/view.py:47-58)."""
+    lib = K.load()
+    lens = M._as_lens(token_sizes)
+    host, index = _sorted_indices(token_sizes)
+    B = lens.numel()
+    T = M.max_len(token_sizes)
+    sorted_indices = index.pin_memory().to(dev, non_blocking=True) if B else index.to(dev)
+    batch_sizes = M.batch_sizes_from_host_lens(host, T)
+    unsorted = torch.empty(B, dtype=torch.long, device=dev)
+    bsz_dev = torch.empty(T, dtype=torch.long, device=dev)
+    K.check(lib.rua_pack_meta(K.ptr(lens), K.ptr(sorted_indices), B, T, K.ptr(unsorted), K.ptr(bsz_dev),
+                              K.stream_ptr(dev)), 'rua_pack_meta')
+    boff = M.exclusive_scan(bsz_dev)
+    return lens, sorted_indices, unsorted, batch_sizes, bsz_dev, boff
+
+
+def _pack_view(self: Union[C, L, R], **kwargs) -> P:
+    """core/view.py:47-58."""
+    dev = K.require_device(self.data)
+    lens, sorted_indices, unsorted, batch_sizes, bsz_dev, boff = _pack_meta(self.token_sizes, dev)
+    p = P(data=self.data, batch_sizes=batch_sizes, sorted_indices=sorted_indices, unsorted_indices=unsorted)
+    M.adopt_pack(p, lens, boff, bsz_dev)
+    return p
+
+
+C.cat_view = _to_self
+L.cat_view = _cat_view
+P.cat_view = _cat_view
+R.cat_view = _cat_view
+
+C.left_view = _padded_view(L)
+L.left_view = _to_self
+P.left_view = _padded_view(L)
+R.left_view = _padded_view(L)
+
+C.pack_view = _pack_view
+L.pack_view = _pack_view
+P.pack_view = _to_self
+R.pack_view = _pack_view
+
+C.right_view = _padded_view(R)
+L.right_view = _padded_view(R)
+P.right_view = _padded_view(R)
+R.right_view = _to_self
+
+
+# ------------------------------------------------------------------ core/cast.py
+def _hidden(z: Z) -> Tuple[int, ...]:
+    return tuple(z.data.shape[1:]) if isinstance(z, (C, P)) else tuple(z.data.shape[2:])
+
+
+def _to_cat(self: Union[L, P, R]) -> C:
+    """core/cast.py:8-16: L/P/R -> C."""
+    lens = lens_of(self)
+    B = lens.numel()
+    n = int(self.data.size(0)) if isinstance(self, P) else M.total_len(lens)
+    dst = M.lay_cat(lens, B, n)
+    data = O.move(self.data, O.MovePlan(dst, describe(self), (n,) + _hidden(self), name='to_cat'))
+    return C(data=data, token_sizes=lens)
+
+
+def _to_padded(cls, kind):
+    def cast(self, fill_value: Number = 0):
+        """core/cast.py:19-38 (left) / 52-71 (right): fill and payload in one pass."""
+        lens = lens_of(self)
+        b, t = self.size()[:2]
+        dst = M.lay_padded(kind, lens, b, t, t)
+        plan = O.MovePlan(dst, describe(self), (b, t) + _hidden(self), fill=fill_value,
+                          name='to_left' if kind == K.LEFT else 'to_right')
+        return cls(data=O.move(self.data, plan), token_sizes=lens)
+    return cast
+
+
+def _to_pack(self: Union[C, L, R]) -> P:
+    """core/cast.py:41-49: C/L/R -> P."""
+    dev = K.require_device(self.data)
+    lens, sorted_indices, unsorted, batch_sizes, bsz_dev, boff = _pack_meta(self.token_sizes, dev)
+    n = int(self.data.size(0)) if isinstance(self, C) else M.total_len(self.token_sizes)
+    shell = P(data=self.data, batch_sizes=batch_sizes, sorted_indices=sorted_indices, unsorted_indices=unsorted)
+    M.adopt_pack(shell, lens, boff, bsz_dev)
+    dst = M.lay_pack(shell, lens=lens, boff=boff, T=batch_sizes.numel(), n_rows=n)
+    data = O.move(self.data, O.MovePlan(dst, describe(self), (n,) + _hidden(self), name='to_pack'))
+    return shell._replace(data=data)
+
+
+C.cat = _to_self
+L.cat = _to_cat
+P.cat = _to_cat
+R.cat = _to_cat
+
+C.left = _to_padded(L, K.LEFT)
+L.left = _to_self
+P.left = _to_padded(L, K.LEFT)
+R.left = _to_padded(L, K.LEFT)
+
+C.pack = _to_pack
+L.pack = _to_pack
+P.pack = _to_self
+R.pack = _to_pack
+
+C.right = _to_padded(R, K.RIGHT)
+L.right = _to_padded(R, K.RIGHT)
+P.right = _to_padded(R, K.RIGHT)
+R.right = _to_self
+
+
+# ------------------------------------------------------------------ core/get.py / core/set.py
+def _is_ptr_pair(key) -> bool:
+    return isinstance(key, tuple) and len(key) == 2 and isinstance(key[0], Tensor) and isinstance(key[1], Tensor)
+
+
+def _flat_rows(z: Z, key: Tuple[Tensor, Tensor]) -> Tensor:
+    """Flat storage rows of (batch_ptr, token_ptr) — core/get.py:25-26, 41-42, 57-58, 73-74 —
+    produced by the mover itself (moving an iota of the storage)."""
+    n_rows = describe(z).n_rows
+    iota = M.exclusive_scan(torch.ones(n_rows, dtype=torch.long, device=z.data.device))
+    return O.launch_move(O.MovePlan(M.lay_list(*key), describe(z), (key[0].numel(),), name='flat_rows'), iota)
+
+
+def _gather_flat(raw: Tensor, index: Tensor) -> Tensor:
+    """raw[index] for an int64 row index of any shape (core/get.py:29,42,61,74) via the mover."""
+    if index.dtype != torch.long:
+        return raw[index]   # bool masks etc.: not a row-index gather
+    flat = index.reshape(-1)
+    shape = tuple(index.shape) + tuple(raw.shape[1:])
+    plan = O.MovePlan(M.lay_list(None, flat), M.lay_flat(int(raw.size(0))), shape, name='gather_flat')
+    if raw.requires_grad and torch.is_grad_enabled():
+        return O._ListGather.apply(raw, plan, lambda: flat)
+    return O.launch_move(plan, raw)
+
+
+def _scatter_flat(raw: Tensor, index: Tensor, value) -> None:
+    """raw[index] = value (core/set.py:30,45,67,82) via the mover in scatter mode."""
+    if index.dtype != torch.long or not raw.is_contiguous():
+        raw[index] = value
+        return
+    flat = index.reshape(-1)
+    value = torch.as_tensor(value, dtype=raw.dtype, device=raw.device)
+    value = value.expand(tuple(index.shape) + tuple(raw.shape[1:])).contiguous()
+    plan = O.MovePlan(M.lay_list(None, flat), M.lay_flat(int(raw.size(0))), raw.shape, flags=K.MOVE_SCATTER,
+                      name='scatter_flat')
+    O.launch_move(plan, value, out=raw.detach())
+
+
+def _getitem(cls):
+    base = tuple.__getitem__
+
+    def getitem(self, key: Key):
+        if isinstance(key, (C, L, P, R)):          # Z key: gather rows by a container of row indices
+            return key._replace(data=_gather_flat(self.raw(), key.data))
+        if _is_ptr_pair(key):                       # (batch_ptr, token_ptr)
+            bp, tp = key
+            shape = tuple(bp.shape) + _hidden(self)
+            plan = O.MovePlan(M.lay_list(bp.reshape(-1), tp.reshape(-1)), describe(self), shape, name='getitem')
+            if self.data.requires_grad and torch.is_grad_enabled():
+                k = (bp.reshape(-1), tp.reshape(-1))
+                return O._ListGather.apply(self.data, plan, lambda: _flat_rows(self, k))
+            return O.launch_move(plan, self.data)
+        if isinstance(key, Tensor):
+            return _gather_flat(self.raw(), key)
+        return base(self, key)
+    return getitem
+
+
+def _setitem(cls):
+    def setitem(self, key: Key, value: Tensor) -> None:
+        if isinstance(key, (C, L, P, R)):
+            _scatter_flat(self.raw(), key.data, value)
+            return None
+        if _is_ptr_pair(key):
+            bp, tp = key[0].reshape(-1), key[1].reshape(-1)
+            if not self.data.is_contiguous():
+                raise K.RuaError('__setitem__ needs contiguous storage')
+            hidden = _hidden(self)
+            value = torch.as_tensor(value, dtype=self.data.dtype, device=self.data.device)
+            value = value.expand((bp.numel(),) + hidden).contiguous()
+            plan = O.MovePlan(M.lay_list(bp, tp), describe(self), self.data.shape, flags=K.MOVE_SCATTER,
+                              name='setitem')
+            O.launch_move(plan, value, out=self.data.detach())
+            return None
+        if isinstance(key, Tensor):
+            _scatter_flat(self.raw(), key, value)
+            return None
+        raise TypeError(f'{cls.__name__} does not support item assignment with key {type(key).__name__}')
+    return setitem
+
+
+for _cls in (C, L, P, R):
+    _cls.__getitem__ = _getitem(_cls)
+    _cls.__setitem__ = _setitem(_cls)
+
+
+_tensor_getitem = Tensor.__getitem__
+_tensor_setitem = Tensor.__setitem__
+
+
+def patch_tensor_indexing() -> None:
+    """Opt-in twin of the reference's import-time patch of Tensor.__getitem__/__setitem__
+    (core/get.py:11-18, core/set.py:10-18): lets `tensor[Z]` re-wrap a container of row indices.
+    Not applied on import so that ordinary tensor indexing in the process is left untouched."""
+    def tensor_getitem(self: T, key):
+        if isinstance(key, (C, L, P, R)):
+            return key._replace(data=_tensor_getitem(self, key.data))
+        return _tensor_getitem(self, key)
+
+    def tensor_setitem(self: T, key, value) -> None:
+        if isinstance(key, (C, L, P, R)):
+            return _tensor_setitem(self, key.data, value)
+        return _tensor_setitem(self, key, value)
+
+    Tensor.__getitem__ = tensor_getitem
+    Tensor.__setitem__ = tensor_setitem
+
+
+# ------------------------------------------------------------------ core/__init__.py constructors
+def _new_cat(tensors: List[T]) -> C:
+    """core/__init__.py:9-15.  The lengths are known on the host here: keep that copy as the
+    host mirror so that later pack()/left()/size() never read them back from the device."""
+    data = torch.cat(tensors, dim=0)
+    host = torch.tensor([tensor.size()[0] for tensor in tensors], dtype=torch.long)
+    if data.is_cuda and host.numel():
+        token_sizes = host.pin_memory().to(data.device, non_blocking=True)
+    else:
+        token_sizes = host.to(data.device)
+    M.attach_host(token_sizes, host)
+    return C(data=data, token_sizes=token_sizes)
+
+
+C.new = staticmethod(_new_cat)
+L.new = staticmethod(lambda tensors, fill_value=0: _new_cat(tensors).left(fill_value=fill_value))
+P.new = staticmethod(lambda tensors: _new_cat(tensors).pack())
+R.new = staticmethod(lambda tensors, fill_value=0: _new_cat(tensors).right(fill_value=fill_value))
+
+
+def with_host_sizes(data: Tensor, token_sizes_host: Tensor) -> C:
+    """C(data, token_sizes) from lengths that live on the host (what C.new does for a list)."""
+    host = token_sizes_host.to(dtype=torch.long, device='cpu')
+    dev_sizes = host.pin_memory().to(data.device, non_blocking=True) if data.is_cuda and host.numel() else host.to(data.device)
+    M.attach_host(dev_sizes, host)
+    return C(data=data, token_sizes=dev_sizes)

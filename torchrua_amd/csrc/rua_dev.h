@@ -68,7 +68,7 @@ __device__ __forceinline__ bool row_to_token(const rua_layout& D, int64_t j, int
       return t >= 0 && t < len;
     }
     case RUA_LIST:
-      b = D.bptr[j];
+      b = D.bptr ? D.bptr[j] : 0;   // bptr == NULL: one sequence, tptr = flat rows
       t = D.tptr[j];
       return true;
   }

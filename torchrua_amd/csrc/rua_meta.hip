@@ -201,7 +201,7 @@ int rua_exclusive_scan_i64(const int64_t* in, int64_t* out, int64_t* total, int6
 
 int rua_pack_meta(const int64_t* lens, const int64_t* sorted, int64_t B, int64_t T, int64_t* unsorted,
                   int64_t* bsz, void* stream) {
-  if (B < 0 || T < 0 || (B > 0 && (!lens || !sorted))) return RUA_EINVAL;
+  if (B < 0 || T < 0 || (B > 0 && !sorted) || (T > 0 && !lens)) return RUA_EINVAL;
   const int64_t n = B > T ? B : T;
   if (n == 0) return 0;
   hipLaunchKernelGGL(pack_meta_kernel, dim3(grid_for(n)), dim3(RUA_BLOCK), 0, (hipStream_t)stream, lens, sorted, B,

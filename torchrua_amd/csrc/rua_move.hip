@@ -41,7 +41,8 @@ template <int VEC, bool SCATTER>
 __global__ __launch_bounds__(RUA_BLOCK) void move_rows_kernel(rua_layout D, rua_layout S, int32_t tmap,
                                                               int64_t targ, char* __restrict__ dst,
                                                               const char* __restrict__ src, int64_t row_bytes,
-                                                              int64_t lpr, int lp_log2, int cpr, uint4 fillpat) {
+                                                              int64_t lpr, int lp_log2, int cpr, uint4 fillpat,
+                                                              int64_t pad_row) {
   using V = typename vec_of<VEC>::type;
   __shared__ int64_t s_ld[TILE_ROWS];
   __shared__ int64_t s_st[TILE_ROWS];
@@ -61,6 +62,8 @@ __global__ __launch_bounds__(RUA_BLOCK) void move_rows_kernel(rua_layout D, rua_
         const int64_t dlen = D.kind == RUA_LIST ? slen : seq_len(D, b);
         const int64_t ts = apply_tmap(tmap, targ, t, slen, dlen);
         if (ts >= 0 && ts < slen) other = token_to_row(S, b, ts, slen);
+      } else {
+        other = pad_row;  // padding row: fill (-1) or a copy of one fixed source row
       }
       if (SCATTER) { s_ld[i] = j; s_st[i] = other; }   // enumerated rows are the source
       else         { s_ld[i] = other; s_st[i] = j; }   // enumerated rows are the destination
@@ -114,7 +117,7 @@ static int check_layout(const rua_layout* L, bool is_dst) {
       return 0;
     case RUA_LIST:
       if (!is_dst) return RUA_EINVAL;
-      if (L->n_rows > 0 && (!L->bptr || !L->tptr)) return RUA_EINVAL;
+      if (L->n_rows > 0 && !L->tptr) return RUA_EINVAL;
       return 0;
   }
   return RUA_EINVAL;
@@ -122,14 +125,14 @@ static int check_layout(const rua_layout* L, bool is_dst) {
 
 template <bool SCATTER>
 static int launch_move(int vec, unsigned grid, hipStream_t s, const rua_layout& D, const rua_layout& S, int32_t tmap,
-                       int64_t targ, char* dst, const char* src, int64_t row_bytes, uint4 fp) {
+                       int64_t targ, char* dst, const char* src, int64_t row_bytes, uint4 fp, int64_t pad_row) {
   const int64_t lpr = (row_bytes + vec - 1) / vec;
   int lp_log2 = 0;
   while ((1 << lp_log2) < lpr && lp_log2 < 6) ++lp_log2;
   const int cpr = (int)((lpr + RUA_WAVE - 1) / RUA_WAVE);
   const dim3 g(grid), b(RUA_BLOCK);
 #define RUA_LAUNCH(VEC) \
-  hipLaunchKernelGGL((move_rows_kernel<VEC, SCATTER>), g, b, 0, s, D, S, tmap, targ, dst, src, row_bytes, lpr, lp_log2, cpr, fp)
+  hipLaunchKernelGGL((move_rows_kernel<VEC, SCATTER>), g, b, 0, s, D, S, tmap, targ, dst, src, row_bytes, lpr, lp_log2, cpr, fp, pad_row)
   switch (vec) {
     case 16: RUA_LAUNCH(16); break;
     case 8:  RUA_LAUNCH(8); break;
@@ -147,13 +150,14 @@ using namespace rua;
 
 extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32_t tmap, int64_t tmap_arg,
                              void* dst_data, const void* src_data, int64_t row_bytes, const void* fill16,
-                             int32_t flags, void* stream) {
+                             int64_t pad_row, int32_t flags, void* stream) {
   int e;
   if ((e = check_layout(dst, true)) != 0) return e;
   if ((e = check_layout(src, false)) != 0) return e;
   if (tmap < RUA_T_SHIFT || tmap > RUA_T_ZERO || row_bytes < 0) return RUA_EINVAL;
   if (dst->n_rows == 0 || row_bytes == 0) return 0;
   if (!dst_data || !src_data) return RUA_EINVAL;
+  if (pad_row < -1 || pad_row >= src->n_rows) return RUA_EINVAL;
   const int64_t ntiles = (dst->n_rows + TILE_ROWS - 1) / TILE_ROWS;
   if (ntiles > 0x7fffffffLL) return RUA_ERANGE;
 
@@ -169,7 +173,7 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
   hipStream_t s = (hipStream_t)stream;
   if (flags & RUA_MOVE_SCATTER)
     return launch_move<true>(vec, (unsigned)ntiles, s, *dst, *src, tmap, tmap_arg, (char*)dst_data,
-                             (const char*)src_data, row_bytes, fp);
+                             (const char*)src_data, row_bytes, fp, pad_row);
   return launch_move<false>(vec, (unsigned)ntiles, s, *dst, *src, tmap, tmap_arg, (char*)dst_data,
-                            (const char*)src_data, row_bytes, fp);
+                            (const char*)src_data, row_bytes, fp, pad_row);
 }

@@ -1,0 +1,47 @@
+"""Batch-sharded execution over several GPUs (one process per GPU, torch.distributed; backend "nccl"
+is RCCL on ROCm, over xGMI).
+
+Every op on the hot path is per-sequence, so rank r simply owns the contiguous shard of sequences
+[r*B/R, (r+1)*B/R) and runs the single-GPU path on it: no payload ever crosses the fabric.  The only
+exchange is ONE all-gather of the reduced [B/R, H] outputs; contiguous shards make the gathered
+buffer come out in global batch order.  The reference has no distributed code."""
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+__all__ = ['shard_bounds', 'all_gather_rows', 'sharded_reduce']
+
+
+def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of n sequences for `rank`; sizes differ by at most one."""
+    if not 0 <= rank < world:
+        raise ValueError(f'rank {rank} outside world of {world}')
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def all_gather_rows(local: Tensor, n_total: Optional[int] = None, group=None) -> Tensor:
+    """Concatenate every rank's [n_r, *H] rows in rank order.  Equal shards use one
+    all_gather_into_tensor (a single ncclAllGather); ragged shards fall back to all_gather."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    local = local.contiguous()
+    if n_total is None:
+        n_total = local.size(0) * world
+    sizes = [shard_bounds(n_total, r, world) for r in range(world)]
+    if sizes[rank][1] - sizes[rank][0] != local.size(0):
+        raise ValueError(f'rank {rank} holds {local.size(0)} rows, its shard of {n_total} is {sizes[rank]}')
+    out = local.new_empty((n_total,) + tuple(local.shape[1:]))
+    if n_total % world == 0:
+        dist.all_gather_into_tensor(out, local, group=group)
+    else:
+        dist.all_gather([out[lo:hi] for lo, hi in sizes], local, group=group)
+    return out
+
+
+def sharded_reduce(local_fn: Callable[[], Tensor], n_total: Optional[int] = None, group=None) -> Tensor:
+    """Run `local_fn` (this rank's pack -> reduce over its own sequences -> [B/R, H]) and all-gather."""
+    return all_gather_rows(local_fn(), n_total=n_total, group=group)

@@ -1,0 +1,211 @@
+"""Segmented and scatter reductions — mirror of torchrua.reduce (reference reduce.py).
+
+segment_*  : torch.segment_reduce(..., lengths=sizes, unsafe=True, initial=..) in the reference
+             (reduce.py:34-61) -> rua_segment_reduce over a CAT layout (fp32 accumulation, one pass;
+             the reference's extra full read for `initial = tensor.min()` is folded into that pass).
+scatter_*  : torch.index_reduce / index_add (reduce.py:6-31) -> bucket the index (counting sort,
+             rua_index_buckets) and run the same segmented kernel through the row indirection:
+             no float atomics, bitwise reproducible.
+reduce_*   : the same reductions over the sequences of ANY container (C/L/P/R) -> [B, *H] in batch
+             order, without first converting to C (BASELINE.json's `reduce_sum`; SURVEY.md §8d spells
+             it in the reference as p.cat() + segment_sum, or scatter_sum over p.ptr()[0]).
+"""
+import torch
+from torch import Tensor
+
+from torchrua_amd import _lib as K
+from torchrua_amd import _meta as M
+from torchrua_amd import _ops as O
+from torchrua_amd.layout import C, L, P, R, T, Z, describe, lens_of
+
+__all__ = [
+    'segment_max', 'segment_min', 'segment_sum', 'segment_mean', 'segment_prod', 'segment_logsumexp',
+    'segment_head', 'segment_last',
+    'scatter_max', 'scatter_min', 'scatter_sum', 'scatter_mean', 'scatter_prod', 'scatter_logsumexp',
+    'reduce_max', 'reduce_min', 'reduce_sum', 'reduce_mean', 'reduce_prod', 'reduce_logsumexp',
+]
+
+
+def _segment(tensor: T, segment_sizes: T, op: int) -> T:
+    K.require_device(tensor, segment_sizes)
+    S = segment_sizes.numel()
+    lay = M.lay_cat(segment_sizes, S, int(tensor.size(0)))
+    return O.reduce(tensor, lay, op, tuple(tensor.shape[1:]), segment_sizes)
+
+
+def segment_max(tensor: T, segment_sizes: T) -> T:
+    """reduce.py:34-36 (empty segment -> tensor.min(), as the reference's `initial`)."""
+    return _segment(tensor, segment_sizes, K.MAX)
+
+
+def segment_min(tensor: T, segment_sizes: T) -> T:
+    """reduce.py:39-41."""
+    return _segment(tensor, segment_sizes, K.MIN)
+
+
+def segment_sum(tensor: T, segment_sizes: T) -> T:
+    """reduce.py:44-45."""
+    return _segment(tensor, segment_sizes, K.SUM)
+
+
+def segment_mean(tensor: T, segment_sizes: T) -> T:
+    """reduce.py:48-49."""
+    return _segment(tensor, segment_sizes, K.MEAN)
+
+
+def segment_prod(tensor: T, segment_sizes: T) -> T:
+    """reduce.py:52-53."""
+    return _segment(tensor, segment_sizes, K.PROD)
+
+
+def segment_logsumexp(tensor: T, segment_sizes: T) -> T:
+    """reduce.py:56-61 (max, sub, exp, sum, log over [N,H] temporaries) as one online pass."""
+    return _segment(tensor, segment_sizes, K.LOGSUMEXP)
+
+
+def segment_head(tensor: T, segment_sizes: T) -> T:
+    """reduce.py:64-65."""
+    return C(data=tensor, token_sizes=segment_sizes).head(n=1).data
+
+
+def segment_last(tensor: T, segment_sizes: T) -> T:
+    """reduce.py:68-69."""
+    return C(data=tensor, token_sizes=segment_sizes).last()
+
+
+# ------------------------------------------------------------------ reduce over sequences of any layout
+def _reduce_seq(sequence: Z, op: int) -> T:
+    hidden = tuple(sequence.data.shape[1:]) if isinstance(sequence, (C, P)) else tuple(sequence.data.shape[2:])
+    return O.reduce(sequence.data, describe(sequence), op, hidden, lens_of(sequence))
+
+
+def reduce_sum(sequence: Z) -> T:
+    return _reduce_seq(sequence, K.SUM)
+
+
+def reduce_mean(sequence: Z) -> T:
+    return _reduce_seq(sequence, K.MEAN)
+
+
+def reduce_max(sequence: Z) -> T:
+    return _reduce_seq(sequence, K.MAX)
+
+
+def reduce_min(sequence: Z) -> T:
+    return _reduce_seq(sequence, K.MIN)
+
+
+def reduce_prod(sequence: Z) -> T:
+    return _reduce_seq(sequence, K.PROD)
+
+
+def reduce_logsumexp(sequence: Z) -> T:
+    return _reduce_seq(sequence, K.LOGSUMEXP)
+
+
+# ------------------------------------------------------------------ scatter_* (reduce.py:6-31)
+def _buckets(index: T, S: int):
+    dev = K.require_device(index)
+    lib = K.load()
+    index = M._as_lens(index)
+    m = index.numel()
+    counts = torch.empty(S, dtype=torch.long, device=dev)
+    off = torch.empty(S, dtype=torch.long, device=dev)
+    perm = torch.empty(m, dtype=torch.long, device=dev)
+    ws = torch.empty(lib.rua_scan_ws_elems(S) + S + m, dtype=torch.long, device=dev)
+    K.check(lib.rua_index_buckets(K.ptr(index), m, S, K.ptr(counts), K.ptr(off), K.ptr(perm), K.ptr(ws),
+                                  K.stream_ptr(dev)), 'rua_index_buckets')
+    M._memo_put(counts, 'off', off)
+    return counts, perm
+
+
+class _Scatter(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tensor: T, index: T, source: T, op: int, include_self: bool):
+        S = tensor.size(0)
+        counts, perm = _buckets(index, S)
+        lay = M.lay_cat(counts, S, int(source.size(0)))
+        hidden = tuple(tensor.shape[1:])
+        if op == K.SUM and not include_self:
+            out, mode = torch.empty_like(tensor), 0            # index_add into zeros (reduce.py:15)
+        else:
+            out = tensor.detach().clone()
+            # include_self: fold the old row in; otherwise rows no index names keep their value
+            # and touched rows start from the identity (torch.index_reduce semantics)
+            mode = 1 if include_self else 2
+        if op == K.LOGSUMEXP and not include_self:
+            out, mode = torch.empty_like(tensor), 0            # untouched rows -> log(0) = -inf (reduce.py:26-31)
+        O.launch_reduce(lay, source.detach(), op, out=out, include_self=mode, perm=perm, hidden=hidden,
+                        reference_initial=False, name='scatter')
+        ctx.op, ctx.include_self, ctx.lay, ctx.perm = op, include_self, lay, perm
+        ctx.save_for_backward(tensor, index, source, out, counts)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad: T):
+        tensor, index, source, out, counts = ctx.saved_tensors
+        op, inc = ctx.op, ctx.include_self
+        grad = grad.contiguous()
+        g_src = g_ten = None
+        view = (-1,) + (1,) * (grad.dim() - 1)
+        touched = (counts > 0).view(view)
+        if op == K.SUM:
+            g_src = grad[index]
+            g_ten = grad if inc else None
+        elif op == K.MEAN:
+            n = (counts + (1 if inc else 0)).clamp_min(1).to(grad.dtype).view(view)
+            g_src = (grad / n)[index]
+            g_ten = grad / n if inc else torch.where(touched, torch.zeros_like(grad), grad)
+        elif op in (K.MAX, K.MIN):
+            hit_s = (source == out[index]).to(grad.dtype)
+            hit_t = (tensor == out).to(grad.dtype) if inc else torch.zeros_like(grad)
+            ties = torch.zeros_like(grad).index_add_(0, index, hit_s) + hit_t
+            share = grad / ties.clamp_min(1)
+            g_src = share[index] * hit_s
+            g_ten = share * hit_t if inc else torch.where(touched, torch.zeros_like(grad), grad)
+        elif op == K.PROD:
+            g_src = (grad * out)[index] / source
+            g_ten = grad * out / tensor if inc else torch.where(touched, torch.zeros_like(grad), grad)
+        else:  # LOGSUMEXP
+            g_src = grad[index] * (source - out[index]).exp()
+            g_ten = grad * (tensor - out).exp() if inc else None
+        return g_ten, None, g_src, None, None
+
+
+def _scatter(tensor: T, index: T, source: T, op: int, include_self: bool, dim: int) -> T:
+    if dim != 0:
+        raise K.RuaError('scatter_* reduce along dim 0 (the only dim the reference uses)')
+    K.require_device(tensor, index, source)
+    if tensor.dtype not in K.DTYPES:
+        raise K.RuaError(f'reductions support {list(K.DTYPES)}; got {tensor.dtype}')
+    return _Scatter.apply(tensor, index, source, op, bool(include_self))
+
+
+def scatter_max(tensor: T, index: T, source: T, include_self: bool = False, dim: int = 0):
+    """reduce.py:6-7."""
+    return _scatter(tensor, index, source, K.MAX, include_self, dim)
+
+
+def scatter_min(tensor: T, index: T, source: T, include_self: bool = False, dim: int = 0):
+    """reduce.py:10-11."""
+    return _scatter(tensor, index, source, K.MIN, include_self, dim)
+
+
+def scatter_sum(tensor: T, index: T, source: T, include_self: bool = False, dim: int = 0):
+    """reduce.py:14-15."""
+    return _scatter(tensor, index, source, K.SUM, include_self, dim)
+
+
+def scatter_mean(tensor: T, index: T, source: T, include_self: bool = False, dim: int = 0):
+    """reduce.py:18-19."""
+    return _scatter(tensor, index, source, K.MEAN, include_self, dim)
+
+
+def scatter_prod(tensor: T, index: T, source: T, include_self: bool = False, dim: int = 0):
+    """reduce.py:22-23."""
+    return _scatter(tensor, index, source, K.PROD, include_self, dim)
+
+
+def scatter_logsumexp(tensor: T, index: T, source: T, include_self: bool = False, dim: int = 0):
+    """reduce.py:26-31."""
+    return _scatter(tensor, index, source, K.LOGSUMEXP, include_self, dim)
