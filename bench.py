@@ -1,0 +1,234 @@
+"""bench.py — the north-star measurement (BASELINE.json): pack -> reduce over 65 536 variable-length
+sequences, hidden 512, bf16, per GPU; M elements/s whole-job + % of the HBM roofline.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the hot path over one batch already resident in HBM:
+    c = C(data, token_sizes)            # token_sizes handed over from the host, as C.new does
+    p = c.pack()                        # host sort (reference's own call) + K1/K3 metadata + row mover
+    out = reduce_sum(p)                 # segmented reduce over the PackedSequence -> [B, H]
+    (N > 1: one RCCL all-gather of `out`; sequences are sharded, payload never crosses xGMI)
+Nothing is cached between steps: every step uploads the lengths again, re-sorts, re-scans, re-moves.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the pack row mover:
+algorithmic bytes 2*N*H*e + 8*(3B+T)), timed with HIP events on the launch stream
+inside the timed region.  `cpu_baseline` times the oracle port on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=65536, help='sequences per GPU')
+    ap.add_argument('--hidden', type=int, default=512)
+    ap.add_argument('--lo', type=int, default=8)
+    ap.add_argument('--hi', type=int, default=512)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=4096, help='sequences in the CPU-baseline sample')
+    return ap.parse_args()
+
+
+def make_inputs(args, rank, dev):
+    """SURVEY.md §8(d) recipe; the payload is drawn on the device (17.45 GB per rank at the default shape)."""
+    g = torch.Generator().manual_seed(5 + rank)
+    lens = torch.randint(args.lo, args.hi + 1, (args.batch,), generator=g)
+    n = int(lens.sum())
+    dg = torch.Generator(device=dev).manual_seed(1005 + rank)
+    data = torch.empty((n, args.hidden), dtype=torch.bfloat16, device=dev)
+    chunk = 1 << 21
+    for lo in range(0, n, chunk):   # bounded fp32 temporaries
+        hi = min(n, lo + chunk)
+        data[lo:hi] = torch.randn((hi - lo, args.hidden), generator=dg, device=dev, dtype=torch.float32)
+    return lens, data
+
+
+class KernelTimer:
+    """HIP events around named kernel launches, recorded on the stream the kernels are launched on."""
+
+    def __init__(self, names):
+        self.names, self.pairs, self.open = set(names), {}, {}
+        self.enabled = False
+
+    def __call__(self, name, begin):
+        if not self.enabled or name not in self.names:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        if begin:
+            self.open[name] = ev
+        else:
+            self.pairs.setdefault(name, []).append((self.open.pop(name), ev))
+
+    def mean_ms(self, name):
+        p = self.pairs.get(name, [])
+        return sum(a.elapsed_time(b) for a, b in p) / len(p) if p else None
+
+
+def cpu_baseline(args):
+    """The oracle port (oracle/rua_oracle.{py,c}: numpy + C/OpenMP restatement of the reference's
+    algorithm) on this box's host cores, over a bounded sample of the same workload."""
+    import numpy as np
+
+    from oracle import rua_oracle as orc
+    cores = int(os.environ.get('OMP_NUM_THREADS', os.cpu_count() or 1))
+    B = args.cpu_sample
+    g = torch.Generator().manual_seed(5)
+    lens = torch.randint(args.lo, args.hi + 1, (B,), generator=g)
+    n = int(lens.sum())
+    data = torch.randn((n, args.hidden), generator=g).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    lens_np = lens.numpy()
+    import ctypes
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        srt = torch.sort(lens, descending=True)[1].numpy()                  # core/view.py:48
+        p = orc.to_pack(orc.C(data, lens_np), srt)                          # core/cast.py:41-49
+        c = orc.to_cat(p)                                                   # core/cast.py:8-10  (spelling A,
+        out = np.empty((B, args.hidden), np.float32)                        #  SURVEY.md §8d) + reduce.py:44
+        off = orc.get_offsets(c.token_sizes)
+        orc.lib().orc_segment_sum_bf16(orc._p(c.data), orc._p(c.token_sizes), orc._p(off), ctypes.c_int64(B),
+                                       ctypes.c_int64(args.hidden), orc._p(out))
+        times.append(time.perf_counter() - t0)
+    t = sorted(times)[len(times) // 2]
+    return {'value': round(n * args.hidden / t / 1e6, 1), 'unit': 'M elements/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{B} sequences len~U({args.lo},{args.hi}) hidden={args.hidden} bf16 ({n} rows), '
+                      f'pack -> cat -> segment_sum, median of 3, {t:.2f} s each'}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    import torchrua_amd as ta
+    from torchrua_amd import _ops
+    from torchrua_amd.parallel import all_gather_rows
+
+    lens_host, data = make_inputs(args, rank, dev)
+    B, H = args.batch, args.hidden
+    N, T = int(data.size(0)), int(lens_host.max())
+    e = data.element_size()
+
+    timer = KernelTimer(['to_pack', 'reduce'])
+    _ops.set_kernel_hook(timer)
+
+    def step(host_mirror=True):
+        if host_mirror:
+            c = ta.with_host_sizes(data, lens_host)          # lengths arrive from the host (as in C.new)
+        else:
+            c = ta.C(data, lens_host.to(dev))                 # device-only lengths: pack() must read them back
+        p = c.pack()
+        out = ta.reduce_sum(p)
+        if world > 1:
+            out = all_gather_rows(out)
+        return p, out
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        p, out = step()
+    sync()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+
+    extra = {}
+    if world == 1:                     # the same pipeline with device-only lengths (blocking D2H per pack)
+        sync()
+        k = max(3, args.steps // 4)
+        t1 = time.perf_counter()
+        for _ in range(k):
+            step(host_mirror=False)
+        sync()
+        extra['value_device_lens'] = round(N * H / ((time.perf_counter() - t1) / k) / 1e6, 1)
+
+    # sanity inside the bench: the last step's output is a real PackedSequence and a finite [B, H] sum
+    assert p.data.shape == data.shape and p.batch_sizes.numel() == T and out.shape[-1] == H
+    assert out.shape[0] == B * world
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        ntot = torch.tensor([N], dtype=torch.float64, device=dev)
+        dist.all_reduce(ntot)
+        n_total = float(ntot.item())
+    else:
+        n_total = float(N)
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = n_total * H / (dt / args.steps) / 1e6
+        move_ms, red_ms = timer.mean_ms('to_pack'), timer.mean_ms('reduce')
+        pack_bytes = 2.0 * N * H * e + 8.0 * (3 * B + T)
+        reduce_bytes = 1.0 * N * H * e + 1.0 * B * H * e + 8.0 * B
+        achieved = pack_bytes / (move_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+        if os.path.exists(tpath) and (B, H, args.lo, args.hi) == (65536, 512, 8, 512):
+            with open(tpath) as f:
+                traffic = json.load(f).get('to_pack_hbm_bytes_per_launch')
+        line = {
+            'metric': 'pack->reduce throughput, 65536 seqs/GPU h=512 bf16 (M elements/s) + % HBM roofline',
+            'value': round(value, 1), 'unit': 'M elements/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'pack->reduce_sum: {B} seqs/GPU, len~U({args.lo},{args.hi}), hidden={H}, bf16 '
+                                   f'(north-star shape; N={N} rows on rank 0)',
+                       'sharding': f'{world} x contiguous batch shards, one all-gather of [B,H]' if world > 1 else 'none',
+                       'lens_source': 'host (C.new-style hand-over)'},
+            'roofline': {'bound': 'hbm', 'kernel': 'move_rows_kernel<16,false> (C->P pack)',
+                         'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                         'algorithmic_bytes': pack_bytes, 'avg_ms': round(move_ms, 4)},
+            'reduce_kernel': {'kernel': 'seg_reduce_kernel<bf16,8,SUM> (over P)', 'avg_ms': round(red_ms, 4),
+                              'achieved': round(reduce_bytes / (red_ms * 1e-3) / 1e9, 1), 'unit': 'GB/s',
+                              'frac': round(reduce_bytes / (red_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            'pipeline': {'algorithmic_bytes': pack_bytes + reduce_bytes,
+                         'kernel_ms': round(move_ms + red_ms, 4),
+                         'frac_of_hbm_peak_kernels': round((pack_bytes + reduce_bytes) / ((move_ms + red_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         'frac_of_hbm_peak_wall': round((pack_bytes + reduce_bytes) * world / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world, 4)},
+        }
+        line.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -15,6 +15,24 @@ from torch import Tensor
 from torchrua_amd import _lib as L
 
 
+class host_serial:
+    """Run the tiny host-side metadata ops (a 1-D sort, bincount, cumsum, staging copies of B int64)
+    on ONE thread.  Handing a 512 KB op to a 128-thread OpenMP team costs 10-100x its serial time
+    (measured on the MI355X box: torch.sort of 65 536 lengths 20 ms vs 1.9 ms), and the sort's result
+    does not depend on the thread count (SURVEY.md §8a note)."""
+
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        if self.n != 1:
+            torch.set_num_threads(1)
+        return self
+
+    def __exit__(self, *exc):
+        if self.n != 1:
+            torch.set_num_threads(self.n)
+        return False
+
+
 # ------------------------------------------------------------------ per-tensor memo
 def _memo_get(t: Tensor, key: str):
     memo = t.__dict__.get('_rua_memo')
@@ -69,7 +87,8 @@ def host_lens(token_sizes: Tensor) -> Tensor:
     hit = _memo_get(token_sizes, 'host')
     if hit is not None:
         return hit
-    return _memo_put(token_sizes, 'host', token_sizes.detach().cpu())
+    with host_serial():
+        return _memo_put(token_sizes, 'host', token_sizes.detach().cpu())
 
 
 def attach_host(token_sizes: Tensor, host: Tensor) -> None:
@@ -81,14 +100,17 @@ def max_len(token_sizes: Tensor) -> int:
     hit = _memo_get(token_sizes, 'max')
     if hit is not None:
         return hit
-    return _memo_put(token_sizes, 'max', int(h.max()) if h.numel() else 0)
+    with host_serial():
+        return _memo_put(token_sizes, 'max', int(h.max()) if h.numel() else 0)
 
 
 def total_len(token_sizes: Tensor) -> int:
     hit = _memo_get(token_sizes, 'sum')
     if hit is not None:
         return hit
-    return _memo_put(token_sizes, 'sum', int(host_lens(token_sizes).sum()))
+    h = host_lens(token_sizes)
+    with host_serial():
+        return _memo_put(token_sizes, 'sum', int(h.sum()))
 
 
 def dev_off(token_sizes: Tensor) -> Tensor:
@@ -156,8 +178,9 @@ def batch_sizes_from_host_lens(h: Tensor, T: int) -> Tensor:
     B = h.numel()
     if T == 0:
         return torch.zeros(0, dtype=torch.long)
-    cnt = torch.bincount(h, minlength=T + 1)
-    return B - torch.cumsum(cnt, 0)[:T]
+    with host_serial():
+        cnt = torch.bincount(h, minlength=T + 1)
+        return B - torch.cumsum(cnt, 0)[:T]
 
 
 # ------------------------------------------------------------------ rua_layout descriptors
@@ -209,6 +232,55 @@ def lay_pack(p, lens: Optional[Tensor] = None, len_add: int = 0, boff: Optional[
     return Lay([lens, boff, p.sorted_indices, p.unsorted_indices], kind=L.PACK, n_rows=n_rows, B=pack_B(p),
                lens=L.ptr(lens), len_add=len_add, boff=L.ptr(boff), T=T, sorted=L.ptr(p.sorted_indices),
                unsorted=L.ptr(p.unsorted_indices))
+
+
+class _StagingRing:
+    """A small ring of pinned host buffers for the per-call metadata uploads (lengths, sorted_indices).
+
+    `tensor.pin_memory()` per call is wrong here: while the GPU is busy the caching host allocator
+    cannot recycle blocks whose copy events are still pending, so every call pays a fresh
+    hipHostMalloc (tens of ms on the MI355X box).  The ring reuses SLOTS buffers; before a slot is
+    reused the host waits for that slot's last copy, which also bounds how far the host may run
+    ahead of the stream (SLOTS uploads = a few pipeline steps)."""
+    SLOTS = 8
+
+    def __init__(self):
+        self.bufs = [None] * self.SLOTS
+        self.events = [None] * self.SLOTS
+        self.i = 0
+
+    def upload(self, host: Tensor, dev: torch.device) -> Tensor:
+        i = self.i
+        self.i = (i + 1) % self.SLOTS
+        if self.events[i] is not None:
+            self.events[i].synchronize()
+        nbytes = host.numel() * host.element_size()
+        buf = self.bufs[i]
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, pin_memory=True)
+            self.bufs[i] = buf
+        staged = buf[:nbytes].view(host.dtype).view(host.shape)
+        staged.copy_(host)
+        out = torch.empty(host.shape, dtype=host.dtype, device=dev)
+        out.copy_(staged, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self.events[i] = ev
+        return out
+
+
+_rings = {}
+
+
+def to_device_async(host: Tensor, dev: torch.device) -> Tensor:
+    """Enqueue the H2D of a small contiguous host vector on the current stream without blocking the host."""
+    if dev.type != 'cuda' or host.numel() == 0 or not host.is_contiguous():
+        return host.to(dev)
+    ring = _rings.get(dev)
+    if ring is None:
+        ring = _rings[dev] = _StagingRing()
+    with host_serial():
+        return ring.upload(host, dev)
 
 
 def lay_list(bptr: Optional[Tensor], tptr: Tensor) -> Lay:

@@ -64,7 +64,8 @@ def _sorted_indices(token_sizes: Tensor) -> Tuple[Tensor, Tensor]:
     Its tie order is implementation-defined, so bit-exact parity means making the identical call
     (SURVEY.md §8a note).  Returns (host lengths, sorted_indices on the host)."""
     host = M.host_lens(token_sizes)
-    _, index = torch.sort(host.detach(), descending=True)
+    with M.host_serial():
+        _, index = torch.sort(host.detach(), descending=True)
     return host, index
 
 
@@ -76,7 +77,7 @@ def _pack_meta(token_sizes: Tensor, dev: torch.device):
     host, index = _sorted_indices(token_sizes)
     B = lens.numel()
     T = M.max_len(token_sizes)
-    sorted_indices = index.pin_memory().to(dev, non_blocking=True) if B else index.to(dev)
+    sorted_indices = M.to_device_async(index, dev)
     batch_sizes = M.batch_sizes_from_host_lens(host, T)
     unsorted = torch.empty(B, dtype=torch.long, device=dev)
     bsz_dev = torch.empty(T, dtype=torch.long, device=dev)
@@ -290,10 +291,7 @@ def _new_cat(tensors: List[T]) -> C:
     host mirror so that later pack()/left()/size() never read them back from the device."""
     data = torch.cat(tensors, dim=0)
     host = torch.tensor([tensor.size()[0] for tensor in tensors], dtype=torch.long)
-    if data.is_cuda and host.numel():
-        token_sizes = host.pin_memory().to(data.device, non_blocking=True)
-    else:
-        token_sizes = host.to(data.device)
+    token_sizes = M.to_device_async(host, data.device)
     M.attach_host(token_sizes, host)
     return C(data=data, token_sizes=token_sizes)
 
@@ -307,6 +305,6 @@ R.new = staticmethod(lambda tensors, fill_value=0: _new_cat(tensors).right(fill_
 def with_host_sizes(data: Tensor, token_sizes_host: Tensor) -> C:
     """C(data, token_sizes) from lengths that live on the host (what C.new does for a list)."""
     host = token_sizes_host.to(dtype=torch.long, device='cpu')
-    dev_sizes = host.pin_memory().to(data.device, non_blocking=True) if data.is_cuda and host.numel() else host.to(data.device)
+    dev_sizes = M.to_device_async(host, data.device)
     M.attach_host(dev_sizes, host)
     return C(data=data, token_sizes=dev_sizes)
