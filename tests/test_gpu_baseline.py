@@ -1,0 +1,158 @@
+"""BASELINE.json configurations on the GPU: (i) reduced replicas hashed against the reference's own
+outputs (tests/golden/sha.json), (ii) the FULL sizes through size-independent properties — round trips,
+permutation/sortedness invariants, linearity, agreement between independent kernel paths, and the CPU
+oracle on sampled sequences."""
+import numpy as np
+import pytest
+import torch
+
+import torchrua_amd as ta
+from gpu_util import DEV
+from helpers import golden_sha, orc, seeded_inputs, sha256, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(c):
+    lens, data = seeded_inputs(c['seed'], c['B'], c['lo'], c['hi'], c['H'], getattr(torch, c['dtype']))
+    return lens, data.to(DEV)
+
+
+def test_sha_cfg1_cat_to_pad():
+    c = golden_sha()['cfg1']
+    lens, data = _cfg(c)
+    seqs = list(torch.split(data, lens.tolist()))
+    left = ta.C.new(seqs).left(0)                      # cat_sequence -> pad
+    assert sha256(left.data) == c['left_data'] and sha256(left.token_sizes) == c['left_sizes']
+    assert sha256(ta.C.new(seqs).right(0).data) == c['right_data']
+
+
+def test_sha_cfg2_pack():
+    c = golden_sha()['cfg2']
+    lens, data = _cfg(c)
+    p = ta.with_host_sizes(data, lens).pack()
+    if sha256(p.sorted_indices) != c['sorted_indices']:
+        pytest.skip('host torch.sort tie order on this machine differs from the generating machine')
+    assert sha256(p.data) == c['pack_data'] and sha256(p.batch_sizes) == c['batch_sizes']
+    assert sha256(p.unsorted_indices) == c['unsorted_indices']
+    assert sha256(p.cat().data) == c['cat_back']
+    bp, tp = p.ptr()
+    assert sha256(bp) == c['ptr_batch'] and sha256(tp) == c['ptr_token']
+
+
+def test_sha_cfg3_segment_max():
+    c = golden_sha()['cfg3']
+    lens, data = _cfg(c)
+    assert sha256(ta.segment_max(data, lens.to(DEV))) == c['segment_max']
+    assert sha256(ta.segment_min(data, lens.to(DEV))) == c['segment_min']
+
+
+def test_sha_cfg4_roll_head_last():
+    c = golden_sha()['cfg4']
+    lens, data = _cfg(c)
+    p = ta.with_host_sizes(data, lens).pack()
+    if sha256(p.sorted_indices) != c['sorted_indices']:
+        pytest.skip('host torch.sort tie order on this machine differs from the generating machine')
+    assert sha256(p.roll(1).data) == c['roll1'] and sha256(p.roll(-3).data) == c['roll_neg3']
+    assert sha256(p.last()) == c['last']
+    h = p.head(16)
+    assert sha256(h.data.contiguous()) == c['head16_data'] and sha256(h.batch_sizes) == c['head16_batch_sizes']
+
+
+# ------------------------------------------------------------------ full sizes
+def _device_inputs(seed, B, lo, hi, H):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(lo, hi + 1, (B,), generator=g)
+    n = int(lens.sum())
+    data = torch.empty((n, H), dtype=torch.bfloat16, device=DEV)
+    dg = torch.Generator(device=DEV).manual_seed(seed)
+    step = 1 << 21
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        data[a:b] = torch.randn((b - a, H), generator=dg, device=DEV)
+    return lens, data
+
+
+def _check_pack_invariants(p, lens):
+    bs = p.batch_sizes
+    assert bs.device.type == 'cpu' and bs.dtype == torch.long
+    assert bool((bs[:-1] >= bs[1:]).all()) and int(bs[0]) == lens.numel() and int(bs.sum()) == int(lens.sum())
+    srt = p.sorted_indices.cpu()
+    assert torch.equal(torch.sort(srt)[0], torch.arange(lens.numel()))            # a permutation
+    ls = lens[srt]
+    assert bool((ls[:-1] >= ls[1:]).all())                                        # lengths non-increasing
+    assert torch.equal(p.unsorted_indices.cpu()[srt], torch.arange(lens.numel()))  # inverse permutation
+    assert torch.equal(srt, torch.sort(lens, descending=True)[1])                 # the reference's host call
+
+
+def _oracle_sample_sum(data, lens, picks):
+    off = torch.cumsum(lens, 0) - lens
+    out = []
+    for b in picks:
+        rows = data[int(off[b]):int(off[b]) + int(lens[b])].float().cpu().numpy()
+        out.append(orc.segment_sum(rows, np.array([rows.shape[0]]))[0])
+    return np.stack(out)
+
+
+@pytest.mark.parametrize('shape', [(2, 4096, 8, 512, 256), (5, 65536, 8, 512, 512)], ids=['cfg2', 'north_star'])
+def test_full_pack_reduce(shape):
+    seed, B, lo, hi, H = shape
+    lens, data = _device_inputs(seed, B, lo, hi, H)
+    c = ta.with_host_sizes(data, lens)
+    p = c.pack()
+    _check_pack_invariants(p, lens)
+    assert torch.equal(p.cat().data, data)                              # pack -> cat round trip, bit-exact
+    assert torch.equal(p.cat().token_sizes.cpu(), lens)
+    out_p = ta.reduce_sum(p)                                            # K10: straight over the PackedSequence
+    out_c = ta.segment_sum(data, c.token_sizes)                         # K8: over the CattedSequence
+    assert out_p.shape == (B, H)
+    torch.testing.assert_close(out_p.float(), out_c.float(), rtol=0, atol=0)   # same fp32 order per sequence
+    # linearity: scaling by 2 is exact in bf16
+    assert torch.equal(ta.reduce_sum(p._replace(data=p.data * 2)), out_p * 2)
+    # oracle on sampled sequences (fp32 accumulation; output rounded once to bf16)
+    picks = torch.randperm(B, generator=torch.Generator().manual_seed(0))[:48].tolist()
+    ref = _oracle_sample_sum(data, lens, picks)
+    got = out_p[picks].float().cpu().numpy()
+    # tolerance: 1e-5 relative on the fp32 sum + one bf16 rounding of the output (2^-9 relative)
+    np.testing.assert_allclose(got, ref, rtol=2 ** -8 + 1e-5, atol=1e-3)
+    # a checksum of checksums: total over everything equals the total of the inputs (fp32 on the GPU)
+    torch.testing.assert_close(out_p.float().sum(), data.float().sum(), rtol=2e-3, atol=1.0)
+
+
+def test_full_cfg3_segment_max():
+    lens, data = _device_inputs(3, 16384, 1, 64, 512)
+    out = ta.segment_max(data, lens.to(DEV))
+    ref = orc.segment_max((to_np(data).astype(np.uint32) << 16).view(np.float32), lens.numpy())
+    assert np.array_equal(out.float().cpu().numpy(), ref)               # max is exact in any dtype
+    d = ta.C(data=torch.ones(16384, dtype=torch.long, device=DEV), token_sizes=torch.ones(16384, dtype=torch.long, device=DEV))
+    via_seg = ta.C(data, lens.to(DEV)).seg(ta.C(lens.to(DEV), d.token_sizes), ta.segment_max)
+    assert torch.equal(via_seg.data, out)                               # C.seg with one run per sequence
+
+
+def test_full_cfg4_roll_head_last():
+    free, _ = torch.cuda.mem_get_info()
+    B, H = 65536, 1024
+    if free < 230e9:
+        B = 16384
+    lens, data = _device_inputs(4, B, 16, 1024, H)
+    p = ta.with_host_sizes(data, lens).pack()
+    del data
+    _check_pack_invariants(p, lens)
+    r = p.roll(1)
+    assert torch.equal(r.batch_sizes, p.batch_sizes) and r.sorted_indices is p.sorted_indices
+    back = r.roll(-1)
+    assert torch.equal(back.data, p.data)                               # roll(1) then roll(-1) = identity
+    del back
+    # roll(1) moves the last token of every sequence to the front
+    assert torch.equal(r.head(1).data[:B], p.last()[p.sorted_indices])
+    assert torch.equal(r.last(), ta.P(p.data, p.batch_sizes, p.sorted_indices, p.unsorted_indices).trunc((0, 1)).last())
+    del r
+    h = p.head(16)
+    assert h.data.data_ptr() == p.data.data_ptr() and h.data.shape[0] == B * 16   # a view, as in the reference
+    c16 = h.cat()
+    assert c16.token_sizes.tolist() == [16] * B
+    last = p.last()
+    off = (torch.cumsum(lens, 0) - lens)
+    c = p.cat()
+    assert torch.equal(last, c.data[(off + lens - 1).to(DEV)])
+    assert torch.equal(c16.data.view(B, 16, H)[:, 0], c.data[off.to(DEV)])

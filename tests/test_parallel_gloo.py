@@ -1,0 +1,79 @@
+"""The N>1 path on CPU: world_size 2 over gloo.  The per-rank compute is the HIP path on a GPU box; here
+(no GPU) the oracle stands in for it so that sharding + the all-gather are what is under test."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import orc
+from torchrua_amd.parallel import all_gather_rows, shard_bounds, sharded_reduce
+
+
+def test_shard_bounds_cover_and_order():
+    for n in (0, 1, 7, 8, 65536, 524288, 524291):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, B, H, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(7)
+        lens = torch.randint(1, 20, (B,), generator=g)
+        data = torch.randn(int(lens.sum()), H, generator=g)
+        lo, hi = shard_bounds(B, rank, world)
+        off = torch.cumsum(lens, 0) - lens
+        row_lo = int(off[lo]) if lo < B else int(lens.sum())
+        row_hi = int(off[hi - 1] + lens[hi - 1]) if hi > lo else row_lo
+
+        def local():   # this rank's pack -> reduce over its own sequences only
+            l, d = lens[lo:hi].numpy(), data[row_lo:row_hi].numpy()
+            p = orc.to_pack(orc.C(d, l), orc.stable_descending_order(l))
+            return torch.from_numpy(orc.segment_sum(orc.to_cat(p).data, l))
+
+        out = sharded_reduce(local, n_total=B)
+        full = torch.from_numpy(orc.segment_sum(data.numpy(), lens.numpy()))
+        ok = torch.equal(out, full) and out.shape == (B, H)
+        same = all_gather_rows(torch.full((1, 2), float(rank)))
+        ok = ok and same[:, 0].tolist() == [float(r) for r in range(world)]
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(B):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, 5, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results == [(0, True), (1, True)]
+
+
+def test_two_rank_gather_even():
+    _run(64)       # equal shards: one all_gather_into_tensor
+
+
+def test_two_rank_gather_ragged():
+    _run(37)       # 19 + 18 sequences: the ragged all_gather path

@@ -25,7 +25,7 @@ def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
 
 def all_gather_rows(local: Tensor, n_total: Optional[int] = None, group=None) -> Tensor:
     """Concatenate every rank's [n_r, *H] rows in rank order.  Equal shards use one
-    all_gather_into_tensor (a single ncclAllGather); ragged shards fall back to all_gather."""
+    all_gather_into_tensor (a single ncclAllGather); shards that differ by a row are padded to the widest."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     local = local.contiguous()
@@ -37,8 +37,15 @@ def all_gather_rows(local: Tensor, n_total: Optional[int] = None, group=None) ->
     out = local.new_empty((n_total,) + tuple(local.shape[1:]))
     if n_total % world == 0:
         dist.all_gather_into_tensor(out, local, group=group)
-    else:
-        dist.all_gather([out[lo:hi] for lo, hi in sizes], local, group=group)
+        return out
+    # shards differ by one row: pad to the largest, gather once, drop the padding rows
+    widest = max(hi - lo for lo, hi in sizes)
+    padded = local.new_zeros((widest,) + tuple(local.shape[1:]))
+    padded[:local.size(0)] = local
+    tmp = local.new_empty((world * widest,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(tmp, padded, group=group)
+    for r, (lo, hi) in enumerate(sizes):
+        out[lo:hi] = tmp[r * widest:r * widest + (hi - lo)]
     return out
 
 
