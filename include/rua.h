@@ -77,6 +77,8 @@ enum rua_tmap {
 
 #define RUA_MOVE_SCATTER 1  /* flags: enumerate `dst` layout rows as the SOURCE rows and write
                                them to the rows computed from `src` layout (core/set.py)        */
+#define RUA_MOVE_NT_ON   2  /* force / forbid non-temporal payload accesses; default: on when the   */
+#define RUA_MOVE_NT_OFF  4  /* destination is >= 512 MiB (cannot stay in the 256 MiB Infinity Cache) */
 
 /* K1. Exclusive prefix sum of n int64 (wavefront scan).  out[i] = sum(in[0..i)).
  * `ws` must hold rua_scan_ws_elems(n) int64.  If total != NULL, *total (device) = sum(in).

@@ -1,0 +1,96 @@
+"""Developer bench (not the driver's bench.py): every BASELINE.json config + a few conversions,
+algorithmic bytes per SURVEY.md §8(d), HIP-event timing, one process."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torchrua_amd as ta  # noqa: E402
+
+dev = torch.device('cuda:0')
+
+
+def inputs(seed, B, lo, hi, H, dtype=torch.bfloat16):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(lo, hi + 1, (B,), generator=g)
+    n = int(lens.sum())
+    data = torch.empty((n, H), dtype=dtype, device=dev)
+    step = 1 << 21
+    for a in range(0, n, step):
+        data[a:min(n, a + step)] = torch.randn((min(n, a + step) - a, H), device=dev)
+    return lens, data
+
+
+def timeit(name, fn, nbytes, iters=10):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    ms = ts[len(ts) // 2]
+    print(f'{name:44s} {ms:9.3f} ms  {nbytes / 1e9:8.2f} GB  {nbytes / ms / 1e9:6.2f} TB/s  ({nbytes / ms / 1e9 / 8 * 100:4.1f} % of 8 TB/s)')
+
+
+def main():
+    e = 2
+    print('--- cfg2: B=4096 U(8,512) H=256 bf16')
+    lens, data = inputs(2, 4096, 8, 512, 256)
+    c = ta.with_host_sizes(data, lens)
+    N, H, B = data.size(0), 256, 4096
+    p = c.pack()
+    timeit('c.pack()', lambda: c.pack(), 2 * N * H * e)
+    timeit('reduce_sum(p)', lambda: ta.reduce_sum(p), N * H * e + B * H * e)
+    timeit('p.cat()', lambda: p.cat(), 2 * N * H * e)
+    timeit('segment_sum(c)', lambda: ta.segment_sum(c.data, c.token_sizes), N * H * e + B * H * e)
+    T = int(lens.max())
+    timeit('c.left()  (pad)', lambda: c.left(), N * H * e + B * T * H * e)
+
+    print('--- cfg3: 16384 segments U(1,64) H=512 bf16')
+    lens, data = inputs(3, 16384, 1, 64, 512)
+    ld = lens.to(dev)
+    N, H, S = data.size(0), 512, 16384
+    for name in ('max', 'sum', 'logsumexp'):
+        fn = getattr(ta, f'segment_{name}')
+        timeit(f'segment_{name}', lambda: fn(data, ld), N * H * e + S * H * e)
+
+    print('--- north star: B=65536 U(8,512) H=512 bf16')
+    lens, data = inputs(5, 65536, 8, 512, 512)
+    c = ta.with_host_sizes(data, lens)
+    N, H, B = data.size(0), 512, 65536
+    p = c.pack()
+    timeit('c.pack()', lambda: c.pack(), 2 * N * H * e)
+    timeit('reduce_sum(p)', lambda: ta.reduce_sum(p), N * H * e + B * H * e)
+    timeit('reduce_max(p)', lambda: ta.reduce_max(p), N * H * e + B * H * e)
+    timeit('reduce_logsumexp(p)', lambda: ta.reduce_logsumexp(p), N * H * e + B * H * e)
+    timeit('p.cat()', lambda: p.cat(), 2 * N * H * e)
+    timeit('segment_sum(c)', lambda: ta.segment_sum(c.data, c.token_sizes), N * H * e + B * H * e)
+    T = int(lens.max())
+    timeit('c.left()  (pad)', lambda: c.left(), N * H * e + B * T * H * e)
+    timeit('p.left()  (pad from pack)', lambda: p.left(), N * H * e + B * T * H * e)
+    lft = c.left()
+    timeit('l.cat()   (unpad)', lambda: lft.cat(), 2 * N * H * e)
+    timeit('l.pack()', lambda: lft.pack(), 2 * N * H * e)
+    del lft, p, c, data
+
+    print('--- cfg4: B=65536 U(16,1024) H=1024 bf16')
+    free, _ = torch.cuda.mem_get_info()
+    B = 65536 if free > 230e9 else 16384
+    lens, data = inputs(4, B, 16, 1024, 1024)
+    N, H = data.size(0), 1024
+    p = ta.with_host_sizes(data, lens).pack()
+    del data
+    timeit('p.roll(1)', lambda: p.roll(1), 2 * N * H * e, iters=5)
+    timeit('p.last()', lambda: p.last(), 2 * B * H * e)
+    timeit('p.head(16) (view)', lambda: p.head(16), 1)
+    timeit('p.rev()', lambda: p.rev(), 2 * N * H * e, iters=5)
+
+
+if __name__ == '__main__':
+    main()

@@ -19,25 +19,41 @@ namespace rua {
 constexpr int TILE_ROWS = 256;  // == RUA_BLOCK: one lane per row in phase 1
 constexpr int UNROLL = 4;       // row groups in flight per wave in phase 2
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
 template <int VEC> struct vec_of;
-template <> struct vec_of<16> { using type = uint4; };
-template <> struct vec_of<8>  { using type = uint2; };
+template <> struct vec_of<16> { using type = u32x4; };
+template <> struct vec_of<8>  { using type = u32x2; };
 template <> struct vec_of<4>  { using type = uint32_t; };
 template <> struct vec_of<2>  { using type = uint16_t; };
 template <> struct vec_of<1>  { using type = uint8_t; };
 
 template <int VEC> __device__ __forceinline__ typename vec_of<VEC>::type fill_of(uint4 p);
-template <> __device__ __forceinline__ uint4    fill_of<16>(uint4 p) { return p; }
-template <> __device__ __forceinline__ uint2    fill_of<8>(uint4 p)  { return make_uint2(p.x, p.y); }
+template <> __device__ __forceinline__ u32x4    fill_of<16>(uint4 p) { u32x4 v = {p.x, p.y, p.z, p.w}; return v; }
+template <> __device__ __forceinline__ u32x2    fill_of<8>(uint4 p)  { u32x2 v = {p.x, p.y}; return v; }
 template <> __device__ __forceinline__ uint32_t fill_of<4>(uint4 p)  { return p.x; }
 template <> __device__ __forceinline__ uint16_t fill_of<2>(uint4 p)  { return (uint16_t)p.x; }
 template <> __device__ __forceinline__ uint8_t  fill_of<1>(uint4 p)  { return (uint8_t)p.x; }
+
+// NT: non-temporal (streaming) accesses for payloads far larger than the 256 MiB Infinity Cache —
+// every byte is touched exactly once, so keeping it in L2/MALL only evicts the index vectors.
+// Measured at the north-star shape: 6.53 -> 6.26 ms (+4 %).  Small payloads keep the default policy
+// so that a following kernel can still find them in cache.
+template <typename V, bool NT> __device__ __forceinline__ V ld_row(const char* p) {
+  if (NT) return __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+  return *reinterpret_cast<const V*>(p);
+}
+template <typename V, bool NT> __device__ __forceinline__ void st_row(char* p, V v) {
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<V*>(p));
+  else *reinterpret_cast<V*>(p) = v;
+}
 
 // lpr      : lanes (VEC-byte columns) per row = ceil(row_bytes / VEC)
 // lp_log2  : log2 of lanes a wave gives one row per instruction (<= 6); rows narrower than
 //            1 KiB share a wave instruction (64 >> lp_log2 rows at a time)
 // cpr      : 64-lane column chunks per row (1 unless row_bytes > 64*VEC)
-template <int VEC, bool SCATTER>
+template <int VEC, bool SCATTER, bool NT>
 __global__ __launch_bounds__(RUA_BLOCK) void move_rows_kernel(rua_layout D, rua_layout S, int32_t tmap,
                                                               int64_t targ, char* __restrict__ dst,
                                                               const char* __restrict__ src, int64_t row_bytes,
@@ -92,12 +108,12 @@ __global__ __launch_bounds__(RUA_BLOCK) void move_rows_kernel(rua_layout D, rua_
         if (colok && r < nrows) {
           const int64_t ld = s_ld[r];
           st[u] = s_st[r];
-          if (ld >= 0 && st[u] >= 0) val[u] = *reinterpret_cast<const V*>(src + ld * row_bytes + col * VEC);
+          if (ld >= 0 && st[u] >= 0) val[u] = ld_row<V, NT>(src + ld * row_bytes + col * VEC);
         }
       }
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u)
-        if (st[u] >= 0) *reinterpret_cast<V*>(dst + st[u] * row_bytes + col * VEC) = val[u];
+        if (st[u] >= 0) st_row<V, NT>(dst + st[u] * row_bytes + col * VEC, val[u]);
     }
   }
 }
@@ -123,7 +139,7 @@ static int check_layout(const rua_layout* L, bool is_dst) {
   return RUA_EINVAL;
 }
 
-template <bool SCATTER>
+template <bool SCATTER, bool NT>
 static int launch_move(int vec, unsigned grid, hipStream_t s, const rua_layout& D, const rua_layout& S, int32_t tmap,
                        int64_t targ, char* dst, const char* src, int64_t row_bytes, uint4 fp, int64_t pad_row) {
   const int64_t lpr = (row_bytes + vec - 1) / vec;
@@ -132,7 +148,7 @@ static int launch_move(int vec, unsigned grid, hipStream_t s, const rua_layout& 
   const int cpr = (int)((lpr + RUA_WAVE - 1) / RUA_WAVE);
   const dim3 g(grid), b(RUA_BLOCK);
 #define RUA_LAUNCH(VEC) \
-  hipLaunchKernelGGL((move_rows_kernel<VEC, SCATTER>), g, b, 0, s, D, S, tmap, targ, dst, src, row_bytes, lpr, lp_log2, cpr, fp, pad_row)
+  hipLaunchKernelGGL((move_rows_kernel<VEC, SCATTER, NT>), g, b, 0, s, D, S, tmap, targ, dst, src, row_bytes, lpr, lp_log2, cpr, fp, pad_row)
   switch (vec) {
     case 16: RUA_LAUNCH(16); break;
     case 8:  RUA_LAUNCH(8); break;
@@ -171,9 +187,14 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
     fp = make_uint4(f[0], f[1], f[2], f[3]);
   }
   hipStream_t s = (hipStream_t)stream;
+  const bool big = (double)dst->n_rows * (double)row_bytes >= (double)(512ll << 20);
+  const bool nt = (flags & RUA_MOVE_NT_ON) ? true : (flags & RUA_MOVE_NT_OFF) ? false : big;
+  char* d = (char*)dst_data;
+  const char* c = (const char*)src_data;
+  const unsigned g = (unsigned)ntiles;
   if (flags & RUA_MOVE_SCATTER)
-    return launch_move<true>(vec, (unsigned)ntiles, s, *dst, *src, tmap, tmap_arg, (char*)dst_data,
-                             (const char*)src_data, row_bytes, fp, pad_row);
-  return launch_move<false>(vec, (unsigned)ntiles, s, *dst, *src, tmap, tmap_arg, (char*)dst_data,
-                            (const char*)src_data, row_bytes, fp, pad_row);
+    return nt ? launch_move<true, true>(vec, g, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row)
+              : launch_move<true, false>(vec, g, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row);
+  return nt ? launch_move<false, true>(vec, g, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row)
+            : launch_move<false, false>(vec, g, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row);
 }

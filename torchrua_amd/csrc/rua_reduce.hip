@@ -75,7 +75,7 @@ __device__ __forceinline__ double unordered_f64(uint64_t u) {
 
 // ---------------------------------------------------------------- the kernel
 // EPL: elements per lane per load (16 B / sizeof(T) on the vector path, 1 on the scalar path)
-template <typename T, int EPL, int OP>
+template <typename T, int EPL, int OP, bool NT>
 __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, const int64_t* __restrict__ perm,
                                                               const T* __restrict__ data, T* __restrict__ out,
                                                               int64_t H, int lp_log2, int64_t n_chunks,
@@ -83,6 +83,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
                                                               unsigned long long* __restrict__ extreme) {
   using A = typename elem<T>::acc;
   struct alignas(sizeof(T) * EPL) Pack { T v[EPL]; };
+  typedef unsigned int RawV __attribute__((ext_vector_type(sizeof(T) * EPL >= 4 ? sizeof(T) * EPL / 4 : 1)));
 
   // ONE wave per workgroup: sequences differ in length, and a multi-wave workgroup would hold
   // its CU slots until its longest sequence is done.
@@ -143,7 +144,15 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
       }
 #pragma unroll
       for (int u = 0; u < UNROLL_T; ++u)
-        if (row[u] >= 0) p[u] = *reinterpret_cast<const Pack*>(data + row[u] * H + col);
+        if (row[u] >= 0) {
+          const T* src = data + row[u] * H + col;
+          if (NT && sizeof(Pack) >= 4) {   // streaming read of a payload that cannot stay in cache
+            RawV raw = __builtin_nontemporal_load(reinterpret_cast<const RawV*>(src));
+            __builtin_memcpy(&p[u], &raw, sizeof(Pack));
+          } else {
+            p[u] = *reinterpret_cast<const Pack*>(src);
+          }
+        }
 #pragma unroll
       for (int u = 0; u < UNROLL_T; ++u) {
         if (row[u] < 0) continue;
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(RUA_BLOCK) void fill_empty_kernel(rua_layout L, T* 
 
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + RUA_BLOCK - 1) / RUA_BLOCK); }
 
-template <typename T, int EPL>
+template <typename T, int EPL, bool NT>
 static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout& L, const int64_t* perm,
                          const void* data, void* out, int64_t H, int lp_log2, int64_t n_chunks, int include_self,
                          uint64_t empty_bits, void* extreme) {
@@ -273,7 +282,7 @@ static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout&
   __builtin_memcpy(&ev, &empty_bits, sizeof(T));
   const dim3 g(grid), b(RUA_WAVE);
 #define RUA_LAUNCH(OP)                                                                                          \
-  hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP>), g, b, 0, s, L, perm, (const T*)data, (T*)out, H, lp_log2, \
+  hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT>), g, b, 0, s, L, perm, (const T*)data, (T*)out, H, lp_log2, \
                      n_chunks, include_self, ev, (unsigned long long*)extreme)
   switch (op) {
     case RUA_SUM: RUA_LAUNCH(RUA_SUM); break;
@@ -300,11 +309,15 @@ static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int
   const int64_t n_chunks = (lpr + RUA_WAVE - 1) / RUA_WAVE;
   const int64_t blocks = L.B * n_chunks;  // one wave per workgroup
   if (blocks > 0x7fffffffLL) return RUA_ERANGE;
+  const bool nt = (double)L.n_rows * (double)H * sizeof(T) >= (double)(512ll << 20);
+  if (vec_ok && nt)
+    return launch_reduce<T, FULL, true>(op, (unsigned)blocks, s, L, perm, data, out, H, lp_log2, n_chunks,
+                                        include_self, empty_bits, extreme);
   if (vec_ok)
-    return launch_reduce<T, FULL>(op, (unsigned)blocks, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
-                                  empty_bits, extreme);
-  return launch_reduce<T, 1>(op, (unsigned)blocks, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
-                             empty_bits, extreme);
+    return launch_reduce<T, FULL, false>(op, (unsigned)blocks, s, L, perm, data, out, H, lp_log2, n_chunks,
+                                         include_self, empty_bits, extreme);
+  return launch_reduce<T, 1, false>(op, (unsigned)blocks, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
+                                    empty_bits, extreme);
 }
 
 }  // namespace rua
