@@ -144,12 +144,12 @@ def pack_bsz_dev(p) -> Tensor:
 
 
 def pack_lens(p) -> Tensor:
-    """token_sizes of a PackedSequence in batch order (K3b) — reference core/view.py:21-25."""
-    anchor = p.unsorted_indices if p.unsorted_indices is not None else p.batch_sizes
-    key = f'lens:{id(p.batch_sizes)}:{p.batch_sizes._version}'
-    hit = _memo_get(anchor, key)
-    if hit is not None:
-        return hit
+    """token_sizes of a PackedSequence in batch order (K3b) — reference core/view.py:21-25.
+    Memoised on the batch_sizes OBJECT together with the unsorted_indices object it was derived with
+    (identity-checked: a slice such as P.head's batch_sizes[:n] is a new object and starts clean)."""
+    hit = _memo_get(p.batch_sizes, 'lens')
+    if hit is not None and hit[0] is p.unsorted_indices and hit[1].device == p.data.device:
+        return hit[1]
     dev = L.require_device(p.data)
     lib = L.load()
     B, T = pack_B(p), p.batch_sizes.numel()
@@ -160,7 +160,8 @@ def pack_lens(p) -> Tensor:
     # T and sum are known on the host for free
     _memo_put(lens, 'max', T)
     _memo_put(lens, 'sum', int(p.data.size(0)))
-    return _memo_put(anchor, key, lens)
+    _memo_put(p.batch_sizes, 'lens', (p.unsorted_indices, lens))
+    return lens
 
 
 def adopt_pack(p, lens: Tensor, boff: Tensor, bsz_dev: Tensor) -> None:
@@ -168,8 +169,7 @@ def adopt_pack(p, lens: Tensor, boff: Tensor, bsz_dev: Tensor) -> None:
     dev = p.data.device
     _memo_put(p.batch_sizes, f'boff:{dev}', boff)
     _memo_put(p.batch_sizes, f'dev:{dev}', bsz_dev)
-    anchor = p.unsorted_indices if p.unsorted_indices is not None else p.batch_sizes
-    _memo_put(anchor, f'lens:{id(p.batch_sizes)}:{p.batch_sizes._version}', lens)
+    _memo_put(p.batch_sizes, 'lens', (p.unsorted_indices, lens))
 
 
 def batch_sizes_from_host_lens(h: Tensor, T: int) -> Tensor:

@@ -49,6 +49,12 @@ template <> __device__ __forceinline__ double acc_inf<double>() { return __built
 template <typename A> __device__ __forceinline__ A nmax(A a, A b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
 template <typename A> __device__ __forceinline__ A nmin(A a, A b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
 
+// NaN-ignoring max/min (one v_max_f32 / v_min_f32)
+__device__ __forceinline__ float fmaxx(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double fmaxx(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float fminx(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double fminx(double a, double b) { return fmin(a, b); }
+
 __device__ __forceinline__ float fexp(float x) { return __expf(x); }
 __device__ __forceinline__ double fexp(double x) { return exp(x); }
 __device__ __forceinline__ float flog(float x) { return logf(x); }
@@ -117,11 +123,13 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
   A acc[EPL], aux[EPL];  // aux: running sum for LOGSUMEXP (acc holds the running max)
   A ext = (OP == RUA_MAX || OP == RUA_LOGSUMEXP) ? acc_inf<A>() : -acc_inf<A>();
   bool ext_nan = false;
+  bool nan_e[EPL];
 #pragma unroll
   for (int e = 0; e < EPL; ++e) {
     acc[e] = (OP == RUA_PROD) ? (A)1 : (OP == RUA_MAX || OP == RUA_LOGSUMEXP) ? -acc_inf<A>()
            : (OP == RUA_MIN) ? acc_inf<A>() : (A)0;
     aux[e] = (A)0;
+    nan_e[e] = false;
   }
 
   // the row table (boff / perm) is fetched 64 entries at a time with one coalesced load and
@@ -153,27 +161,52 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
             p[u] = *reinterpret_cast<const Pack*>(src);
           }
         }
-#pragma unroll
-      for (int u = 0; u < UNROLL_T; ++u) {
-        if (row[u] < 0) continue;
+      if (OP == RUA_LOGSUMEXP) {
+        // chunk-wise online logsumexp: the chunk's max first, ONE rescale of the running sum per
+        // chunk, then one fma + one v_exp per element (exp(x - m) = exp2(x*log2e - m*log2e))
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-          const A x = elem<T>::up(p[u].v[e]);
-          if (OP == RUA_SUM || OP == RUA_MEAN) acc[e] += x;
-          else if (OP == RUA_PROD) acc[e] *= x;
-          else if (OP == RUA_MAX) acc[e] = nmax(acc[e], x);
-          else if (OP == RUA_MIN) acc[e] = nmin(acc[e], x);
-          else {  // online logsumexp: acc = running max m, aux = sum exp(x - m)
-            if (x > acc[e]) { aux[e] = aux[e] * fexp(acc[e] - x) + (A)1; acc[e] = x; }
-            else if (x == x) aux[e] += fexp(x - acc[e]);
-            else { acc[e] = x; aux[e] = x; }  // NaN poisons
+          A x[UNROLL_T];
+          A cm = -acc_inf<A>();
+#pragma unroll
+          for (int u = 0; u < UNROLL_T; ++u) {
+            x[u] = row[u] >= 0 ? elem<T>::up(p[u].v[e]) : -acc_inf<A>();
+            cm = fmaxx(cm, x[u]);
+            if (row[u] >= 0) { ext = fminx(ext, x[u]); ext_nan |= (x[u] != x[u]); }
           }
-          if (OP == RUA_MAX || OP == RUA_LOGSUMEXP) { ext = x < ext ? x : ext; ext_nan |= (x != x); }
-          if (OP == RUA_MIN) { ext = x > ext ? x : ext; ext_nan |= (x != x); }
+          if (cm > acc[e]) { aux[e] *= fexp(acc[e] - cm); acc[e] = cm; }
+          const A m = acc[e];
+#pragma unroll
+          for (int u = 0; u < UNROLL_T; ++u)
+            if (row[u] >= 0) aux[e] += fexp(x[u] - m);   // NaN x -> NaN sum; all -inf -> NaN, as the reference
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < UNROLL_T; ++u) {
+          if (row[u] < 0) continue;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            const A x = elem<T>::up(p[u].v[e]);
+            if (OP == RUA_SUM || OP == RUA_MEAN) acc[e] += x;
+            else if (OP == RUA_PROD) acc[e] *= x;
+            else if (OP == RUA_MAX) {   // v_max ignores NaN: NaNs are tracked on the side (a scalar mask OR)
+              acc[e] = fmaxx(acc[e], x); nan_e[e] |= (x != x); ext = fminx(ext, x);
+            } else if (OP == RUA_MIN) {
+              acc[e] = fminx(acc[e], x); nan_e[e] |= (x != x); ext = fmaxx(ext, x);
+            }
+          }
         }
       }
     }
     tv = tv_next;
+  }
+
+  if (OP == RUA_MAX || OP == RUA_MIN) {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      if (nan_e[e]) acc[e] = acc[e] - acc[e] + (A)__builtin_nanf("");   // torch: max/min propagate NaN
+      ext_nan |= nan_e[e];
+    }
   }
 
   // combine the rpw row-groups of the wave (lanes that differ in the bits above lp_log2)
@@ -254,11 +287,13 @@ __global__ __launch_bounds__(RUA_BLOCK) void fill_empty_kernel(rua_layout L, T* 
                                                                int want_max_of_data,
                                                                const unsigned long long* __restrict__ ext) {
   using A = typename elem<T>::acc;
-  // decode the tracked extreme (all threads, 65 cached loads)
-  unsigned long long best = ext[0];
-  for (int i = 1; i < EXTREME_SLOTS; ++i) {
-    const unsigned long long v = ext[i];
-    best = want_max_of_data ? (v > best ? v : best) : (v < best ? v : best);
+  // decode the tracked extreme: lane i reads slot i, 6-step butterfly
+  const int lane = threadIdx.x & (RUA_WAVE - 1);
+  unsigned long long best = ext[lane];
+#pragma unroll
+  for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {
+    const unsigned long long o = __shfl_xor(best, d, RUA_WAVE);
+    best = want_max_of_data ? (o > best ? o : best) : (o < best ? o : best);
   }
   const bool poison = ext[EXTREME_SLOTS] != 0ull;
   A val;
@@ -266,10 +301,12 @@ __global__ __launch_bounds__(RUA_BLOCK) void fill_empty_kernel(rua_layout L, T* 
   if (poison) val = val - val + (A)__builtin_nanf("");
   const T tv = elem<T>::down(val);
 
-  const int64_t i = (int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x;
-  if (i >= L.B * H) return;
-  const int64_t b = i / H;
-  if (poison || seq_len(L, b) <= 0) out[i] = tv;
+  // one thread per sequence; only empty sequences (or everything, when a NaN poisoned `initial`) are written
+  const int64_t b = (int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x;
+  if (b >= L.B) return;
+  if (!poison && seq_len(L, b) > 0) return;
+  T* o = out + b * H;
+  for (int64_t h = 0; h < H; ++h) o[h] = tv;
 }
 
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + RUA_BLOCK - 1) / RUA_BLOCK); }
@@ -359,7 +396,7 @@ int rua_fill_empty(const rua_layout* lay, void* out, int64_t H, int32_t dtype, i
   if (n == 0) return 0;
   if (!out) return RUA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const dim3 g(grid_for(n)), b(RUA_BLOCK);
+  const dim3 g(grid_for(lay->B)), b(RUA_BLOCK);
   const int wmax = op == RUA_MIN ? 1 : 0;
   const unsigned long long* e = (const unsigned long long*)extreme;
   switch (dtype) {
