@@ -123,11 +123,13 @@ def layout_case(case, lens, H, dtype, seed):
         put(case, f'setitem.{k}', z2.data)
 
 
-def reduce_case(case, lens, H, seed, zero_len=False):
+def reduce_case(case, lens, H, seed, zero_len=False, nan_at=None):
     g = torch.Generator().manual_seed(seed)
     lens = torch.as_tensor(lens, dtype=torch.long)
     N = int(lens.sum())
     data = torch.randn((N, H), generator=g)
+    if nan_at is not None:
+        data[nan_at] = float('nan')
     put(case, 'lens', lens)
     put(case, 'data', data)
     for name in ('max', 'min', 'sum', 'mean', 'prod', 'logsumexp', 'head', 'last'):
@@ -271,6 +273,8 @@ def main():
     zl = rng.randint(0, 4, 30)
     zl[0] = 3
     reduce_case('reduce.zero_len', zl, 6, seed=203, zero_len=True)
+
+    reduce_case('reduce.nan', rng.randint(1, 5, 6), 4, seed=204, nan_at=(3, 2))
 
     seg_case('seg.a', rng.randint(1, 9, 7), 3, seed=300)
     seg_case('seg.b', rng.randint(1, 25, 20), 5, seed=301)

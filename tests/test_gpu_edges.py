@@ -1,0 +1,152 @@
+"""Edge cases through the C ABI vs the CPU oracle: odd row widths (every vector width of the mover and
+the scalar path of the reducer), rows wider than a wave instruction, multi-dim hidden, integer payloads,
+single-token / single-sequence batches, zero-length segments, non-contiguous inputs, huge shifts."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import given, settings, strategies as st
+
+import torchrua_amd as ta
+from gpu_util import DEV, assert_same_seq, dev_seq, host_sort
+from helpers import orc, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(lens, hidden, dtype, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    n = int(sum(lens))
+    if dtype in (torch.long, torch.int32, torch.uint8, torch.int16):
+        data = torch.randint(0, 100, (n,) + tuple(hidden), generator=g).to(dtype)
+    else:
+        data = torch.randn((n,) + tuple(hidden), generator=g).to(dtype)
+    return data, torch.tensor(lens, dtype=torch.long)
+
+
+WIDTHS = [((1,), torch.uint8), ((3,), torch.uint8), ((1,), torch.int16), ((3,), torch.float16), ((1,), torch.float32),
+          ((33,), torch.float32), ((6,), torch.float32), ((1,), torch.long), ((2,), torch.long), ((5,), torch.long),
+          ((300,), torch.float32), ((1024,), torch.bfloat16), ((1030,), torch.bfloat16), ((4, 3), torch.float32),
+          ((2, 3, 5), torch.float64), ((), torch.float32), ((513,), torch.float16)]
+
+
+@pytest.mark.parametrize('hidden,dtype', WIDTHS, ids=[f'{h}-{str(d)[6:]}' for h, d in WIDTHS])
+def test_all_casts_and_selects_any_row_width(hidden, dtype):
+    lens = [3, 1, 7, 2, 7, 4, 1, 5, 6, 2, 3, 3, 9, 1, 2, 8, 4, 4, 2]
+    data, lt = _mk(lens, hidden, dtype)
+    bf = dtype == torch.bfloat16
+    srt = host_sort(lens)
+    oc = orc.C(to_np(data), lt.numpy())
+    fill = 0
+    osq = {'C': oc, 'L': orc.to_left(oc, fill), 'P': orc.to_pack(oc, srt), 'R': orc.to_right(oc, fill)}
+    dsq = {k: dev_seq(v, bf16=bf) for k, v in osq.items()}
+    for k, z in dsq.items():
+        for dst in 'CLPR':
+            out = {'C': z.cat, 'P': z.pack, 'L': z.left, 'R': z.right}[dst]()
+            assert_same_seq(out, orc.to_kind(osq[k], dst, fill, srt), f'{k}->{dst}')
+        for s in (-20, -1, 3, 9, 1000003):
+            assert_same_seq(z.roll(s), orc.roll(osq[k], s, srt), f'roll {k} {s}')
+        assert_same_seq(z.rev(), orc.rev(osq[k], srt), f'rev {k}')
+        assert np.array_equal(to_np(z.last()), orc.last(osq[k])), f'last {k}'
+        h = z.head(1)
+        assert_same_seq(h._replace(data=h.data.contiguous()), orc.head(osq[k], 1), f'head {k}')
+
+
+@settings(deadline=None, max_examples=40)
+@given(lens=st.lists(st.integers(1, 40), min_size=1, max_size=40), h=st.integers(1, 70),
+       dtype=st.sampled_from([torch.float32, torch.bfloat16, torch.float16, torch.float64]),
+       name=st.sampled_from(['sum', 'mean', 'max', 'min', 'prod', 'logsumexp']), kind=st.sampled_from('CLPR'))
+def test_reduce_any_width_dtype_layout(lens, h, dtype, name, kind):
+    data, lt = _mk(lens, (h,), dtype)
+    data = (data * 0.5).to(dtype)
+    f = data.double().numpy() if dtype == torch.float64 else data.float().numpy()
+    ref = getattr(orc, f'segment_{name}')(f, lt.numpy())                 # reference semantics on the upcast input
+    z = {'C': lambda c: c, 'L': lambda c: c.left(), 'P': lambda c: c.pack(), 'R': lambda c: c.right()}[kind](
+        ta.C(data.to(DEV), lt.to(DEV)))
+    out = getattr(ta, f'reduce_{name}')(z)
+    assert out.dtype == dtype and out.shape == (len(lens), h)
+    # fp32 accumulate then ONE rounding to the output dtype: 1e-5 on the accumulation + half an ulp of the dtype
+    ulp = {torch.float32: 0.0, torch.float64: 0.0, torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dtype]
+    np.testing.assert_allclose(out.double().cpu().numpy(), ref.astype(np.float64), rtol=1e-5 + ulp, atol=1e-5 + ulp)
+
+
+def test_zero_length_segments_and_initial():
+    """Empty segments take the reference's `initial`: 0 / 1 / the GLOBAL min (max) resp. max (min)."""
+    lens = [0, 3, 0, 0, 2, 5, 0]
+    data, lt = _mk(lens, (6,), torch.float32, seed=3)
+    for name in ('sum', 'mean', 'prod', 'max', 'min', 'logsumexp'):
+        ref = getattr(orc, f'segment_{name}')(data.numpy(), lt.numpy())
+        out = getattr(ta, f'segment_{name}')(data.to(DEV), lt.to(DEV)).cpu().numpy()
+        np.testing.assert_allclose(out, ref, rtol=1e-5, atol=1e-6, err_msg=name)
+    # zero-length sequences inside a CattedSequence survive pad / unpad (the reference's P cannot hold them)
+    c = ta.C(data.to(DEV), lt.to(DEV))
+    oc = orc.C(data.numpy(), lt.numpy())
+    assert_same_seq(c.left(-2.0), orc.to_left(oc, -2.0), 'left with empties')
+    assert_same_seq(c.right(-2.0), orc.to_right(oc, -2.0), 'right with empties')
+    assert torch.equal(c.left().cat().data, c.data)
+    assert torch.equal(c.roll(2).roll(-2).data, c.data)
+
+
+def test_nan_semantics_match_reference():
+    data, lt = _mk([2, 3, 1], (4,), torch.float32, seed=1)
+    data[3, 2] = float('nan')
+    for name in ('max', 'min', 'sum'):
+        ref = getattr(orc, f'segment_{name}')(data.numpy(), lt.numpy())
+        out = getattr(ta, f'segment_{name}')(data.to(DEV), lt.to(DEV)).cpu().numpy()
+        assert np.array_equal(np.isnan(out), np.isnan(ref)), name     # incl. the reference's initial=NaN poisoning
+        np.testing.assert_allclose(out[~np.isnan(ref)], ref[~np.isnan(ref)], rtol=1e-6)
+
+
+def test_non_contiguous_and_views():
+    data, lt = _mk([4, 2, 5, 1], (8,), torch.float32)
+    wide = torch.randn(12, 16, device=DEV)
+    wide[:, ::2] = data.to(DEV)
+    c = ta.C(wide[:, ::2], lt.to(DEV))                                  # strided payload
+    oc = orc.C(data.numpy(), lt.numpy())
+    assert_same_seq(c.pack(), orc.to_pack(oc, host_sort(lt)), 'pack of a strided view')
+    l = c.left()
+    assert torch.equal(l.head(2).cat().data, c.head(2).data)            # L.head is a view; cat() of a view
+    assert torch.equal(l.trunc((1, 0)).cat().data, c.trunc((1, 0)).data) if min(lt) > 1 else True
+    p = c.pack()
+    assert torch.equal(p.head(1).cat().data, c.head(1).data)            # P.head is a view sharing indices
+
+
+def test_single_sequences_and_scalars():
+    for lens, hidden in (([1], ()), ([1], (1,)), ([9], (2,)), ([1, 1, 1], (3,))):
+        data, lt = _mk(lens, hidden, torch.float32)
+        c = ta.C(data.to(DEV), lt.to(DEV))
+        oc = orc.C(data.numpy(), lt.numpy())
+        srt = host_sort(lens)
+        assert_same_seq(c.pack(), orc.to_pack(oc, srt))
+        assert_same_seq(c.pack().left(), orc.to_left(oc))
+        assert_same_seq(c.right().pack().cat(), oc)
+        assert np.array_equal(to_np(c.last()), orc.last(oc))
+        assert np.allclose(to_np(ta.reduce_sum(c.pack())), orc.segment_sum(data.numpy().reshape(len(data), -1), lt.numpy()).reshape(
+            (len(lens),) + tuple(hidden)), atol=1e-6)
+
+
+def test_index_primitives():
+    sizes = torch.tensor([3, 0, 2, 5, 1], device=DEV)
+    assert ta.get_offsets(sizes).tolist() == [0, 3, 3, 5, 10]
+    major, minor = ta.major_sizes_to_ptr(sizes)
+    assert major.tolist() == [0, 1, 2, 0, 1, 0, 1, 2, 3, 4, 0] and minor.tolist() == [0, 0, 0, 2, 2, 3, 3, 3, 3, 3, 4]
+    perm = torch.randperm(1000, device=DEV)
+    inv = ta.invert_permutation(perm)
+    assert torch.equal(inv[perm], torch.arange(1000, device=DEV))
+    big = torch.randint(0, 50, (300007,), device=DEV)
+    assert torch.equal(ta.get_offsets(big), torch.cumsum(big, 0) - big)
+
+
+def test_scatter_large_fan_in_is_deterministic():
+    """Buckets longer than a wave (rank-by-counting path) and run-to-run bitwise reproducibility."""
+    g = torch.Generator().manual_seed(0)
+    S, M, H = 7, 5000, 16
+    index = torch.randint(0, S, (M,), generator=g).to(DEV)
+    src = torch.randn(M, H, generator=g).to(DEV)
+    ten = torch.randn(S, H, generator=g).to(DEV)
+    a = ta.scatter_sum(ten, index, src, include_self=True)
+    b = ta.scatter_sum(ten, index, src, include_self=True)
+    assert torch.equal(a, b)
+    ref = orc.scatter_sum(ten.cpu().numpy(), index.cpu().numpy(), src.cpu().numpy(), include_self=True)
+    np.testing.assert_allclose(a.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+    m = ta.scatter_max(ten, index, src)
+    assert np.array_equal(m.cpu().numpy(), orc.scatter_max(ten.cpu().numpy(), index.cpu().numpy(), src.cpu().numpy()))
