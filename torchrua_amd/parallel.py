@@ -23,9 +23,11 @@ def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def all_gather_rows(local: Tensor, n_total: Optional[int] = None, group=None) -> Tensor:
+def all_gather_rows(local: Tensor, n_total: Optional[int] = None, group=None, async_op: bool = False):
     """Concatenate every rank's [n_r, *H] rows in rank order.  Equal shards use one
-    all_gather_into_tensor (a single ncclAllGather); shards that differ by a row are padded to the widest."""
+    all_gather_into_tensor (a single ncclAllGather); shards that differ by a row are padded to the widest.
+    async_op=True (equal shards only) returns (out, work): the collective runs on RCCL's own stream and
+    overlaps whatever is enqueued next; call work.wait() before reading `out`."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     local = local.contiguous()
@@ -36,8 +38,10 @@ def all_gather_rows(local: Tensor, n_total: Optional[int] = None, group=None) ->
         raise ValueError(f'rank {rank} holds {local.size(0)} rows, its shard of {n_total} is {sizes[rank]}')
     out = local.new_empty((n_total,) + tuple(local.shape[1:]))
     if n_total % world == 0:
-        dist.all_gather_into_tensor(out, local, group=group)
-        return out
+        work = dist.all_gather_into_tensor(out, local, group=group, async_op=async_op)
+        return (out, work) if async_op else out
+    if async_op:
+        raise ValueError('async_op needs equal shards')
     # shards differ by one row: pad to the largest, gather once, drop the padding rows
     widest = max(hi - lo for lo, hi in sizes)
     padded = local.new_zeros((widest,) + tuple(local.shape[1:]))
