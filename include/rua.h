@@ -146,6 +146,15 @@ int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* d
                        int64_t H, int32_t dtype, int32_t op, int32_t include_self,
                        uint64_t empty_bits, void* extreme, void* stream);
 
+/* Fused pack + reduce (an EXTENSION: the reference has no one-call equivalent; it is exactly
+ * core/cast.py:41-49 followed by the reduction of reduce.py:34-61 over the packed rows).  One pass over
+ * the payload of `src` (CAT/LEFT/RIGHT): every row is stored to its row of the PackedSequence `pack`
+ * (boff[t] + unsorted[b]) AND folded into out[b, :].  Bit-identical to rua_move_rows(pack <- src) followed
+ * by rua_segment_reduce(pack), at 2/3 of the HBM traffic.  Needs H*sizeof(dtype) % 16 == 0 and 16-byte
+ * aligned pointers (returns RUA_EALIGN otherwise: run the two-call form). */
+int rua_pack_reduce(const rua_layout* src, const rua_layout* pack, const void* data, void* pack_data, void* out,
+                    int64_t H, int32_t dtype, int32_t op, uint64_t empty_bits, void* extreme, void* stream);
+
 /* Patch rows of empty sequences with *extreme after rua_segment_reduce (MAX/MIN), and poison
  * every row with NaN when *extreme is NaN (the reference's initial=NaN behaviour). */
 int rua_fill_empty(const rua_layout* lay, void* out, int64_t H, int32_t dtype, int32_t op,

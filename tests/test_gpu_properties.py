@@ -207,3 +207,18 @@ def test_compose_and_split(groups, data):
         for a, e in zip(c.split(), s):
             assert torch.equal(a, e)
         assert c.tolist() == [e.tolist() for e in s]
+
+
+@settings(**SET)
+@given(lens=lens_st, dim=st.sampled_from([4, 8, 16, 36, 3]), name=st.sampled_from(sorted(REDUCERS)),
+       src=st.sampled_from([ta.C, ta.L, ta.R]), dtype=st.sampled_from([torch.float32, torch.bfloat16]))
+def test_fused_pack_reduce_equals_two_calls(lens, dim, name, src, dtype):
+    """pack_reduce (one pass) == pack() then reduce_*() bit for bit, PackedSequence metadata included."""
+    xs = [torch.randn((n, dim), device=DEV).to(dtype) for n in lens]
+    z = src.new(xs)
+    p1 = z.pack()
+    o1 = getattr(ta, f'reduce_{name}')(p1)
+    p2, o2 = ta.pack_reduce(z, name)
+    assert torch.equal(p1.data, p2.data) and torch.equal(p1.batch_sizes, p2.batch_sizes)
+    assert torch.equal(p1.sorted_indices, p2.sorted_indices) and torch.equal(p1.unsorted_indices, p2.unsorted_indices)
+    assert torch.equal(o1, o2) or (torch.isnan(o1) == torch.isnan(o2)).all()

@@ -81,12 +81,16 @@ __device__ __forceinline__ double unordered_f64(uint64_t u) {
 
 // ---------------------------------------------------------------- the kernel
 // EPL: elements per lane per load (16 B / sizeof(T) on the vector path, 1 on the scalar path)
-template <typename T, int EPL, int OP, bool NT>
+// COPY: every row that is read is ALSO stored to its row of a PackedSequence (layout CD, storage
+// `copy`) — pack and reduce in one pass over the payload (rua_pack_reduce): N*H*e read + N*H*e written
+// instead of 3*N*H*e for pack-then-reduce.  Sequences are then walked in CD's rank order.
+template <typename T, int EPL, int OP, bool NT, bool COPY>
 __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, const int64_t* __restrict__ perm,
                                                               const T* __restrict__ data, T* __restrict__ out,
                                                               int64_t H, int lp_log2, int64_t n_chunks,
                                                               int include_self, T empty_val,
-                                                              unsigned long long* __restrict__ extreme) {
+                                                              unsigned long long* __restrict__ extreme,
+                                                              rua_layout CD, T* __restrict__ copy) {
   using A = typename elem<T>::acc;
   struct alignas(sizeof(T) * EPL) Pack { T v[EPL]; };
   typedef unsigned int RawV __attribute__((ext_vector_type(sizeof(T) * EPL >= 4 ? sizeof(T) * EPL / 4 : 1)));
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
   const int64_t chunk = wid - q * n_chunks;
   // PACK is walked in rank order (longest first = LPT schedule; neighbouring workgroups read
   // neighbouring rows of every time step), everything else in batch order.
-  const int64_t b = (L.kind == RUA_PACK && L.sorted) ? L.sorted[q] : q;
+  const int64_t b = COPY ? (CD.sorted ? CD.sorted[q] : q) : ((L.kind == RUA_PACK && L.sorted) ? L.sorted[q] : q);
 
   const int rpw = RUA_WAVE >> lp_log2;
   const int rsub = lane >> lp_log2;
@@ -136,12 +140,15 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
   // handed to the lanes by ds_bpermute; the next block's entries are in flight while this
   // block's payload streams.
   int64_t tv = (tbl && lane < len) ? tbl[tb + lane] : 0;
+  int64_t cv = (COPY && lane < len) ? CD.boff[lane] : 0;      // destination rows: boff[t] + rank
   for (int64_t tblk = 0; tblk < len; tblk += RUA_WAVE) {
     const int64_t nxt = tblk + RUA_WAVE + lane;
     const int64_t tv_next = (tbl && nxt < len) ? tbl[tb + nxt] : 0;
+    const int64_t cv_next = (COPY && nxt < len) ? CD.boff[nxt] : 0;
     const int nblk = (len - tblk) < RUA_WAVE ? (int)(len - tblk) : RUA_WAVE;
     for (int k = 0; k < nblk; k += rpw * UNROLL_T) {
       int64_t row[UNROLL_T];
+      int64_t crow[UNROLL_T];
       Pack p[UNROLL_T];
 #pragma unroll
       for (int u = 0; u < UNROLL_T; ++u) {
@@ -149,6 +156,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
         const int64_t tabv = __shfl(tv, tl & (RUA_WAVE - 1), RUA_WAVE);
         row[u] = -1;
         if (colok && tl < nblk) row[u] = base + (tbl ? tabv : tblk + tl);
+        if (COPY) crow[u] = __shfl(cv, tl & (RUA_WAVE - 1), RUA_WAVE) + q;
       }
 #pragma unroll
       for (int u = 0; u < UNROLL_T; ++u)
@@ -161,6 +169,20 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
             p[u] = *reinterpret_cast<const Pack*>(src);
           }
         }
+      if (COPY) {
+#pragma unroll
+        for (int u = 0; u < UNROLL_T; ++u)
+          if (row[u] >= 0) {
+            T* dstp = copy + crow[u] * H + col;
+            if (NT && sizeof(Pack) >= 4) {
+              RawV raw;
+              __builtin_memcpy(&raw, &p[u], sizeof(Pack));
+              __builtin_nontemporal_store(raw, reinterpret_cast<RawV*>(dstp));
+            } else {
+              *reinterpret_cast<Pack*>(dstp) = p[u];
+            }
+          }
+      }
       if (OP == RUA_LOGSUMEXP) {
         // chunk-wise online logsumexp: the chunk's max first, ONE rescale of the running sum per
         // chunk, then one fma + one v_exp per element (exp(x - m) = exp2(x*log2e - m*log2e))
@@ -199,6 +221,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
       }
     }
     tv = tv_next;
+    cv = cv_next;
   }
 
   if (OP == RUA_MAX || OP == RUA_MIN) {
@@ -311,16 +334,16 @@ __global__ __launch_bounds__(RUA_BLOCK) void fill_empty_kernel(rua_layout L, T* 
 
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + RUA_BLOCK - 1) / RUA_BLOCK); }
 
-template <typename T, int EPL, bool NT>
+template <typename T, int EPL, bool NT, bool COPY>
 static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout& L, const int64_t* perm,
                          const void* data, void* out, int64_t H, int lp_log2, int64_t n_chunks, int include_self,
-                         uint64_t empty_bits, void* extreme) {
+                         uint64_t empty_bits, void* extreme, const rua_layout& CD, void* copy) {
   T ev;
   __builtin_memcpy(&ev, &empty_bits, sizeof(T));
   const dim3 g(grid), b(RUA_WAVE);
 #define RUA_LAUNCH(OP)                                                                                          \
-  hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT>), g, b, 0, s, L, perm, (const T*)data, (T*)out, H, lp_log2, \
-                     n_chunks, include_self, ev, (unsigned long long*)extreme)
+  hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY>), g, b, 0, s, L, perm, (const T*)data, (T*)out, H, \
+                     lp_log2, n_chunks, include_self, ev, (unsigned long long*)extreme, CD, (T*)copy)
   switch (op) {
     case RUA_SUM: RUA_LAUNCH(RUA_SUM); break;
     case RUA_MEAN: RUA_LAUNCH(RUA_MEAN); break;
@@ -336,9 +359,10 @@ static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout&
 
 template <typename T>
 static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,
-                           void* out, int64_t H, int include_self, uint64_t empty_bits, void* extreme) {
+                           void* out, int64_t H, int include_self, uint64_t empty_bits, void* extreme,
+                           const rua_layout* CD = nullptr, void* copy = nullptr) {
   constexpr int FULL = 16 / sizeof(T);
-  const bool vec_ok = (H % FULL == 0) && (((uintptr_t)data | (uintptr_t)out) % 16 == 0);
+  const bool vec_ok = (H % FULL == 0) && (((uintptr_t)data | (uintptr_t)out | (uintptr_t)copy) % 16 == 0);
   const int epl = vec_ok ? FULL : 1;
   const int64_t lpr = (H + epl - 1) / epl;  // lanes per row
   int lp_log2 = 0;
@@ -347,14 +371,23 @@ static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int
   const int64_t blocks = L.B * n_chunks;  // one wave per workgroup
   if (blocks > 0x7fffffffLL) return RUA_ERANGE;
   const bool nt = (double)L.n_rows * (double)H * sizeof(T) >= (double)(512ll << 20);
+  const unsigned g = (unsigned)blocks;
+  static const rua_layout none = {};
+  if (copy) {   // fused pack + reduce: vector path only (the caller falls back to two launches otherwise)
+    if (!vec_ok) return RUA_EALIGN;
+    return nt ? launch_reduce<T, FULL, true, true>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
+                                                   empty_bits, extreme, *CD, copy)
+              : launch_reduce<T, FULL, false, true>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
+                                                    empty_bits, extreme, *CD, copy);
+  }
   if (vec_ok && nt)
-    return launch_reduce<T, FULL, true>(op, (unsigned)blocks, s, L, perm, data, out, H, lp_log2, n_chunks,
-                                        include_self, empty_bits, extreme);
+    return launch_reduce<T, FULL, true, false>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
+                                               empty_bits, extreme, none, nullptr);
   if (vec_ok)
-    return launch_reduce<T, FULL, false>(op, (unsigned)blocks, s, L, perm, data, out, H, lp_log2, n_chunks,
-                                         include_self, empty_bits, extreme);
-  return launch_reduce<T, 1, false>(op, (unsigned)blocks, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
-                                    empty_bits, extreme);
+    return launch_reduce<T, FULL, false, false>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
+                                                empty_bits, extreme, none, nullptr);
+  return launch_reduce<T, 1, false, false>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
+                                           empty_bits, extreme, none, nullptr);
 }
 
 }  // namespace rua
@@ -384,6 +417,27 @@ int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* d
     case RUA_BF16: return dispatch_reduce<__hip_bfloat16>(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme);
     case RUA_F16: return dispatch_reduce<__half>(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme);
     case RUA_F64: return dispatch_reduce<double>(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme);
+  }
+  return RUA_EINVAL;
+}
+
+int rua_pack_reduce(const rua_layout* src, const rua_layout* pack, const void* data, void* pack_data, void* out,
+                    int64_t H, int32_t dtype, int32_t op, uint64_t empty_bits, void* extreme, void* stream) {
+  if (!src || !pack || H < 0 || src->B < 0) return RUA_EINVAL;
+  if (src->kind != RUA_CAT && src->kind != RUA_LEFT && src->kind != RUA_RIGHT) return RUA_EINVAL;
+  if (src->kind == RUA_CAT && src->lens && !src->off) return RUA_EINVAL;
+  if (pack->kind != RUA_PACK || pack->B != src->B || (pack->T > 0 && !pack->boff)) return RUA_EINVAL;
+  if (src->B == 0 || H == 0) return 0;
+  if (!out || !pack_data || !data) return RUA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (extreme && (op == RUA_MAX || op == RUA_MIN || op == RUA_LOGSUMEXP))
+    hipLaunchKernelGGL(extreme_init_kernel, dim3(1), dim3(128), 0, s, (unsigned long long*)extreme,
+                       op == RUA_MIN ? 1 : 0);
+  switch (dtype) {
+    case RUA_F32: return dispatch_reduce<float>(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, pack, pack_data);
+    case RUA_BF16: return dispatch_reduce<__hip_bfloat16>(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, pack, pack_data);
+    case RUA_F16: return dispatch_reduce<__half>(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, pack, pack_data);
+    case RUA_F64: return dispatch_reduce<double>(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, pack, pack_data);
   }
   return RUA_EINVAL;
 }

@@ -23,6 +23,7 @@ __all__ = [
     'segment_head', 'segment_last',
     'scatter_max', 'scatter_min', 'scatter_sum', 'scatter_mean', 'scatter_prod', 'scatter_logsumexp',
     'reduce_max', 'reduce_min', 'reduce_sum', 'reduce_mean', 'reduce_prod', 'reduce_logsumexp',
+    'pack_reduce',
 ]
 
 
@@ -209,3 +210,53 @@ def scatter_prod(tensor: T, index: T, source: T, include_self: bool = False, dim
 def scatter_logsumexp(tensor: T, index: T, source: T, include_self: bool = False, dim: int = 0):
     """reduce.py:26-31."""
     return _scatter(tensor, index, source, K.LOGSUMEXP, include_self, dim)
+
+
+# ------------------------------------------------------------------ fused pack + reduce (extension)
+_OPS = {'sum': K.SUM, 'mean': K.MEAN, 'max': K.MAX, 'min': K.MIN, 'prod': K.PROD, 'logsumexp': K.LOGSUMEXP}
+
+
+def pack_reduce(sequence: Z, op: str = 'sum'):
+    """(sequence.pack(), reduce_<op>(that PackedSequence)) in ONE pass over the payload.
+
+    An extension with no one-call twin in the reference: it equals core/cast.py:41-49 followed by the
+    per-sequence reduction (reduce.py:34-61 spelled over the packed rows), bit for bit, but reads the
+    payload once instead of twice (2*N*H*e + B*H*e bytes instead of 3*N*H*e + B*H*e).  Falls back to the
+    two-kernel form when autograd is recording, for a PackedSequence input, or for rows that are not a
+    multiple of 16 bytes."""
+    from torchrua_amd.core import _hidden, _pack_meta
+    code = _OPS[op]
+    data = sequence.data
+    hidden = _hidden(sequence)
+    H = 1
+    for d in hidden:
+        H *= d
+    fusable = (not isinstance(sequence, P) and data.dtype in K.DTYPES and data.is_contiguous()
+               and (H * data.element_size()) % 16 == 0 and data.data_ptr() % 16 == 0
+               and not (data.requires_grad and torch.is_grad_enabled()))
+    if not fusable:
+        p = sequence.pack()
+        return p, _reduce_seq(p, code)
+    dev = K.require_device(data)
+    lib = K.load()
+    lens, sorted_indices, unsorted, batch_sizes, bsz_dev, boff = _pack_meta(sequence.token_sizes, dev)
+    n = int(data.size(0)) if isinstance(sequence, C) else M.total_len(sequence.token_sizes)
+    B = lens.numel()
+    pdata = torch.empty((n,) + hidden, dtype=data.dtype, device=dev)
+    p = P(data=pdata, batch_sizes=batch_sizes, sorted_indices=sorted_indices, unsorted_indices=unsorted)
+    M.adopt_pack(p, lens, boff, bsz_dev)
+    dst = M.lay_pack(p, lens=lens, boff=boff, T=batch_sizes.numel(), n_rows=n)
+    src = describe(sequence)
+    out = torch.empty((B,) + hidden, dtype=data.dtype, device=dev)
+    extreme = torch.empty(65, dtype=torch.long, device=dev) if code in (K.MAX, K.MIN, K.LOGSUMEXP) else None
+    if O._kernel_hook:
+        O._kernel_hook('pack_reduce', True)
+    K.check(lib.rua_pack_reduce(src.ref(), dst.ref(), K.ptr(data), K.ptr(pdata), K.ptr(out), H, K.DTYPES[data.dtype],
+                                code, O._bits(O._EMPTY[code], data.dtype), K.ptr(extreme), K.stream_ptr(dev)),
+            'rua_pack_reduce')
+    if O._kernel_hook:
+        O._kernel_hook('pack_reduce', False)
+    if extreme is not None:
+        K.check(lib.rua_fill_empty(src.ref(), K.ptr(out), H, K.DTYPES[data.dtype], code, K.ptr(extreme),
+                                   K.stream_ptr(dev)), 'rua_fill_empty')
+    return p, out
