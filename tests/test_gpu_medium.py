@@ -1,0 +1,84 @@
+"""Medium-size randomized parity vs the CPU oracle: big enough to cross every internal boundary
+(multi-block scans: B > 2048; many mover tiles; sequences longer than the reducer's 64-row table block;
+rows wider than one wave instruction), small enough for the oracle to finish in seconds."""
+import numpy as np
+import pytest
+import torch
+
+import torchrua_amd as ta
+from gpu_util import DEV, assert_same_seq, dev_seq, host_sort
+from helpers import orc, to_np
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # B, lo, hi, hidden, dtype
+    (5000, 1, 40, (24,), torch.float32),
+    (300, 1, 700, (136,), torch.bfloat16),     # 272-byte rows, T > 512
+    (2049, 1, 9, (1,), torch.float32),          # scan tile boundary, 4-byte rows
+    (70, 50, 400, (640,), torch.float32),       # 2 560-byte rows: 3 column chunks per row
+]
+
+
+def _inputs(shape):
+    B, lo, hi, hidden, dtype = shape
+    g = torch.Generator().manual_seed(B)
+    lens = torch.randint(lo, hi + 1, (B,), generator=g)
+    data = torch.randn((int(lens.sum()),) + hidden, generator=g).to(dtype)
+    return lens, data
+
+
+@pytest.mark.parametrize('shape', SHAPES, ids=[f'B{s[0]}-T{s[2]}-H{s[3][0]}' for s in SHAPES])
+def test_casts_selects_vs_oracle(shape):
+    lens, data = _inputs(shape)
+    bf = data.dtype == torch.bfloat16
+    srt = host_sort(lens)
+    oc = orc.C(to_np(data), lens.numpy())
+    fill = np.array([0xC040], dtype=np.uint16) if bf else -3.0          # bf16 bits of -3.0
+    osq = {'C': oc, 'L': orc.to_left(oc, fill), 'P': orc.to_pack(oc, srt), 'R': orc.to_right(oc, fill)}
+    dsq = {k: dev_seq(v, bf16=bf) for k, v in osq.items()}
+    for k, z in dsq.items():
+        for dst in 'CLPR':
+            out = {'C': z.cat, 'P': z.pack, 'L': lambda: z.left(-3.0), 'R': lambda: z.right(-3.0)}[dst]()
+            assert_same_seq(out, orc.to_kind(osq[k], dst, fill, srt), f'{k}->{dst}')
+        bp, tp = z.ptr()
+        obp, otp = orc.ptr(osq[k])
+        assert np.array_equal(to_np(bp), obp) and np.array_equal(to_np(tp), otp), f'ptr {k}'
+        assert np.array_equal(to_np(z.idx().data), orc.idx(osq[k]).data), f'idx {k}'
+        assert np.array_equal(to_np(ta.get_mask(z)), orc.get_mask(osq[k])), f'mask {k}'
+        for s in (1, -7, 123):
+            assert_same_seq(z.roll(s), orc.roll(osq[k], s, srt), f'roll {k} {s}')
+        assert_same_seq(z.rev(), orc.rev(osq[k], srt), f'rev {k}')
+        assert np.array_equal(to_np(z.last()), orc.last(osq[k])), f'last {k}'
+        m = int(lens.min())
+        a, b = (m - 1) // 2, (m - 1) - (m - 1) // 2
+        t = z.trunc((a, b))
+        assert_same_seq(t._replace(data=t.data.contiguous()), orc.trunc(osq[k], (a, b)), f'trunc {k}')
+
+
+@pytest.mark.parametrize('shape', SHAPES[:2] + SHAPES[3:], ids=['B5000', 'B300-bf16', 'B70-wide'])
+def test_reductions_vs_oracle(shape):
+    lens, data = _inputs(shape)
+    data = (data * 0.25).to(data.dtype)
+    f32 = data.float().numpy()
+    c = ta.C(data.to(DEV), lens.to(DEV))
+    p = c.pack()
+    ulp = 2.0 ** -8 if data.dtype == torch.bfloat16 else 0.0
+    for name in ('sum', 'mean', 'max', 'min', 'logsumexp'):
+        ref = getattr(orc, f'segment_{name}')(f32, lens.numpy())
+        for what, got in (('segment', getattr(ta, f'segment_{name}')(c.data, c.token_sizes)),
+                          ('reduce(P)', getattr(ta, f'reduce_{name}')(p)),
+                          ('reduce(L)', getattr(ta, f'reduce_{name}')(c.left())),
+                          ('fused', ta.pack_reduce(c, name)[1])):
+            # 1e-5 on the fp32 accumulation (scaled by the magnitude that was summed) + output rounding
+            scale = np.abs(f32).max() * (lens.max().item() if name == 'sum' else 1)
+            np.testing.assert_allclose(got.float().cpu().numpy(), ref, rtol=1e-5 + ulp, atol=1e-5 * scale + 1e-6,
+                                       err_msg=f'{what} {name}')
+    # scatter: rows shuffled, destinations = sequence ids
+    index = torch.repeat_interleave(torch.arange(lens.numel()), lens)
+    perm = torch.randperm(index.numel(), generator=torch.Generator().manual_seed(1))
+    if data.dtype == torch.float32:
+        ten = torch.randn((lens.numel(),) + tuple(data.shape[1:]))
+        for name in ('sum', 'max', 'mean'):
+            ref = getattr(orc, f'scatter_{name}')(ten.numpy(), index[perm].numpy(), f32[perm.numpy()], include_self=True)
+            got = getattr(ta, f'scatter_{name}')(ten.to(DEV), index[perm].to(DEV), data[perm].to(DEV), include_self=True)
+            np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=1e-4, err_msg=f'scatter {name}')
