@@ -70,6 +70,12 @@ def main():
     timeit('reduce_max(p)', lambda: ta.reduce_max(p), N * H * e + B * H * e)
     timeit('reduce_logsumexp(p)', lambda: ta.reduce_logsumexp(p), N * H * e + B * H * e)
     timeit('p.cat()', lambda: p.cat(), 2 * N * H * e)
+    timeit('c.roll(0) (streaming copy through the mover)', lambda: c.roll(0), 2 * N * H * e)
+    timeit('p.roll(0)', lambda: p.roll(0), 2 * N * H * e)
+    outbuf = torch.empty_like(data)
+    timeit('torch copy_', lambda: outbuf.copy_(data), 2 * N * H * e)
+    del outbuf
+    timeit('pack_reduce(c) fused', lambda: ta.pack_reduce(c, 'sum'), 2 * N * H * e + B * H * e)
     timeit('segment_sum(c)', lambda: ta.segment_sum(c.data, c.token_sizes), N * H * e + B * H * e)
     T = int(lens.max())
     timeit('c.left()  (pad)', lambda: c.left(), N * H * e + B * T * H * e)

@@ -150,3 +150,36 @@ def test_scatter_large_fan_in_is_deterministic():
     np.testing.assert_allclose(a.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
     m = ta.scatter_max(ten, index, src)
     assert np.array_equal(m.cpu().numpy(), orc.scatter_max(ten.cpu().numpy(), index.cpu().numpy(), src.cpu().numpy()))
+
+
+def test_backward_ties_and_long_sequences():
+    """max/min share the gradient equally among ties (torch.segment_reduce backward; SURVEY.md §4: [1,5,5] ->
+    [0,.5,.5]); sequences longer than the kernel's 64-row table block; every layout."""
+    x = torch.tensor([[1.0], [5.0], [5.0], [2.0], [2.0], [2.0]], device=DEV, requires_grad=True)
+    lens = torch.tensor([3, 3], device=DEV)
+    ta.segment_max(x, lens).sum().backward()
+    third = float(torch.tensor(1.0) / 3)
+    assert x.grad.view(-1).tolist() == [0.0, 0.5, 0.5, third, third, third]
+    x.grad = None
+    ta.segment_min(x, lens).sum().backward()
+    assert x.grad.view(-1).tolist() == [1.0, 0.0, 0.0, third, third, third]
+
+    g = torch.Generator().manual_seed(0)
+    lens = torch.tensor([200, 1, 131, 64, 65])
+    data = torch.randn(int(lens.sum()), 24, generator=g)
+    for name, fn in (('sum', lambda t: t.sum(0)), ('mean', lambda t: t.mean(0)), ('max', lambda t: t.max(0).values),
+                     ('logsumexp', lambda t: t.logsumexp(0)), ('prod', lambda t: (t * 0.9).prod(0))):
+        for kind in 'CLPR':
+            xs = data.clone().to(DEV).requires_grad_(True)
+            scaled = xs * 0.9 if name == 'prod' else xs
+            c = ta.C(scaled, lens.to(DEV))
+            z = {'C': c, 'L': c.left, 'P': c.pack, 'R': c.right}[kind]
+            z = z if kind == 'C' else z()
+            out = getattr(ta, f'reduce_{name}')(z)
+            cot = torch.randn(out.shape, generator=g).to(DEV)
+            out.backward(cot)
+            ref_in = data.clone().to(DEV).requires_grad_(True)
+            ref = torch.stack([fn(s) for s in torch.split(ref_in, lens.tolist())])
+            ref.backward(cot)
+            torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(xs.grad, ref_in.grad, rtol=1e-4, atol=1e-5, msg=f'{name} {kind}')

@@ -54,6 +54,8 @@ SYMBOLS = {
                                    c_int32, c_uint64, c_void_p, c_void_p]),
     'rua_pack_reduce': (c_int, [POINTER(RuaLayout), POINTER(RuaLayout), c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                 c_int32, c_uint64, c_void_p, c_void_p]),
+    'rua_segment_reduce_backward': (c_int, [POINTER(RuaLayout), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_int64, c_int32, c_int32, c_void_p]),
     'rua_fill_empty': (c_int, [POINTER(RuaLayout), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     'rua_index_buckets': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rua_abi_version': (c_int, []),
@@ -93,6 +95,11 @@ def check(code: int, what: str) -> None:
 
 
 def stream_ptr(device) -> int:
+    """torch's current stream on `device`.  HIP launches go to the calling thread's current device, so the
+    tensors' device must be it (one process per GPU sets it once with torch.cuda.set_device)."""
+    if device.index is not None and torch.cuda.current_device() != device.index:
+        raise RuaError(f'tensors live on cuda:{device.index} but the current device is '
+                       f'cuda:{torch.cuda.current_device()}: call torch.cuda.set_device / use torch.cuda.device(...)')
     return torch.cuda.current_stream(device).cuda_stream
 
 

@@ -1,9 +1,9 @@
 """Kernel launches with autograd: the row mover and the segmented reduce.
 
 Backward of a move is the adjoint move (layouts swapped, token map inverted, zero fill for rows
-nothing maps to) — the same kernel.  Backward of a reduce broadcasts the cotangent back through a
-move (token map ZERO) and, for max/min/prod/logsumexp, finishes with elementwise torch ops on the
-result (SURVEY.md §8f rank 3 allows composing v0 backward this way; forward is kernel-only).
+nothing maps to) — the same kernel.  Backward of a segmented reduce is one fused kernel
+(rua_segment_reduce_backward); scatter_* backward is still composed from
+gathers + elementwise torch ops on the result.
 """
 import struct
 from typing import Callable, Optional, Sequence, Tuple
@@ -145,40 +145,31 @@ def launch_reduce(lay: M.Lay, data: Tensor, op: int, out: Optional[Tensor] = Non
     return out
 
 
-def broadcast_rows(rows: Tensor, lay: M.Lay, out_shape: Sequence[int]) -> Tensor:
-    """out[row(b,t)] = rows[b] for every token of `lay` (padding rows 0): the adjoint of a sum."""
-    B = lay.B
-    src = M.lay_padded(L.LEFT, None, B, 1, 1, len_add=1)
-    return launch_move(MovePlan(lay, src, out_shape, L.T_ZERO, 0, fill=0, name='broadcast'), rows.contiguous())
-
-
 class _Reduce(torch.autograd.Function):
     @staticmethod
     def forward(ctx, data: Tensor, lay: M.Lay, op: int, hidden, lens: Optional[Tensor]):
         out = launch_reduce(lay, data, op, hidden=hidden)
         ctx.lay, ctx.op, ctx.lens = lay, op, lens
-        ctx.save_for_backward(data, out)
+        ctx.save_for_backward(data.contiguous(), out)
         return out
 
     @staticmethod
     def backward(ctx, grad: Tensor):
+        """One fused kernel (rua_segment_reduce_backward): reads the payload once (twice for max/min: the tie
+        count), writes the gradient once — no [N, H] temporaries."""
         data, out = ctx.saved_tensors
         lay, op = ctx.lay, ctx.op
-        shape = tuple(data.shape)
+        dev = L.require_device(data)
+        lib = L.load()
         grad = grad.contiguous()
-        if op == L.SUM:
-            g = broadcast_rows(grad, lay, shape)
-        elif op == L.MEAN:
-            lens = ctx.lens.clamp_min(1).to(grad.dtype).view((-1,) + (1,) * (grad.dim() - 1))
-            g = broadcast_rows(grad / lens, lay, shape)
-        elif op in (L.MAX, L.MIN):
-            hit = (data == broadcast_rows(out, lay, shape)).to(grad.dtype)
-            ties = launch_reduce(lay, hit, L.SUM, hidden=tuple(out.shape[1:])).clamp_min(1)
-            g = broadcast_rows(grad / ties, lay, shape) * hit      # ties share the gradient equally
-        elif op == L.PROD:
-            g = broadcast_rows(grad * out, lay, shape) / data
-        else:  # LOGSUMEXP
-            g = broadcast_rows(grad, lay, shape) * (data - broadcast_rows(out, lay, shape)).exp()
+        padded = lay.kind in (L.LEFT, L.RIGHT)
+        g = (torch.zeros if padded else torch.empty)(data.shape, dtype=data.dtype, device=dev)
+        H = 1
+        for d in out.shape[1:]:
+            H *= d
+        L.check(lib.rua_segment_reduce_backward(lay.ref(), None, L.ptr(data), L.ptr(out), L.ptr(grad), L.ptr(g), H,
+                                                L.DTYPES[data.dtype], op, L.stream_ptr(dev)),
+                'rua_segment_reduce_backward')
         return g, None, None, None, None
 
 

@@ -298,6 +298,117 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
   }
 }
 
+// ---------------------------------------------------------------- backward of the reductions
+// One wave per (sequence, column chunk), same row addressing as the forward.  grad_in[row] is
+//   SUM  g            MEAN g / len           PROD g * out / x        LOGSUMEXP g * exp(x - out)
+//   MAX/MIN  (x == out) ? g / ties : 0   — ties counted in a first walk over the sequence (the rows are
+//   re-read from L2 by the second walk), so tied maxima share the gradient equally like torch's
+//   segment_reduce backward.  Rows of padded layouts that hold no token are not written (the caller
+//   zero-fills padded grads).
+constexpr int UNROLL_B = 4;
+
+template <typename T, int EPL, int OP>
+__global__ __launch_bounds__(RUA_WAVE) void seg_backward_kernel(rua_layout L, const int64_t* __restrict__ perm,
+                                                                const T* __restrict__ data,
+                                                                const T* __restrict__ out,
+                                                                const T* __restrict__ gout, T* __restrict__ gin,
+                                                                int64_t H, int lp_log2, int64_t n_chunks) {
+  using A = typename elem<T>::acc;
+  struct alignas(sizeof(T) * EPL) Pack { T v[EPL]; };
+  const int lane = threadIdx.x;
+  const int64_t wid = blockIdx.x;
+  const int64_t q = wid / n_chunks;
+  if (q >= L.B) return;
+  const int64_t chunk = wid - q * n_chunks;
+  const int64_t b = (L.kind == RUA_PACK && L.sorted) ? L.sorted[q] : q;
+  const int rpw = RUA_WAVE >> lp_log2;
+  const int rsub = lane >> lp_log2;
+  const int64_t col = (chunk * RUA_WAVE + (lane & ((1 << lp_log2) - 1))) * EPL;
+  const bool colok = col < H;
+  const int64_t len = seq_len(L, b);
+  if (len <= 0) return;
+  int64_t base = 0, tb = 0;
+  const int64_t* __restrict__ tbl = nullptr;
+  switch (L.kind) {
+    case RUA_CAT:
+      if (perm) { tbl = perm; tb = cat_off(L, b); } else base = cat_off(L, b);
+      break;
+    case RUA_PACK:  tbl = L.boff; base = L.sorted ? q : (L.unsorted ? L.unsorted[b] : b); break;
+    case RUA_LEFT:  base = b * L.T_phys; break;
+    case RUA_RIGHT: base = b * L.T_phys + (L.T_log - len); break;
+  }
+
+  A o[EPL], g[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) { o[e] = (A)0; g[e] = (A)0; }
+  if (colok) {
+    const Pack po = *reinterpret_cast<const Pack*>(out + b * H + col);
+    const Pack pg = *reinterpret_cast<const Pack*>(gout + b * H + col);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { o[e] = elem<T>::up(po.v[e]); g[e] = elem<T>::up(pg.v[e]); }
+  }
+  if (OP == RUA_MEAN) {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) g[e] = g[e] / (A)len;
+  }
+
+  for (int pass = (OP == RUA_MAX || OP == RUA_MIN) ? 0 : 1; pass < 2; ++pass) {
+    A cnt[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) cnt[e] = (A)0;
+    int64_t tv = (tbl && lane < len) ? tbl[tb + lane] : 0;
+    for (int64_t tblk = 0; tblk < len; tblk += RUA_WAVE) {
+      const int64_t nxt = tblk + RUA_WAVE + lane;
+      const int64_t tv_next = (tbl && nxt < len) ? tbl[tb + nxt] : 0;
+      const int nblk = (len - tblk) < RUA_WAVE ? (int)(len - tblk) : RUA_WAVE;
+      for (int k = 0; k < nblk; k += rpw * UNROLL_B) {
+        int64_t row[UNROLL_B];
+        Pack p[UNROLL_B];
+#pragma unroll
+        for (int u = 0; u < UNROLL_B; ++u) {
+          const int tl = k + u * rpw + rsub;
+          const int64_t tabv = __shfl(tv, tl & (RUA_WAVE - 1), RUA_WAVE);
+          row[u] = -1;
+          if (colok && tl < nblk) row[u] = base + (tbl ? tabv : tblk + tl);
+        }
+        const bool need_x = (OP != RUA_SUM && OP != RUA_MEAN);
+#pragma unroll
+        for (int u = 0; u < UNROLL_B; ++u)
+          if (need_x && row[u] >= 0) p[u] = *reinterpret_cast<const Pack*>(data + row[u] * H + col);
+#pragma unroll
+        for (int u = 0; u < UNROLL_B; ++u) {
+          if (row[u] < 0) continue;
+          Pack r;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            const A x = need_x ? elem<T>::up(p[u].v[e]) : (A)0;
+            A gi;
+            if (OP == RUA_SUM || OP == RUA_MEAN) gi = g[e];
+            else if (OP == RUA_PROD) gi = g[e] * o[e] / x;
+            else if (OP == RUA_LOGSUMEXP) gi = g[e] * fexp(x - o[e]);
+            else {
+              const bool hit = (x == o[e]) || (x != x && o[e] != o[e]);
+              if (pass == 0) cnt[e] += hit ? (A)1 : (A)0;
+              gi = hit ? g[e] : (A)0;
+            }
+            r.v[e] = elem<T>::down(gi);
+          }
+          if (pass == 1) *reinterpret_cast<Pack*>(gin + row[u] * H + col) = r;
+        }
+      }
+      tv = tv_next;
+    }
+    if (pass == 0) {   // MAX/MIN: share the gradient among the ties of every column
+      for (int d = 1 << lp_log2; d < RUA_WAVE; d <<= 1) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) cnt[e] += __shfl_xor(cnt[e], d, RUA_WAVE);
+      }
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) g[e] = g[e] / (cnt[e] > (A)0 ? cnt[e] : (A)1);
+    } 
+  }
+}
+
 // extreme scratch: [0..63] hashed ordered-bit slots, [64] NaN flag
 __global__ void extreme_init_kernel(unsigned long long* ext, int want_max_of_data) {
   const int i = threadIdx.x;
@@ -390,11 +501,71 @@ static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int
                                            empty_bits, extreme, none, nullptr);
 }
 
+
+template <typename T, int EPL>
+static int launch_backward(int op, unsigned grid, hipStream_t s, const rua_layout& L, const int64_t* perm,
+                           const void* data, const void* out, const void* gout, void* gin, int64_t H, int lp_log2,
+                           int64_t n_chunks) {
+  const dim3 g(grid), b(RUA_WAVE);
+#define RUA_LAUNCH(OP)                                                                                            \
+  hipLaunchKernelGGL((seg_backward_kernel<T, EPL, OP>), g, b, 0, s, L, perm, (const T*)data, (const T*)out,       \
+                     (const T*)gout, (T*)gin, H, lp_log2, n_chunks)
+  switch (op) {
+    case RUA_SUM: RUA_LAUNCH(RUA_SUM); break;
+    case RUA_MEAN: RUA_LAUNCH(RUA_MEAN); break;
+    case RUA_MAX: RUA_LAUNCH(RUA_MAX); break;
+    case RUA_MIN: RUA_LAUNCH(RUA_MIN); break;
+    case RUA_PROD: RUA_LAUNCH(RUA_PROD); break;
+    case RUA_LOGSUMEXP: RUA_LAUNCH(RUA_LOGSUMEXP); break;
+    default: return RUA_EINVAL;
+  }
+#undef RUA_LAUNCH
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,
+                             const void* out, const void* gout, void* gin, int64_t H) {
+  constexpr int FULL = 16 / sizeof(T);
+  const uintptr_t ptrs = (uintptr_t)data | (uintptr_t)out | (uintptr_t)gout | (uintptr_t)gin;
+  const bool vec_ok = (H % FULL == 0) && (ptrs % 16 == 0);
+  const int epl = vec_ok ? FULL : 1;
+  const int64_t lpr = (H + epl - 1) / epl;
+  int lp_log2 = 0;
+  while ((1 << lp_log2) < lpr && lp_log2 < 6) ++lp_log2;
+  const int64_t n_chunks = (lpr + RUA_WAVE - 1) / RUA_WAVE;
+  const int64_t blocks = L.B * n_chunks;
+  if (blocks > 0x7fffffffLL) return RUA_ERANGE;
+  if (vec_ok) return launch_backward<T, FULL>(op, (unsigned)blocks, s, L, perm, data, out, gout, gin, H, lp_log2, n_chunks);
+  return launch_backward<T, 1>(op, (unsigned)blocks, s, L, perm, data, out, gout, gin, H, lp_log2, n_chunks);
+}
+
 }  // namespace rua
 
 using namespace rua;
 
 extern "C" {
+
+int rua_segment_reduce_backward(const rua_layout* lay, const int64_t* perm, const void* data, const void* out,
+                                const void* grad_out, void* grad_in, int64_t H, int32_t dtype, int32_t op,
+                                void* stream) {
+  if (!lay || H < 0 || lay->B < 0) return RUA_EINVAL;
+  if (lay->kind != RUA_CAT && lay->kind != RUA_PACK && lay->kind != RUA_LEFT && lay->kind != RUA_RIGHT)
+    return RUA_EINVAL;
+  if (lay->kind == RUA_CAT && lay->lens && !lay->off) return RUA_EINVAL;
+  if (lay->kind == RUA_PACK && lay->T > 0 && !lay->boff) return RUA_EINVAL;
+  if (perm && lay->kind != RUA_CAT) return RUA_EINVAL;
+  if (lay->B == 0 || H == 0 || lay->n_rows == 0) return 0;
+  if (!data || !out || !grad_out || !grad_in) return RUA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case RUA_F32: return dispatch_backward<float>(op, s, *lay, perm, data, out, grad_out, grad_in, H);
+    case RUA_BF16: return dispatch_backward<__hip_bfloat16>(op, s, *lay, perm, data, out, grad_out, grad_in, H);
+    case RUA_F16: return dispatch_backward<__half>(op, s, *lay, perm, data, out, grad_out, grad_in, H);
+    case RUA_F64: return dispatch_backward<double>(op, s, *lay, perm, data, out, grad_out, grad_in, H);
+  }
+  return RUA_EINVAL;
+}
 
 int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* data, void* out, int64_t H,
                        int32_t dtype, int32_t op, int32_t include_self, uint64_t empty_bits, void* extreme,
