@@ -32,13 +32,14 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-le
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=65536, help='sequences per GPU')
     ap.add_argument('--hidden', type=int, default=512)
     ap.add_argument('--lo', type=int, default=8)
     ap.add_argument('--hi', type=int, default=512)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--trace-host', action='store_true', help='print per-step host enqueue time to stderr')
     ap.add_argument('--cpu-sample', type=int, default=4096, help='sequences in the CPU-baseline sample')
     return ap.parse_args()
 
@@ -170,10 +171,15 @@ def main():
     sync()
     timer.enabled = True
     t0 = time.perf_counter()
+    host_ms = []
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         p, out = step()
+        host_ms.append((time.perf_counter() - h0) * 1e3)
     sync()
     dt = time.perf_counter() - t0
+    if args.trace_host and rank == 0:
+        print('host enqueue ms per step:', ' '.join(f'{x:.2f}' for x in host_ms), file=sys.stderr)
     timer.enabled = False
 
     extra = {}
@@ -236,11 +242,11 @@ def main():
                                    f'(north-star shape; N={N} rows on rank 0)',
                        'sharding': f'{world} x contiguous batch shards, one all-gather of [B,H]' if world > 1 else 'none',
                        'lens_source': 'host (C.new-style hand-over)'},
-            'roofline': {'bound': 'hbm', 'kernel': 'move_rows_kernel<16,false> (C->P pack)',
+            'roofline': {'bound': 'hbm', 'kernel': 'move_rows_kernel<16,false,NT> (C->P pack)',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                          'algorithmic_bytes': pack_bytes, 'avg_ms': round(move_ms, 4)},
-            'reduce_kernel': {'kernel': 'seg_reduce_kernel<bf16,8,SUM> (over P)', 'avg_ms': round(red_ms, 4),
+            'reduce_kernel': {'kernel': 'seg_reduce_kernel<bf16,8,SUM,NT> (over P)', 'avg_ms': round(red_ms, 4),
                               'achieved': round(reduce_bytes / (red_ms * 1e-3) / 1e9, 1), 'unit': 'GB/s',
                               'frac': round(reduce_bytes / (red_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             'pipeline': {'algorithmic_bytes': pack_bytes + reduce_bytes,

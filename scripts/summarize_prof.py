@@ -55,7 +55,7 @@ for k, c in pmc.items():
                              'hbm_bytes_per_launch': rd + wr, 'raw': c}
 with open(os.path.join(P, f'{tag}_pmc.json'), 'w') as f:
     json.dump(out, f, indent=1, sort_keys=True)
-move = [v for k, v in out['kernels'].items() if 'move_rows_kernel<16, false>' in k]
+move = [v for k, v in out['kernels'].items() if 'move_rows_kernel<16, false' in k]
 if move:
     with open(os.path.join(P, f'{tag}_traffic.json'), 'w') as f:
         json.dump({'to_pack_hbm_bytes_per_launch': move[0]['hbm_bytes_per_launch'],

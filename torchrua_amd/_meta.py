@@ -241,8 +241,8 @@ class _StagingRing:
     cannot recycle blocks whose copy events are still pending, so every call pays a fresh
     hipHostMalloc (tens of ms on the MI355X box).  The ring reuses SLOTS buffers; before a slot is
     reused the host waits for that slot's last copy, which also bounds how far the host may run
-    ahead of the stream (SLOTS uploads = a few pipeline steps)."""
-    SLOTS = 8
+    ahead of the stream (SLOTS uploads = about 16 pack() calls: deep enough to ride out host hiccups)."""
+    SLOTS = 32
 
     def __init__(self):
         self.bufs = [None] * self.SLOTS
