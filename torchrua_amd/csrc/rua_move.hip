@@ -74,6 +74,9 @@ __global__ __launch_bounds__(RUA_BLOCK) void move_rows_kernel(rua_layout D, rua_
       const int64_t j = tile0 + i;
       int64_t b, t, other = -1;
       if (row_to_token(D, j, b, t)) {
+        // caller-supplied (batch_ptr, token_ptr) pairs are range-checked: a bad pair yields the fill /
+        // is skipped instead of faulting the GPU (the reference raises an IndexError there)
+        if (D.kind == RUA_LIST && (b < 0 || b >= S.B)) { b = 0; t = -1; }
         const int64_t slen = seq_len(S, b);
         const int64_t dlen = D.kind == RUA_LIST ? slen : seq_len(D, b);
         const int64_t ts = apply_tmap(tmap, targ, t, slen, dlen);
