@@ -138,13 +138,18 @@ enum rua_op {
  * form of scatter_* (reduce.py:6-31).
  * Empty sequence -> `empty_bits` (the reference's `initial`: 0, 1, or the global min/max).
  * If `extreme` != NULL (MAX/MIN only) the kernel also folds every element it reads into
- * *extreme (f32/f64 by dtype, pre-initialised by the caller) so that the reference's
+ * *extreme (65 uint64 of scratch, initialised by the library) so that the reference's
  * `initial = tensor.min()` (reduce.py:35,40) costs no extra pass; rua_fill_empty then
  * patches the empty segments.
- * include_self: `out` already holds values that take part in the reduction (scatter_*). */
+ * include_self: 0 overwrite | 1 `out` already holds values that take part (scatter_* include_self) |
+ *               2 rows of empty sequences are left untouched (torch.index_reduce semantics).
+ * split_rows > 0 (with `ws` of rua_reduce_ws_bytes(lay->n_rows, H, dtype, split_rows) bytes) cuts sequences
+ * longer than split_rows into parts handled by separate waves (published through a device-side work list,
+ * fp32 partials folded in part order: deterministic); 0 = one wave streams each sequence. */
+int64_t rua_reduce_ws_bytes(int64_t n_rows, int64_t H, int32_t dtype, int64_t split_rows);
 int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* data, void* out,
                        int64_t H, int32_t dtype, int32_t op, int32_t include_self,
-                       uint64_t empty_bits, void* extreme, void* stream);
+                       uint64_t empty_bits, void* extreme, int64_t split_rows, void* ws, void* stream);
 
 /* Fused pack + reduce (an EXTENSION: the reference has no one-call equivalent; it is exactly
  * core/cast.py:41-49 followed by the reduction of reduce.py:34-61 over the packed rows).  One pass over
@@ -153,7 +158,8 @@ int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* d
  * by rua_segment_reduce(pack), at 2/3 of the HBM traffic.  Needs H*sizeof(dtype) % 16 == 0 and 16-byte
  * aligned pointers (returns RUA_EALIGN otherwise: run the two-call form). */
 int rua_pack_reduce(const rua_layout* src, const rua_layout* pack, const void* data, void* pack_data, void* out,
-                    int64_t H, int32_t dtype, int32_t op, uint64_t empty_bits, void* extreme, void* stream);
+                    int64_t H, int32_t dtype, int32_t op, uint64_t empty_bits, void* extreme, int64_t split_rows,
+                    void* ws, void* stream);
 
 /* Backward of rua_segment_reduce in one kernel (semantics of torch's
  * segment_reduce backward, which the reference inherits through autograd: reduce.py:34-61):

@@ -183,3 +183,46 @@ def test_backward_ties_and_long_sequences():
             ref.backward(cot)
             torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-5)
             torch.testing.assert_close(xs.grad, ref_in.grad, rtol=1e-4, atol=1e-5, msg=f'{name} {kind}')
+
+
+@pytest.mark.parametrize('hidden,dtype', [(8, torch.float32), (512, torch.bfloat16), (70, torch.float32), (130, torch.float64)])
+def test_long_sequences_are_split(hidden, dtype):
+    """Sequences far beyond the reducer's 4 096-row part size (split + tail + combine kernels), next to
+    short ones and exact multiples; host-known and device-only lengths; every op; C / P / L inputs; fused."""
+    from torchrua_amd import _meta as M
+    lens = [20000, 3, 9000, 1, 4097, 4096, 12289, 8192]
+    g = torch.Generator().manual_seed(4)
+    data = (torch.randn(sum(lens), hidden, generator=g) * 0.1).to(dtype)
+    lt = torch.tensor(lens)
+    f = data.double().numpy() if dtype == torch.float64 else data.float().numpy()
+    ulp = {torch.float32: 0.0, torch.float64: 0.0, torch.bfloat16: 2.0 ** -8}[dtype]
+    known = ta.with_host_sizes(data.to(DEV), lt)          # host mirror: the split is chosen from max(len)
+    blind = ta.C(data.to(DEV), lt.to(DEV))                # device-only lengths: armed by the heuristic
+    assert M.reduce_split_rows(M.lay_cat(known.token_sizes, len(lens), sum(lens))) == M.SPLIT_ROWS
+    assert M.reduce_split_rows(M.lay_cat(blind.token_sizes, len(lens), sum(lens))) == M.SPLIT_ROWS
+    p = known.pack()
+    for name in ('sum', 'mean', 'max', 'min', 'logsumexp', 'prod'):
+        src = f if name != 'prod' else np.where(np.abs(f) > 0, 1.0 + f * 1e-3, 1.0).astype(f.dtype)
+        dd = data if name != 'prod' else torch.from_numpy(src).to(dtype)
+        up = dd.double().numpy() if dtype == torch.float64 else dd.float().numpy()   # what the kernel really sees
+        ref = getattr(orc, f'segment_{name}')(up, lt.numpy())
+        kc = ta.with_host_sizes(dd.to(DEV), lt)
+        outs = {'segment(known)': getattr(ta, f'segment_{name}')(kc.data, kc.token_sizes),
+                'segment(blind)': getattr(ta, f'segment_{name}')(dd.to(DEV), blind.token_sizes),
+                'reduce(P)': getattr(ta, f'reduce_{name}')(kc.pack())}
+        if hidden % (16 // data.element_size()) == 0:
+            pf, of = ta.pack_reduce(kc, name)
+            outs['fused'] = of
+            assert torch.equal(pf.data, kc.pack().data)
+        if hidden <= 70:
+            outs['reduce(L)'] = getattr(ta, f'reduce_{name}')(kc.left())
+        for what, got in outs.items():
+            scale = 20000 * 0.5 if name == 'sum' else 1.0
+            # a 20 000-factor fp32 product carries ~n*2^-24 of rounding on BOTH sides (order differs): 1e-3
+            rtol = 1e-3 if name == 'prod' else 2e-5
+            np.testing.assert_allclose(got.double().cpu().numpy(), ref.astype(np.float64), rtol=rtol + ulp,
+                                       atol=1e-5 * scale + ulp, err_msg=f'{what} {name}')
+    # gradients through a split sequence
+    x = data.to(DEV).float().requires_grad_(True)
+    ta.segment_sum(x, known.token_sizes).sum().backward()
+    assert torch.equal(x.grad, torch.ones_like(x))

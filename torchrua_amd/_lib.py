@@ -50,10 +50,11 @@ SYMBOLS = {
     'rua_mask': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int32, c_uint64, c_uint64, c_void_p]),
     'rua_move_rows': (c_int, [POINTER(RuaLayout), POINTER(RuaLayout), c_int32, c_int64, c_void_p, c_void_p,
                               c_int64, c_void_p, c_int64, c_int32, c_void_p]),
+    'rua_reduce_ws_bytes': (c_int64, [c_int64, c_int64, c_int32, c_int64]),
     'rua_segment_reduce': (c_int, [POINTER(RuaLayout), c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
-                                   c_int32, c_uint64, c_void_p, c_void_p]),
+                                   c_int32, c_uint64, c_void_p, c_int64, c_void_p, c_void_p]),
     'rua_pack_reduce': (c_int, [POINTER(RuaLayout), POINTER(RuaLayout), c_void_p, c_void_p, c_void_p, c_int64, c_int32,
-                                c_int32, c_uint64, c_void_p, c_void_p]),
+                                c_int32, c_uint64, c_void_p, c_int64, c_void_p, c_void_p]),
     'rua_segment_reduce_backward': (c_int, [POINTER(RuaLayout), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_int64, c_int32, c_int32, c_void_p]),
     'rua_fill_empty': (c_int, [POINTER(RuaLayout), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),

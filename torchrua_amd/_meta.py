@@ -184,16 +184,29 @@ def batch_sizes_from_host_lens(h: Tensor, T: int) -> Tensor:
 
 
 # ------------------------------------------------------------------ rua_layout descriptors
+def known_max_len(token_sizes: Optional[Tensor]) -> Optional[int]:
+    """max(token_sizes) if the host can tell WITHOUT a device sync (memoised, or a host mirror exists)."""
+    if token_sizes is None:
+        return None
+    hit = _memo_get(token_sizes, 'max')
+    if hit is not None:
+        return hit
+    if not token_sizes.is_cuda or _memo_get(token_sizes, 'host') is not None:
+        return max_len(token_sizes)
+    return None
+
+
 class Lay:
     """A rua_layout plus the tensors its pointers borrow (kept alive with it)."""
-    __slots__ = ('c', 'keep', 'kind', 'n_rows', 'B')
+    __slots__ = ('c', 'keep', 'kind', 'n_rows', 'B', 'max_len')
 
-    def __init__(self, keep: List[Optional[Tensor]], **fields):
+    def __init__(self, keep: List[Optional[Tensor]], max_len: Optional[int] = None, **fields):
         self.c = L.RuaLayout(**fields)
         self.keep = keep
         self.kind = fields['kind']
         self.n_rows = fields['n_rows']
         self.B = fields['B']
+        self.max_len = max_len      # longest sequence, when the host knows it for free
 
     def ref(self):
         return ctypes.byref(self.c)
@@ -202,10 +215,11 @@ class Lay:
 def lay_cat(lens: Optional[Tensor], B: int, n_rows: int, len_add: int = 0) -> Lay:
     """CAT rows; `lens=None` means every sequence has exactly `len_add` rows."""
     if lens is None:
-        return Lay([], kind=L.CAT, n_rows=n_rows, B=B, len_add=len_add)
+        return Lay([], max_len=len_add, kind=L.CAT, n_rows=n_rows, B=B, len_add=len_add)
     lens = _as_lens(lens)
     off = dev_off(lens)
-    return Lay([lens, off], kind=L.CAT, n_rows=n_rows, B=B, lens=L.ptr(lens), len_add=len_add, off=L.ptr(off))
+    mx = known_max_len(lens)
+    return Lay([lens, off], max_len=None if mx is None else mx + len_add, kind=L.CAT, n_rows=n_rows, B=B, lens=L.ptr(lens), len_add=len_add, off=L.ptr(off))
 
 
 def lay_padded(kind: int, lens: Optional[Tensor], B: int, T_phys: int, T_log: int, len_add: int = 0,
@@ -220,7 +234,8 @@ def lay_padded(kind: int, lens: Optional[Tensor], B: int, T_phys: int, T_log: in
             off = dev_off(lens)
             keep.append(off)
             f['off'] = L.ptr(off)
-    return Lay(keep, **f)
+    mx = len_add if lens is None else known_max_len(lens)
+    return Lay(keep, max_len=mx if lens is None or mx is None else mx + len_add, **f)
 
 
 def lay_pack(p, lens: Optional[Tensor] = None, len_add: int = 0, boff: Optional[Tensor] = None,
@@ -229,7 +244,7 @@ def lay_pack(p, lens: Optional[Tensor] = None, len_add: int = 0, boff: Optional[
     boff = pack_boff(p) if boff is None else boff
     T = p.batch_sizes.numel() if T is None else T
     n_rows = int(p.data.size(0)) if n_rows is None else n_rows
-    return Lay([lens, boff, p.sorted_indices, p.unsorted_indices], kind=L.PACK, n_rows=n_rows, B=pack_B(p),
+    return Lay([lens, boff, p.sorted_indices, p.unsorted_indices], max_len=T, kind=L.PACK, n_rows=n_rows, B=pack_B(p),
                lens=L.ptr(lens), len_add=len_add, boff=L.ptr(boff), T=T, sorted=L.ptr(p.sorted_indices),
                unsorted=L.ptr(p.unsorted_indices))
 
@@ -303,3 +318,19 @@ def row_bytes(data: Tensor, lead: int) -> int:
     for d in data.shape[lead:]:
         n *= d
     return n * data.element_size()
+
+
+# ------------------------------------------------------------------ long-sequence splitting of the reducer
+SPLIT_ROWS = 4096
+
+
+def reduce_split_rows(lay: Lay) -> int:
+    """Rows per part for rua_segment_reduce, or 0.  One wave streams a sequence at ~4 GB/s, so sequences
+    beyond a few thousand rows are cut into parts.  When the host does not know the longest sequence
+    (device-only lengths) the split machinery (one memset + two near-empty launches) is armed only where a
+    tail could matter: long average sequences or few of them."""
+    if lay.n_rows <= SPLIT_ROWS:
+        return 0
+    if lay.max_len is not None:
+        return SPLIT_ROWS if lay.max_len > SPLIT_ROWS else 0
+    return SPLIT_ROWS if (lay.n_rows >= 256 * max(lay.B, 1) or lay.B < 1024) else 0

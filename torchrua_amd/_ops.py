@@ -115,6 +115,15 @@ def _bits(value: float, dtype: torch.dtype) -> int:
     return int.from_bytes(raw, 'little')
 
 
+def split_workspace(lay: M.Lay, H: int, dtype: torch.dtype, dev) -> Tuple[int, Optional[Tensor]]:
+    """(split_rows, workspace) for the reducer's long-sequence splitting (0, None when it is off)."""
+    split = M.reduce_split_rows(lay)
+    if not split:
+        return 0, None
+    nbytes = L.load().rua_reduce_ws_bytes(lay.n_rows, H, L.DTYPES[dtype], split)
+    return split, torch.empty(nbytes, dtype=torch.uint8, device=dev)
+
+
 def launch_reduce(lay: M.Lay, data: Tensor, op: int, out: Optional[Tensor] = None, include_self: int = 0,
                   perm: Optional[Tensor] = None, hidden: Tuple[int, ...] = (), reference_initial: bool = True,
                   name: str = 'reduce') -> Tensor:
@@ -132,11 +141,12 @@ def launch_reduce(lay: M.Lay, data: Tensor, op: int, out: Optional[Tensor] = Non
     extreme = None
     if reference_initial and op in (L.MAX, L.MIN, L.LOGSUMEXP) and include_self == 0:
         extreme = torch.empty(65, dtype=torch.long, device=dev)  # initialised by the library
+    split, ws = split_workspace(lay, H, data.dtype, dev)
     if _kernel_hook:
         _kernel_hook(name, True)
     L.check(lib.rua_segment_reduce(lay.ref(), L.ptr(perm), L.ptr(data), L.ptr(out), H, L.DTYPES[data.dtype], op,
-                                   include_self, _bits(_EMPTY[op], data.dtype), L.ptr(extreme), L.stream_ptr(dev)),
-            'rua_segment_reduce')
+                                   include_self, _bits(_EMPTY[op], data.dtype), L.ptr(extreme), split, L.ptr(ws),
+                                   L.stream_ptr(dev)), 'rua_segment_reduce')
     if _kernel_hook:
         _kernel_hook(name, False)
     if extreme is not None:

@@ -79,73 +79,100 @@ __device__ __forceinline__ double unordered_f64(uint64_t u) {
   return __longlong_as_double((long long)u);
 }
 
-// ---------------------------------------------------------------- the kernel
+// ---------------------------------------------------------------- the forward kernels
 // EPL: elements per lane per load (16 B / sizeof(T) on the vector path, 1 on the scalar path)
 // COPY: every row that is read is ALSO stored to its row of a PackedSequence (layout CD, storage
 // `copy`) — pack and reduce in one pass over the payload (rua_pack_reduce): N*H*e read + N*H*e written
 // instead of 3*N*H*e for pack-then-reduce.  Sequences are then walked in CD's rank order.
+// SPLIT: sequences longer than `split` rows are cut into parts of `split` rows; the wave that owns the
+// sequence publishes the extra parts to a work list (consumed by seg_reduce_tail_kernel, launched next on
+// the stream) and every part stores a raw fp32 partial; seg_reduce_combine_kernel folds the partials in
+// part order (deterministic) and finalises.  Without it one wave streams a whole sequence (~4 GB/s).
+
+// the addressing of one (sequence slot, column chunk) unit
+template <typename T, int EPL>
+struct Unit {
+  int64_t q, b, chunk, col, len, base, tb;
+  const int64_t* tbl;
+  int rpw, rsub, lp_log2;
+  bool colok;
+};
+
+template <typename T, int EPL, bool COPY>
+__device__ __forceinline__ Unit<T, EPL> make_unit(const rua_layout& L, const rua_layout& CD, const int64_t* perm,
+                                                   int64_t q, int64_t chunk, int64_t H, int lp_log2, int lane) {
+  Unit<T, EPL> u;
+  u.q = q;
+  u.chunk = chunk;
+  // PACK is walked in rank order (longest first = LPT schedule; neighbouring workgroups read
+  // neighbouring rows of every time step), everything else in batch order.
+  u.b = COPY ? (CD.sorted ? CD.sorted[q] : q) : ((L.kind == RUA_PACK && L.sorted) ? L.sorted[q] : q);
+  u.lp_log2 = lp_log2;
+  u.rpw = RUA_WAVE >> lp_log2;
+  u.rsub = lane >> lp_log2;
+  u.col = (chunk * RUA_WAVE + (lane & ((1 << lp_log2) - 1))) * EPL;
+  u.colok = u.col < H;
+  u.len = seq_len(L, u.b);
+  u.base = 0;
+  u.tb = 0;
+  u.tbl = nullptr;   // row(t) = base + (tbl ? tbl[tb + t] : t)
+  switch (L.kind) {
+    case RUA_CAT:
+      if (perm) { u.tbl = perm; u.tb = cat_off(L, u.b); } else u.base = cat_off(L, u.b);
+      break;
+    case RUA_PACK:  u.tbl = L.boff; u.base = L.sorted ? q : (L.unsorted ? L.unsorted[u.b] : u.b); break;
+    case RUA_LEFT:  u.base = u.b * L.T_phys; break;
+    case RUA_RIGHT: u.base = u.b * L.T_phys + (L.T_log - u.len); break;
+  }
+  return u;
+}
+
+// running state of one lane
+template <typename A, int EPL>
+struct Fold {
+  A acc[EPL], aux[EPL];   // aux: running sum for LOGSUMEXP (acc holds the running max)
+  bool nan_e[EPL];
+  A ext;                  // extreme of everything read (the reference's global `initial`)
+  bool ext_nan;
+};
+
+template <typename A, int EPL, int OP>
+__device__ __forceinline__ void fold_init(Fold<A, EPL>& f) {
+  f.ext = (OP == RUA_MAX || OP == RUA_LOGSUMEXP) ? acc_inf<A>() : -acc_inf<A>();
+  f.ext_nan = false;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    f.acc[e] = (OP == RUA_PROD) ? (A)1 : (OP == RUA_MAX || OP == RUA_LOGSUMEXP) ? -acc_inf<A>()
+             : (OP == RUA_MIN) ? acc_inf<A>() : (A)0;
+    f.aux[e] = (A)0;
+    f.nan_e[e] = false;
+  }
+}
+
+// fold rows [t_lo, t_hi) of the unit's sequence
 template <typename T, int EPL, int OP, bool NT, bool COPY>
-__global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, const int64_t* __restrict__ perm,
-                                                              const T* __restrict__ data, T* __restrict__ out,
-                                                              int64_t H, int lp_log2, int64_t n_chunks,
-                                                              int include_self, T empty_val,
-                                                              unsigned long long* __restrict__ extreme,
-                                                              rua_layout CD, T* __restrict__ copy) {
+__device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, int64_t t_hi,
+                                          const T* __restrict__ data, int64_t H,
+                                          Fold<typename elem<T>::acc, EPL>& f, const rua_layout& CD,
+                                          T* __restrict__ copy, int lane) {
   using A = typename elem<T>::acc;
   struct alignas(sizeof(T) * EPL) Pack { T v[EPL]; };
   typedef unsigned int RawV __attribute__((ext_vector_type(sizeof(T) * EPL >= 4 ? sizeof(T) * EPL / 4 : 1)));
-
-  // ONE wave per workgroup: sequences differ in length, and a multi-wave workgroup would hold
-  // its CU slots until its longest sequence is done.
-  const int lane = threadIdx.x;
-  const int64_t wid = blockIdx.x;
-  const int64_t q = wid / n_chunks;          // sequence slot
-  if (q >= L.B) return;
-  const int64_t chunk = wid - q * n_chunks;
-  // PACK is walked in rank order (longest first = LPT schedule; neighbouring workgroups read
-  // neighbouring rows of every time step), everything else in batch order.
-  const int64_t b = COPY ? (CD.sorted ? CD.sorted[q] : q) : ((L.kind == RUA_PACK && L.sorted) ? L.sorted[q] : q);
-
-  const int rpw = RUA_WAVE >> lp_log2;
-  const int rsub = lane >> lp_log2;
-  const int64_t col = (chunk * RUA_WAVE + (lane & ((1 << lp_log2) - 1))) * EPL;
-  const bool colok = col < H;
-
-  const int64_t len = seq_len(L, b);
-  // row(t) = base + (tbl ? tbl[tb + t] : t)
-  int64_t base = 0, tb = 0;
-  const int64_t* __restrict__ tbl = nullptr;
-  switch (L.kind) {
-    case RUA_CAT:
-      if (perm) { tbl = perm; tb = cat_off(L, b); } else base = cat_off(L, b);
-      break;
-    case RUA_PACK:  tbl = L.boff; base = L.sorted ? q : (L.unsorted ? L.unsorted[b] : b); break;
-    case RUA_LEFT:  base = b * L.T_phys; break;
-    case RUA_RIGHT: base = b * L.T_phys + (L.T_log - len); break;
-  }
-
-  A acc[EPL], aux[EPL];  // aux: running sum for LOGSUMEXP (acc holds the running max)
-  A ext = (OP == RUA_MAX || OP == RUA_LOGSUMEXP) ? acc_inf<A>() : -acc_inf<A>();
-  bool ext_nan = false;
-  bool nan_e[EPL];
-#pragma unroll
-  for (int e = 0; e < EPL; ++e) {
-    acc[e] = (OP == RUA_PROD) ? (A)1 : (OP == RUA_MAX || OP == RUA_LOGSUMEXP) ? -acc_inf<A>()
-           : (OP == RUA_MIN) ? acc_inf<A>() : (A)0;
-    aux[e] = (A)0;
-    nan_e[e] = false;
-  }
+  const int rpw = U.rpw, rsub = U.rsub;
+  const bool colok = U.colok;
+  const int64_t col = U.col, base = U.base, tb = U.tb;
+  const int64_t* __restrict__ tbl = U.tbl;
 
   // the row table (boff / perm) is fetched 64 entries at a time with one coalesced load and
   // handed to the lanes by ds_bpermute; the next block's entries are in flight while this
   // block's payload streams.
-  int64_t tv = (tbl && lane < len) ? tbl[tb + lane] : 0;
-  int64_t cv = (COPY && lane < len) ? CD.boff[lane] : 0;      // destination rows: boff[t] + rank
-  for (int64_t tblk = 0; tblk < len; tblk += RUA_WAVE) {
+  int64_t tv = (tbl && t_lo + lane < t_hi) ? tbl[tb + t_lo + lane] : 0;
+  int64_t cv = (COPY && t_lo + lane < t_hi) ? CD.boff[t_lo + lane] : 0;      // destination rows: boff[t] + rank
+  for (int64_t tblk = t_lo; tblk < t_hi; tblk += RUA_WAVE) {
     const int64_t nxt = tblk + RUA_WAVE + lane;
-    const int64_t tv_next = (tbl && nxt < len) ? tbl[tb + nxt] : 0;
-    const int64_t cv_next = (COPY && nxt < len) ? CD.boff[nxt] : 0;
-    const int nblk = (len - tblk) < RUA_WAVE ? (int)(len - tblk) : RUA_WAVE;
+    const int64_t tv_next = (tbl && nxt < t_hi) ? tbl[tb + nxt] : 0;
+    const int64_t cv_next = (COPY && nxt < t_hi) ? CD.boff[nxt] : 0;
+    const int nblk = (t_hi - tblk) < RUA_WAVE ? (int)(t_hi - tblk) : RUA_WAVE;
     for (int k = 0; k < nblk; k += rpw * UNROLL_T) {
       int64_t row[UNROLL_T];
       int64_t crow[UNROLL_T];
@@ -156,7 +183,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
         const int64_t tabv = __shfl(tv, tl & (RUA_WAVE - 1), RUA_WAVE);
         row[u] = -1;
         if (colok && tl < nblk) row[u] = base + (tbl ? tabv : tblk + tl);
-        if (COPY) crow[u] = __shfl(cv, tl & (RUA_WAVE - 1), RUA_WAVE) + q;
+        if (COPY) crow[u] = __shfl(cv, tl & (RUA_WAVE - 1), RUA_WAVE) + U.q;
       }
 #pragma unroll
       for (int u = 0; u < UNROLL_T; ++u)
@@ -185,7 +212,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
       }
       if (OP == RUA_LOGSUMEXP) {
         // chunk-wise online logsumexp: the chunk's max first, ONE rescale of the running sum per
-        // chunk, then one fma + one v_exp per element (exp(x - m) = exp2(x*log2e - m*log2e))
+        // chunk, then one exp per element
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
           A x[UNROLL_T];
@@ -194,13 +221,13 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
           for (int u = 0; u < UNROLL_T; ++u) {
             x[u] = row[u] >= 0 ? elem<T>::up(p[u].v[e]) : -acc_inf<A>();
             cm = fmaxx(cm, x[u]);
-            if (row[u] >= 0) { ext = fminx(ext, x[u]); ext_nan |= (x[u] != x[u]); }
+            if (row[u] >= 0) { f.ext = fminx(f.ext, x[u]); f.ext_nan |= (x[u] != x[u]); }
           }
-          if (cm > acc[e]) { aux[e] *= fexp(acc[e] - cm); acc[e] = cm; }
-          const A m = acc[e];
+          if (cm > f.acc[e]) { f.aux[e] *= fexp(f.acc[e] - cm); f.acc[e] = cm; }
+          const A m = f.acc[e];
 #pragma unroll
           for (int u = 0; u < UNROLL_T; ++u)
-            if (row[u] >= 0) aux[e] += fexp(x[u] - m);   // NaN x -> NaN sum; all -inf -> NaN, as the reference
+            if (row[u] >= 0) f.aux[e] += fexp(x[u] - m);   // NaN x -> NaN sum; all -inf -> NaN, as the reference
         }
       } else {
 #pragma unroll
@@ -209,12 +236,12 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
 #pragma unroll
           for (int e = 0; e < EPL; ++e) {
             const A x = elem<T>::up(p[u].v[e]);
-            if (OP == RUA_SUM || OP == RUA_MEAN) acc[e] += x;
-            else if (OP == RUA_PROD) acc[e] *= x;
+            if (OP == RUA_SUM || OP == RUA_MEAN) f.acc[e] += x;
+            else if (OP == RUA_PROD) f.acc[e] *= x;
             else if (OP == RUA_MAX) {   // v_max ignores NaN: NaNs are tracked on the side (a scalar mask OR)
-              acc[e] = fmaxx(acc[e], x); nan_e[e] |= (x != x); ext = fminx(ext, x);
+              f.acc[e] = fmaxx(f.acc[e], x); f.nan_e[e] |= (x != x); f.ext = fminx(f.ext, x);
             } else if (OP == RUA_MIN) {
-              acc[e] = fminx(acc[e], x); nan_e[e] |= (x != x); ext = fmaxx(ext, x);
+              f.acc[e] = fminx(f.acc[e], x); f.nan_e[e] |= (x != x); f.ext = fmaxx(f.ext, x);
             }
           }
         }
@@ -223,53 +250,80 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
     tv = tv_next;
     cv = cv_next;
   }
+}
 
+// fold the NaN flags in and combine the rpw row-groups of the wave (lanes that differ in the bits above
+// lp_log2); afterwards every lane of a column holds the wave's value
+template <typename A, int EPL, int OP>
+__device__ __forceinline__ void fold_wave(Fold<A, EPL>& f, int lp_log2) {
   if (OP == RUA_MAX || OP == RUA_MIN) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
-      if (nan_e[e]) acc[e] = acc[e] - acc[e] + (A)__builtin_nanf("");   // torch: max/min propagate NaN
-      ext_nan |= nan_e[e];
+      if (f.nan_e[e]) f.acc[e] = f.acc[e] - f.acc[e] + (A)__builtin_nanf("");   // torch: max/min propagate NaN
+      f.ext_nan |= f.nan_e[e];
     }
   }
-
-  // combine the rpw row-groups of the wave (lanes that differ in the bits above lp_log2)
   for (int d = 1 << lp_log2; d < RUA_WAVE; d <<= 1) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
-      const A o = __shfl_xor(acc[e], d, RUA_WAVE);
-      if (OP == RUA_SUM || OP == RUA_MEAN) acc[e] += o;
-      else if (OP == RUA_PROD) acc[e] *= o;
-      else if (OP == RUA_MAX) acc[e] = nmax(acc[e], o);
-      else if (OP == RUA_MIN) acc[e] = nmin(acc[e], o);
+      const A o = __shfl_xor(f.acc[e], d, RUA_WAVE);
+      if (OP == RUA_SUM || OP == RUA_MEAN) f.acc[e] += o;
+      else if (OP == RUA_PROD) f.acc[e] *= o;
+      else if (OP == RUA_MAX) f.acc[e] = nmax(f.acc[e], o);
+      else if (OP == RUA_MIN) f.acc[e] = nmin(f.acc[e], o);
       else {
-        const A os = __shfl_xor(aux[e], d, RUA_WAVE);
-        const A m = nmax(acc[e], o);
-        if (m == -acc_inf<A>()) { aux[e] = aux[e] + os; }       // both empty so far
-        else { aux[e] = aux[e] * fexp(acc[e] - m) + os * fexp(o - m); }
-        acc[e] = m;
+        const A os = __shfl_xor(f.aux[e], d, RUA_WAVE);
+        const A m = nmax(f.acc[e], o);
+        if (m == -acc_inf<A>()) { f.aux[e] = f.aux[e] + os; }       // both empty so far
+        else { f.aux[e] = f.aux[e] * fexp(f.acc[e] - m) + os * fexp(o - m); }
+        f.acc[e] = m;
       }
     }
   }
+}
 
-  // include_self: 0 = overwrite (empty sequence -> empty_val), 1 = fold the old out[b] in,
-  //               2 = leave out[b] untouched when the sequence is empty (index_reduce semantics)
-  const bool keep = include_self == 2 && len <= 0;
-  include_self = include_self == 1;
-  if (colok && rsub == 0 && !keep) {
-    T* o = out + b * H + col;
-    const int64_t cnt = len + (include_self ? 1 : 0);
+// merge another part's (already wave-folded) values, in part order
+template <typename A, int EPL, int OP>
+__device__ __forceinline__ void fold_merge(Fold<A, EPL>& f, const A* acc2, const A* aux2) {
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    const A o = acc2[e];
+    if (OP == RUA_SUM || OP == RUA_MEAN) f.acc[e] += o;
+    else if (OP == RUA_PROD) f.acc[e] *= o;
+    else if (OP == RUA_MAX) f.acc[e] = nmax(f.acc[e], o);
+    else if (OP == RUA_MIN) f.acc[e] = nmin(f.acc[e], o);
+    else {
+      const A m = nmax(f.acc[e], o);
+      if (m == -acc_inf<A>()) { f.aux[e] = f.aux[e] + aux2[e]; }
+      else { f.aux[e] = f.aux[e] * fexp(f.acc[e] - m) + aux2[e] * fexp(o - m); }
+      f.acc[e] = m;
+    }
+  }
+}
+
+// include_self: 0 = overwrite (empty sequence -> empty_val), 1 = fold the old out[b] in,
+//               2 = leave out[b] untouched when the sequence is empty (index_reduce semantics)
+template <typename T, int EPL, int OP>
+__device__ __forceinline__ void fold_store(const Unit<T, EPL>& U, Fold<typename elem<T>::acc, EPL>& f,
+                                           T* __restrict__ out, int64_t H, int include_self, T empty_val) {
+  using A = typename elem<T>::acc;
+  const bool keep = include_self == 2 && U.len <= 0;
+  const bool inc = include_self == 1;
+  if (U.colok && U.rsub == 0 && !keep) {
+    T* o = out + U.b * H + U.col;
+    const int64_t cnt = U.len + (inc ? 1 : 0);
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
-      A r = acc[e];
+      A r = f.acc[e];
       if (OP == RUA_LOGSUMEXP) {
-        if (include_self) {  // fold exp(self) in
+        if (inc) {  // fold exp(self) in
           const A x = elem<T>::up(o[e]);
           const A m = nmax(r, x);
-          aux[e] = aux[e] * fexp(r - m) + fexp(x - m);
+          f.aux[e] = f.aux[e] * fexp(r - m) + fexp(x - m);
           r = m;
         }
-        r = flog(aux[e]) + r;
-      } else if (include_self) {
+        r = flog(f.aux[e]) + r;
+      } else if (inc) {
         const A x = elem<T>::up(o[e]);
         if (OP == RUA_SUM || OP == RUA_MEAN) r += x;
         else if (OP == RUA_PROD) r *= x;
@@ -280,22 +334,141 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
       o[e] = (cnt == 0) ? empty_val : elem<T>::down(r);
     }
   }
+}
 
-  if (extreme && (OP == RUA_MAX || OP == RUA_MIN || OP == RUA_LOGSUMEXP)) {
-    // wave-level fold, then ONE no-return integer atomic per wave into a hashed slot
+// one no-return integer atomic per wave into a hashed slot (the reference's global initial, reduce.py:35,40)
+template <typename A, int EPL, int OP>
+__device__ __forceinline__ void fold_extreme(Fold<A, EPL>& f, unsigned long long* __restrict__ extreme,
+                                             int64_t wid, int lane, bool any_rows) {
+  if (!(OP == RUA_MAX || OP == RUA_MIN || OP == RUA_LOGSUMEXP) || !extreme) return;
+  A ext = f.ext;
 #pragma unroll
-    for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {
-      const A o = __shfl_xor(ext, d, RUA_WAVE);
-      if (OP == RUA_MIN) ext = o > ext ? o : ext; else ext = o < ext ? o : ext;
-    }
-    const bool any_nan = __any(ext_nan);
-    if (lane == 0 && len > 0) {
-      const int slot = (int)(wid & (EXTREME_SLOTS - 1));
-      if (OP == RUA_MIN) atomicMax(&extreme[slot], (unsigned long long)ordered_bits(ext));
-      else atomicMin(&extreme[slot], (unsigned long long)ordered_bits(ext));
-      if (any_nan) atomicOr(&extreme[EXTREME_SLOTS], 1ull);
-    }
+  for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {
+    const A o = __shfl_xor(ext, d, RUA_WAVE);
+    if (OP == RUA_MIN) ext = o > ext ? o : ext; else ext = o < ext ? o : ext;
   }
+  const bool any_nan = __any(f.ext_nan);
+  if (lane == 0 && any_rows) {
+    const int slot = (int)(wid & (EXTREME_SLOTS - 1));
+    if (OP == RUA_MIN) atomicMax(&extreme[slot], (unsigned long long)ordered_bits(ext));
+    else atomicMin(&extreme[slot], (unsigned long long)ordered_bits(ext));
+    if (any_nan) atomicOr(&extreme[EXTREME_SLOTS], 1ull);
+  }
+}
+
+// ---- long-sequence splitting: workspace layout (int64 words unless noted)
+//   ctr[0] = published extra items, ctr[1] = long units, ctr[2] = partial slots handed out
+//   long_list[max_u][4] = {q, chunk, nparts, pbase};  items[max_u][4] = {q, chunk, part, slot}
+//   partials[2*max_u][2][64*EPL] of A
+struct SplitWs {
+  unsigned long long* ctr;
+  int64_t* long_list;
+  int64_t* items;
+  void* partials;
+  int64_t max_u;      // bound on extra items and on long units
+  int64_t split;      // rows per part (0 = splitting off)
+};
+
+template <typename A, int EPL>
+__device__ __forceinline__ void store_partial(void* partials, int64_t slot, int lane, const Fold<A, EPL>& f) {
+  A* p = reinterpret_cast<A*>(partials) + (slot * 2 * RUA_WAVE + lane) * EPL;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) { p[e] = f.acc[e]; p[RUA_WAVE * EPL + e] = f.aux[e]; }
+}
+
+template <typename T, int EPL, int OP, bool NT, bool COPY, bool SPLIT>
+__global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, const int64_t* __restrict__ perm,
+                                                              const T* __restrict__ data, T* __restrict__ out,
+                                                              int64_t H, int lp_log2, int64_t n_chunks,
+                                                              int include_self, T empty_val,
+                                                              unsigned long long* __restrict__ extreme,
+                                                              rua_layout CD, T* __restrict__ copy, SplitWs W) {
+  using A = typename elem<T>::acc;
+  // ONE wave per workgroup: sequences differ in length, and a multi-wave workgroup would hold
+  // its CU slots until its longest sequence is done.
+  const int lane = threadIdx.x;
+  const int64_t wid = blockIdx.x;
+  const int64_t q = wid / n_chunks;          // sequence slot
+  if (q >= L.B) return;
+  const Unit<T, EPL> U = make_unit<T, EPL, COPY>(L, CD, perm, q, wid - q * n_chunks, H, lp_log2, lane);
+  Fold<A, EPL> f;
+  fold_init<A, EPL, OP>(f);
+
+  if (SPLIT && U.len > W.split) {
+    // long sequence: this wave takes part 0 and publishes the rest
+    const int64_t nparts = (U.len + W.split - 1) / W.split;
+    int64_t pbase = 0, ibase = 0, li = 0;
+    if (lane == 0) {
+      pbase = (int64_t)atomicAdd(&W.ctr[2], (unsigned long long)nparts);
+      ibase = (int64_t)atomicAdd(&W.ctr[0], (unsigned long long)(nparts - 1));
+      li = (int64_t)atomicAdd(&W.ctr[1], 1ull);
+      int64_t* e = W.long_list + li * 4;
+      e[0] = q; e[1] = U.chunk; e[2] = nparts; e[3] = pbase;
+    }
+    pbase = __shfl(pbase, 0, RUA_WAVE);
+    ibase = __shfl(ibase, 0, RUA_WAVE);
+    for (int64_t p = 1 + lane; p < nparts; p += RUA_WAVE) {
+      int64_t* e = W.items + (ibase + p - 1) * 4;
+      e[0] = q; e[1] = U.chunk; e[2] = p; e[3] = pbase + p;
+    }
+    fold_rows<T, EPL, OP, NT, COPY>(U, 0, W.split, data, H, f, CD, copy, lane);
+    fold_wave<A, EPL, OP>(f, lp_log2);
+    store_partial<A, EPL>(W.partials, pbase, lane, f);
+  } else {
+    fold_rows<T, EPL, OP, NT, COPY>(U, 0, U.len, data, H, f, CD, copy, lane);
+    fold_wave<A, EPL, OP>(f, lp_log2);
+    fold_store<T, EPL, OP>(U, f, out, H, include_self, empty_val);
+  }
+  fold_extreme<A, EPL, OP>(f, extreme, wid, lane, U.len > 0);
+}
+
+// the published parts 1.. of long sequences
+template <typename T, int EPL, int OP, bool NT, bool COPY>
+__global__ __launch_bounds__(RUA_WAVE) void seg_reduce_tail_kernel(rua_layout L, const int64_t* __restrict__ perm,
+                                                                   const T* __restrict__ data, int64_t H,
+                                                                   int lp_log2,
+                                                                   unsigned long long* __restrict__ extreme,
+                                                                   rua_layout CD, T* __restrict__ copy, SplitWs W) {
+  using A = typename elem<T>::acc;
+  const int lane = threadIdx.x;
+  const int64_t i = blockIdx.x;
+  if ((unsigned long long)i >= W.ctr[0]) return;
+  const int64_t* e = W.items + i * 4;
+  const Unit<T, EPL> U = make_unit<T, EPL, COPY>(L, CD, perm, e[0], e[1], H, lp_log2, lane);
+  const int64_t t_lo = e[2] * W.split;
+  const int64_t t_hi = (t_lo + W.split < U.len) ? t_lo + W.split : U.len;
+  Fold<A, EPL> f;
+  fold_init<A, EPL, OP>(f);
+  fold_rows<T, EPL, OP, NT, COPY>(U, t_lo, t_hi, data, H, f, CD, copy, lane);
+  fold_wave<A, EPL, OP>(f, lp_log2);
+  store_partial<A, EPL>(W.partials, e[3], lane, f);
+  fold_extreme<A, EPL, OP>(f, extreme, i, lane, true);
+}
+
+// fold the partials of every long unit in part order and finalise
+template <typename T, int EPL, int OP>
+__global__ __launch_bounds__(RUA_WAVE) void seg_reduce_combine_kernel(rua_layout L, const int64_t* __restrict__ perm,
+                                                                      T* __restrict__ out, int64_t H, int lp_log2,
+                                                                      int include_self, T empty_val, rua_layout CD,
+                                                                      int copy_mode, SplitWs W) {
+  using A = typename elem<T>::acc;
+  const int lane = threadIdx.x;
+  const int64_t j = blockIdx.x;
+  if ((unsigned long long)j >= W.ctr[1]) return;
+  const int64_t* e = W.long_list + j * 4;
+  const Unit<T, EPL> U = copy_mode ? make_unit<T, EPL, true>(L, CD, perm, e[0], e[1], H, lp_log2, lane)
+                                   : make_unit<T, EPL, false>(L, CD, perm, e[0], e[1], H, lp_log2, lane);
+  Fold<A, EPL> f;
+  fold_init<A, EPL, OP>(f);
+  const A* P = reinterpret_cast<const A*>(W.partials);
+  for (int64_t p = 0; p < e[2]; ++p) {
+    const A* pp = P + ((e[3] + p) * 2 * RUA_WAVE + lane) * EPL;
+    A a2[EPL], x2[EPL];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) { a2[k] = pp[k]; x2[k] = pp[RUA_WAVE * EPL + k]; }
+    fold_merge<A, EPL, OP>(f, a2, x2);
+  }
+  fold_store<T, EPL, OP>(U, f, out, H, include_self, empty_val);
 }
 
 // ---------------------------------------------------------------- backward of the reductions
@@ -445,16 +618,53 @@ __global__ __launch_bounds__(RUA_BLOCK) void fill_empty_kernel(rua_layout L, T* 
 
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + RUA_BLOCK - 1) / RUA_BLOCK); }
 
+// workspace carving for the long-sequence split (see SplitWs)
+static inline int64_t split_max_extra(int64_t n_rows, int64_t split) { return split > 0 ? n_rows / split : 0; }
+
+template <typename A>
+static SplitWs carve_ws(void* ws, int64_t max_u, int64_t split) {
+  SplitWs W;
+  char* p = (char*)ws;
+  W.ctr = (unsigned long long*)p;            p += 4 * sizeof(unsigned long long);
+  W.long_list = (int64_t*)p;                 p += (size_t)max_u * 4 * sizeof(int64_t);
+  W.items = (int64_t*)p;                     p += (size_t)max_u * 4 * sizeof(int64_t);
+  W.partials = (void*)p;
+  W.max_u = max_u;
+  W.split = split;
+  return W;
+}
+
 template <typename T, int EPL, bool NT, bool COPY>
 static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout& L, const int64_t* perm,
                          const void* data, void* out, int64_t H, int lp_log2, int64_t n_chunks, int include_self,
-                         uint64_t empty_bits, void* extreme, const rua_layout& CD, void* copy) {
+                         uint64_t empty_bits, void* extreme, const rua_layout& CD, void* copy, int64_t split,
+                         void* ws) {
+  using A = typename elem<T>::acc;
   T ev;
   __builtin_memcpy(&ev, &empty_bits, sizeof(T));
   const dim3 g(grid), b(RUA_WAVE);
-#define RUA_LAUNCH(OP)                                                                                          \
-  hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY>), g, b, 0, s, L, perm, (const T*)data, (T*)out, H, \
-                     lp_log2, n_chunks, include_self, ev, (unsigned long long*)extreme, CD, (T*)copy)
+  const int64_t max_u = split_max_extra(L.n_rows, split) * n_chunks;
+  const bool do_split = split > 0 && ws && max_u > 0;
+  SplitWs W = {};
+  if (do_split) {
+    if (max_u > 0x7fffffffLL) return RUA_ERANGE;
+    W = carve_ws<A>(ws, max_u, split);
+    hipError_t e = hipMemsetAsync(W.ctr, 0, 4 * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return (int)e;
+  }
+  unsigned long long* ext = (unsigned long long*)extreme;
+#define RUA_LAUNCH(OP)                                                                                              \
+  if (do_split) {                                                                                                   \
+    hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY, true>), g, b, 0, s, L, perm, (const T*)data,        \
+                       (T*)out, H, lp_log2, n_chunks, include_self, ev, ext, CD, (T*)copy, W);                      \
+    hipLaunchKernelGGL((seg_reduce_tail_kernel<T, EPL, OP, NT, COPY>), dim3((unsigned)max_u), b, 0, s, L, perm,     \
+                       (const T*)data, H, lp_log2, ext, CD, (T*)copy, W);                                           \
+    hipLaunchKernelGGL((seg_reduce_combine_kernel<T, EPL, OP>), dim3((unsigned)max_u), b, 0, s, L, perm, (T*)out,   \
+                       H, lp_log2, include_self, ev, CD, COPY ? 1 : 0, W);                                          \
+  } else {                                                                                                          \
+    hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY, false>), g, b, 0, s, L, perm, (const T*)data,       \
+                       (T*)out, H, lp_log2, n_chunks, include_self, ev, ext, CD, (T*)copy, W);                      \
+  }
   switch (op) {
     case RUA_SUM: RUA_LAUNCH(RUA_SUM); break;
     case RUA_MEAN: RUA_LAUNCH(RUA_MEAN); break;
@@ -471,7 +681,7 @@ static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout&
 template <typename T>
 static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,
                            void* out, int64_t H, int include_self, uint64_t empty_bits, void* extreme,
-                           const rua_layout* CD = nullptr, void* copy = nullptr) {
+                           int64_t split, void* ws, const rua_layout* CD = nullptr, void* copy = nullptr) {
   constexpr int FULL = 16 / sizeof(T);
   const bool vec_ok = (H % FULL == 0) && (((uintptr_t)data | (uintptr_t)out | (uintptr_t)copy) % 16 == 0);
   const int epl = vec_ok ? FULL : 1;
@@ -487,18 +697,18 @@ static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int
   if (copy) {   // fused pack + reduce: vector path only (the caller falls back to two launches otherwise)
     if (!vec_ok) return RUA_EALIGN;
     return nt ? launch_reduce<T, FULL, true, true>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
-                                                   empty_bits, extreme, *CD, copy)
+                                                   empty_bits, extreme, *CD, copy, split, ws)
               : launch_reduce<T, FULL, false, true>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
-                                                    empty_bits, extreme, *CD, copy);
+                                                    empty_bits, extreme, *CD, copy, split, ws);
   }
   if (vec_ok && nt)
     return launch_reduce<T, FULL, true, false>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
-                                               empty_bits, extreme, none, nullptr);
+                                               empty_bits, extreme, none, nullptr, split, ws);
   if (vec_ok)
     return launch_reduce<T, FULL, false, false>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
-                                                empty_bits, extreme, none, nullptr);
+                                                empty_bits, extreme, none, nullptr, split, ws);
   return launch_reduce<T, 1, false, false>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
-                                           empty_bits, extreme, none, nullptr);
+                                           empty_bits, extreme, none, nullptr, split, ws);
 }
 
 
@@ -567,9 +777,19 @@ int rua_segment_reduce_backward(const rua_layout* lay, const int64_t* perm, cons
   return RUA_EINVAL;
 }
 
+int64_t rua_reduce_ws_bytes(int64_t n_rows, int64_t H, int32_t dtype, int64_t split_rows) {
+  if (split_rows <= 0 || n_rows <= 0 || H <= 0) return 0;
+  const int64_t acc = dtype == RUA_F64 ? 8 : 4;
+  const int64_t max_extra = n_rows / split_rows;
+  const int64_t chunks_scalar = (H + RUA_WAVE - 1) / RUA_WAVE;              // worst case: one element per lane
+  const int64_t max_u = max_extra * chunks_scalar;
+  const int64_t cols = chunks_scalar * RUA_WAVE * (dtype == RUA_F64 ? 2 : 8);  // >= n_chunks * 64 * EPL on any path
+  return 32 + max_u * 64 + 2 * max_extra * 2 * cols * acc + 256;
+}
+
 int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* data, void* out, int64_t H,
                        int32_t dtype, int32_t op, int32_t include_self, uint64_t empty_bits, void* extreme,
-                       void* stream) {
+                       int64_t split_rows, void* ws, void* stream) {
   if (!lay || H < 0 || lay->B < 0) return RUA_EINVAL;
   if (lay->kind != RUA_CAT && lay->kind != RUA_PACK && lay->kind != RUA_LEFT && lay->kind != RUA_RIGHT)
     return RUA_EINVAL;
@@ -584,16 +804,17 @@ int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* d
                        op == RUA_MIN ? 1 : 0);
   }
   switch (dtype) {
-    case RUA_F32: return dispatch_reduce<float>(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme);
-    case RUA_BF16: return dispatch_reduce<__hip_bfloat16>(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme);
-    case RUA_F16: return dispatch_reduce<__half>(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme);
-    case RUA_F64: return dispatch_reduce<double>(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme);
+    case RUA_F32: return dispatch_reduce<float>(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws);
+    case RUA_BF16: return dispatch_reduce<__hip_bfloat16>(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws);
+    case RUA_F16: return dispatch_reduce<__half>(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws);
+    case RUA_F64: return dispatch_reduce<double>(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws);
   }
   return RUA_EINVAL;
 }
 
 int rua_pack_reduce(const rua_layout* src, const rua_layout* pack, const void* data, void* pack_data, void* out,
-                    int64_t H, int32_t dtype, int32_t op, uint64_t empty_bits, void* extreme, void* stream) {
+                    int64_t H, int32_t dtype, int32_t op, uint64_t empty_bits, void* extreme, int64_t split_rows,
+                    void* ws, void* stream) {
   if (!src || !pack || H < 0 || src->B < 0) return RUA_EINVAL;
   if (src->kind != RUA_CAT && src->kind != RUA_LEFT && src->kind != RUA_RIGHT) return RUA_EINVAL;
   if (src->kind == RUA_CAT && src->lens && !src->off) return RUA_EINVAL;
@@ -605,10 +826,10 @@ int rua_pack_reduce(const rua_layout* src, const rua_layout* pack, const void* d
     hipLaunchKernelGGL(extreme_init_kernel, dim3(1), dim3(128), 0, s, (unsigned long long*)extreme,
                        op == RUA_MIN ? 1 : 0);
   switch (dtype) {
-    case RUA_F32: return dispatch_reduce<float>(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, pack, pack_data);
-    case RUA_BF16: return dispatch_reduce<__hip_bfloat16>(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, pack, pack_data);
-    case RUA_F16: return dispatch_reduce<__half>(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, pack, pack_data);
-    case RUA_F64: return dispatch_reduce<double>(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, pack, pack_data);
+    case RUA_F32: return dispatch_reduce<float>(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data);
+    case RUA_BF16: return dispatch_reduce<__hip_bfloat16>(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data);
+    case RUA_F16: return dispatch_reduce<__half>(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data);
+    case RUA_F64: return dispatch_reduce<double>(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data);
   }
   return RUA_EINVAL;
 }

@@ -249,11 +249,12 @@ def pack_reduce(sequence: Z, op: str = 'sum'):
     src = describe(sequence)
     out = torch.empty((B,) + hidden, dtype=data.dtype, device=dev)
     extreme = torch.empty(65, dtype=torch.long, device=dev) if code in (K.MAX, K.MIN, K.LOGSUMEXP) else None
+    split, ws = O.split_workspace(src, H, data.dtype, dev)
     if O._kernel_hook:
         O._kernel_hook('pack_reduce', True)
     K.check(lib.rua_pack_reduce(src.ref(), dst.ref(), K.ptr(data), K.ptr(pdata), K.ptr(out), H, K.DTYPES[data.dtype],
-                                code, O._bits(O._EMPTY[code], data.dtype), K.ptr(extreme), K.stream_ptr(dev)),
-            'rua_pack_reduce')
+                                code, O._bits(O._EMPTY[code], data.dtype), K.ptr(extreme), split, K.ptr(ws),
+                                K.stream_ptr(dev)), 'rua_pack_reduce')
     if O._kernel_hook:
         O._kernel_hook('pack_reduce', False)
     if extreme is not None:
