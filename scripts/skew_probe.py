@@ -1,0 +1,45 @@
+"""Developer probe: the reducer on a skewed batch (one very long sequence among short ones), with and
+without the long-sequence splitting."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torchrua_amd as ta  # noqa: E402
+from torchrua_amd import _meta as M  # noqa: E402
+
+dev = torch.device('cuda:0')
+H = 512
+lens = torch.full((2048,), 64, dtype=torch.long)
+lens[777] = 1_000_000
+data = torch.randn(int(lens.sum()), H, device=dev, dtype=torch.bfloat16)
+c = ta.with_host_sizes(data, lens)
+p = c.pack()
+nbytes = data.numel() * 2
+
+
+def t(name, fn):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+    e0.record()
+    for _ in range(3):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    print(f'{name:34s} {ms:9.3f} ms  {nbytes / ms / 1e9:6.2f} TB/s')
+
+
+for split in (256, 4096, 1 << 60):
+    M.SPLIT_MIN_ROWS = min(split, 1 << 40)
+    M.SPLIT_ROWS = max(split, 4096)
+    tag = f'split {split}' if split < (1 << 40) else 'no split  '
+    t(f'segment_sum(C)  {tag}', lambda: ta.segment_sum(c.data, c.token_sizes))
+    t(f'reduce_sum(P)   {tag}', lambda: ta.reduce_sum(p))
+    t(f'reduce_max(P)   {tag}', lambda: ta.reduce_max(p))
+a = ta.reduce_sum(p)
+M.SPLIT_MIN_ROWS, M.SPLIT_ROWS = 256, 4096
+b = ta.reduce_sum(p)
+print('max |split - nosplit| =', (a.float() - b.float()).abs().max().item())

@@ -190,7 +190,7 @@ def test_long_sequences_are_split(hidden, dtype):
     """Sequences far beyond the reducer's 4 096-row part size (split + tail + combine kernels), next to
     short ones and exact multiples; host-known and device-only lengths; every op; C / P / L inputs; fused."""
     from torchrua_amd import _meta as M
-    lens = [20000, 3, 9000, 1, 4097, 4096, 12289, 8192]
+    lens = [20000, 3, 9000, 1, 4097, 4096, 12289, 8192, 257, 256, 511]
     g = torch.Generator().manual_seed(4)
     data = (torch.randn(sum(lens), hidden, generator=g) * 0.1).to(dtype)
     lt = torch.tensor(lens)
@@ -198,8 +198,8 @@ def test_long_sequences_are_split(hidden, dtype):
     ulp = {torch.float32: 0.0, torch.float64: 0.0, torch.bfloat16: 2.0 ** -8}[dtype]
     known = ta.with_host_sizes(data.to(DEV), lt)          # host mirror: the split is chosen from max(len)
     blind = ta.C(data.to(DEV), lt.to(DEV))                # device-only lengths: armed by the heuristic
-    assert M.reduce_split_rows(M.lay_cat(known.token_sizes, len(lens), sum(lens))) == M.SPLIT_ROWS
-    assert M.reduce_split_rows(M.lay_cat(blind.token_sizes, len(lens), sum(lens))) == M.SPLIT_ROWS
+    assert M.reduce_split_rows(M.lay_cat(known.token_sizes, len(lens), sum(lens))) == M.SPLIT_MIN_ROWS
+    assert M.reduce_split_rows(M.lay_cat(blind.token_sizes, len(lens), sum(lens))) == M.SPLIT_MIN_ROWS
     p = known.pack()
     for name in ('sum', 'mean', 'max', 'min', 'logsumexp', 'prod'):
         src = f if name != 'prod' else np.where(np.abs(f) > 0, 1.0 + f * 1e-3, 1.0).astype(f.dtype)

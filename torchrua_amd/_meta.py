@@ -321,16 +321,20 @@ def row_bytes(data: Tensor, lead: int) -> int:
 
 
 # ------------------------------------------------------------------ long-sequence splitting of the reducer
-SPLIT_ROWS = 4096
+SPLIT_ROWS = 4096      # upper bound on rows per part
+SPLIT_MIN_ROWS = 256   # lower bound: a part still streams 256 KiB at 1 KiB rows, partials stay < 2 % of traffic
+FILL_WAVES = 8192      # 256 CUs x 32 waves
 
 
 def reduce_split_rows(lay: Lay) -> int:
-    """Rows per part for rua_segment_reduce, or 0.  One wave streams a sequence at ~4 GB/s, so sequences
-    beyond a few thousand rows are cut into parts.  When the host does not know the longest sequence
-    (device-only lengths) the split machinery (one memset + two near-empty launches) is armed only where a
-    tail could matter: long average sequences or few of them."""
-    if lay.n_rows <= SPLIT_ROWS:
+    """Rows per part for rua_segment_reduce, or 0 (= one wave streams each whole sequence, ~4 GB/s per wave).
+    The part size is chosen so that even ONE sequence holding all the rows yields enough parts to fill the
+    chip (n_rows / 8192, clamped to [256, 4096]); sequences no longer than that are never split.  When the
+    host does not know the longest sequence (device-only lengths) the machinery (one memset + two near-empty
+    launches) is armed only where a tail could matter: long average sequences or few of them."""
+    target = max(SPLIT_MIN_ROWS, min(SPLIT_ROWS, lay.n_rows // FILL_WAVES))
+    if lay.n_rows <= target:
         return 0
     if lay.max_len is not None:
-        return SPLIT_ROWS if lay.max_len > SPLIT_ROWS else 0
-    return SPLIT_ROWS if (lay.n_rows >= 256 * max(lay.B, 1) or lay.B < 1024) else 0
+        return target if lay.max_len > target else 0
+    return target if (lay.n_rows >= 256 * max(lay.B, 1) or lay.B < 1024) else 0

@@ -445,29 +445,56 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_tail_kernel(rua_layout L,
   fold_extreme<A, EPL, OP>(f, extreme, i, lane, true);
 }
 
-// fold the partials of every long unit in part order and finalise
+// fold the partials of every long unit and finalise.  A 16-wave workgroup per unit: wave w folds the
+// contiguous range of parts [w*per, (w+1)*per) in order (4 partials in flight), then wave 0 folds the 16
+// range results in wave order — a fixed association that depends only on the part count, so the result is
+// bitwise reproducible.
+constexpr int COMBINE_WAVES = 16;
+
 template <typename T, int EPL, int OP>
-__global__ __launch_bounds__(RUA_WAVE) void seg_reduce_combine_kernel(rua_layout L, const int64_t* __restrict__ perm,
-                                                                      T* __restrict__ out, int64_t H, int lp_log2,
-                                                                      int include_self, T empty_val, rua_layout CD,
-                                                                      int copy_mode, SplitWs W) {
+__global__ __launch_bounds__(RUA_WAVE * COMBINE_WAVES) void seg_reduce_combine_kernel(
+    rua_layout L, const int64_t* __restrict__ perm, T* __restrict__ out, int64_t H, int lp_log2, int include_self,
+    T empty_val, rua_layout CD, int copy_mode, SplitWs W) {
   using A = typename elem<T>::acc;
-  const int lane = threadIdx.x;
+  __shared__ A s_acc[COMBINE_WAVES][RUA_WAVE * EPL];
+  __shared__ A s_aux[COMBINE_WAVES][RUA_WAVE * EPL];
+  const int lane = threadIdx.x & (RUA_WAVE - 1), wave = threadIdx.x >> 6;
   const int64_t j = blockIdx.x;
-  if ((unsigned long long)j >= W.ctr[1]) return;
+  if ((unsigned long long)j >= W.ctr[1]) return;   // block-uniform
   const int64_t* e = W.long_list + j * 4;
-  const Unit<T, EPL> U = copy_mode ? make_unit<T, EPL, true>(L, CD, perm, e[0], e[1], H, lp_log2, lane)
-                                   : make_unit<T, EPL, false>(L, CD, perm, e[0], e[1], H, lp_log2, lane);
+  const int64_t nparts = e[2], pbase = e[3];
+  const int64_t per = (nparts + COMBINE_WAVES - 1) / COMBINE_WAVES;
+  const int64_t p_lo = wave * per, p_hi = (p_lo + per < nparts) ? p_lo + per : nparts;
   Fold<A, EPL> f;
   fold_init<A, EPL, OP>(f);
   const A* P = reinterpret_cast<const A*>(W.partials);
-  for (int64_t p = 0; p < e[2]; ++p) {
-    const A* pp = P + ((e[3] + p) * 2 * RUA_WAVE + lane) * EPL;
+  constexpr int PF = 4;
+  for (int64_t p = p_lo; p < p_hi; p += PF) {
+    A a2[PF][EPL], x2[PF][EPL];
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if (p + u < p_hi) {
+        const A* pp = P + ((pbase + p + u) * 2 * RUA_WAVE + lane) * EPL;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) { a2[u][k] = pp[k]; x2[u][k] = pp[RUA_WAVE * EPL + k]; }
+      }
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if (p + u < p_hi) fold_merge<A, EPL, OP>(f, a2[u], x2[u]);
+  }
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) { s_acc[wave][lane * EPL + k] = f.acc[k]; s_aux[wave][lane * EPL + k] = f.aux[k]; }
+  __syncthreads();
+  if (wave != 0) return;
+  for (int w = 1; w < COMBINE_WAVES; ++w) {
+    if (w * per >= nparts) break;     // ranges beyond the last part are empty
     A a2[EPL], x2[EPL];
 #pragma unroll
-    for (int k = 0; k < EPL; ++k) { a2[k] = pp[k]; x2[k] = pp[RUA_WAVE * EPL + k]; }
+    for (int k = 0; k < EPL; ++k) { a2[k] = s_acc[w][lane * EPL + k]; x2[k] = s_aux[w][lane * EPL + k]; }
     fold_merge<A, EPL, OP>(f, a2, x2);
   }
+  const Unit<T, EPL> U = copy_mode ? make_unit<T, EPL, true>(L, CD, perm, e[0], e[1], H, lp_log2, lane)
+                                   : make_unit<T, EPL, false>(L, CD, perm, e[0], e[1], H, lp_log2, lane);
   fold_store<T, EPL, OP>(U, f, out, H, include_self, empty_val);
 }
 
@@ -659,7 +686,8 @@ static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout&
                        (T*)out, H, lp_log2, n_chunks, include_self, ev, ext, CD, (T*)copy, W);                      \
     hipLaunchKernelGGL((seg_reduce_tail_kernel<T, EPL, OP, NT, COPY>), dim3((unsigned)max_u), b, 0, s, L, perm,     \
                        (const T*)data, H, lp_log2, ext, CD, (T*)copy, W);                                           \
-    hipLaunchKernelGGL((seg_reduce_combine_kernel<T, EPL, OP>), dim3((unsigned)max_u), b, 0, s, L, perm, (T*)out,   \
+    hipLaunchKernelGGL((seg_reduce_combine_kernel<T, EPL, OP>), dim3((unsigned)max_u),                             \
+                       dim3(RUA_WAVE * COMBINE_WAVES), 0, s, L, perm, (T*)out,                                      \
                        H, lp_log2, include_self, ev, CD, COPY ? 1 : 0, W);                                          \
   } else {                                                                                                          \
     hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY, false>), g, b, 0, s, L, perm, (const T*)data,       \
