@@ -87,3 +87,23 @@ def test_host_metadata_helpers():
     assert M._memo_get(t, 'k') == 7
     t.add_(1)                                # in-place edit invalidates what was derived from it
     assert M._memo_get(t, 'k') is None
+
+
+def test_reducer_split_policy():
+    """Host-side choice of the reducer's part size (no GPU involved)."""
+    from torchrua_amd import _meta as M
+
+    class FakeLay:
+        def __init__(self, n_rows, B, max_len):
+            self.n_rows, self.B, self.max_len = n_rows, B, max_len
+
+    ns = FakeLay(17_046_960, 65536, 512)               # north-star shape: nothing to split
+    assert M.reduce_split_rows(ns) == 0
+    assert M.reduce_split_rows(FakeLay(34_000_000, 65536, 1024)) == 0          # cfg4
+    assert M.reduce_split_rows(FakeLay(1_131_008, 2048, 1_000_000)) == 256     # one giant sequence
+    assert M.reduce_split_rows(FakeLay(100_000_000, 64, 5_000_000)) == 4096
+    assert M.reduce_split_rows(FakeLay(536_149, 16384, None)) == 0             # cfg3, device-only lengths
+    assert M.reduce_split_rows(FakeLay(5_000_000, 100, None)) == 610           # few long sequences, lengths unknown
+    assert M.reduce_split_rows(FakeLay(200, 3, 150)) == 0
+    t = torch.tensor([3, 9, 2])
+    assert M.known_max_len(t) == 9 and M.known_max_len(None) is None

@@ -1,0 +1,108 @@
+"""API-surface behaviours next to the kernels: dtype/device movers, *_view constructors, the opt-in Tensor
+indexing patch, the torchrua alias, PackedSequences made by torch itself."""
+import sys
+
+import numpy as np
+import pytest
+import torch
+from torch.nn.utils.rnn import pack_sequence, pad_sequence
+
+import torchrua_amd as ta
+from gpu_util import DEV
+
+pytestmark = pytest.mark.gpu
+
+
+def _xs(lens, dim=5):
+    return [torch.randn(n, dim, device=DEV) for n in lens]
+
+
+def test_movers_keep_structure():
+    c = ta.C.new(_xs([3, 1, 4]))
+    for z in (c, c.left(), c.right()):
+        assert z.double().data.dtype == torch.float64 and z.half().data.dtype == torch.float16
+        assert z.long().data.dtype == torch.long and z.byte().data.dtype == torch.uint8
+        assert type(z.float()) is type(z) and z.float().token_sizes.dtype == torch.long
+        back = z.cpu()
+        assert back.data.device.type == 'cpu' and back.token_sizes.device.type == 'cpu'
+        again = back.cuda()
+        assert torch.equal(again.data, z.data) and again.data.is_cuda
+        assert not z.detach().data.requires_grad
+        assert torch.equal(z.to(dtype=torch.float64).cat().data, c.data.double())
+
+
+def test_views_share_storage_and_metadata():
+    xs = _xs([2, 5, 3])
+    c = ta.C.new(xs)
+    p = c.pack()
+    l = c.left()
+    assert p.cat_view().data is p.data and p.cat_view().token_sizes.tolist() == [2, 5, 3]
+    assert c.cat_view() is c and l.left_view(0) is l and p.pack_view() is p
+    lv = c.left_view(-1.0)
+    assert lv.data.shape == (3, 5, 5) and bool((lv.data == -1).all()) and lv.token_sizes.tolist() == [2, 5, 3]
+    rv = p.right_view(7, dtype=torch.long)
+    assert rv.data.dtype == torch.long and bool((rv.data == 7).all())
+    pv = l.pack_view()
+    assert pv.data is l.data and torch.equal(pv.batch_sizes, p.batch_sizes)
+    assert torch.equal(pv.sorted_indices, p.sorted_indices) and torch.equal(pv.unsorted_indices, p.unsorted_indices)
+    assert c.raw() is c.data and l.raw().shape == (15, 5)
+    assert c.size() == (3, 5, 5) == l.size() == p.size()
+
+
+def test_z_keys_and_tensor_patch():
+    xs = _xs([2, 4, 1])
+    c = ta.C.new(xs)
+    p = c.pack()
+    idx = p.idx()                                   # a PackedSequence of row indices
+    assert torch.equal(p[idx].data, p.data)         # container[Z] re-wraps
+    assert torch.equal(c[c.idx().roll(1)].data, c.roll(1).data)
+    plain = torch.arange(10, device=DEV)
+    with pytest.raises((TypeError, IndexError, RuntimeError)):
+        plain[idx]                                  # not patched by default
+    ta.patch_tensor_indexing()
+    try:
+        got = p.data[idx]                           # reference core/get.py:11-18 behaviour, opt-in
+        assert isinstance(got, ta.P) and torch.equal(got.data, p.data)
+        buf = torch.zeros_like(p.data)
+        buf[idx] = p.data
+        assert torch.equal(buf, p.data)
+        assert plain[2].item() == 2                 # ordinary indexing untouched
+    finally:
+        from torchrua_amd import core
+        torch.Tensor.__getitem__ = core._tensor_getitem
+        torch.Tensor.__setitem__ = core._tensor_setitem
+
+
+def test_alias_module():
+    ta.install_as_torchrua()
+    import torchrua
+    assert torchrua is sys.modules['torchrua_amd'] and torchrua.C is ta.C
+    assert torchrua.segment_sum is ta.segment_sum
+
+
+def test_packed_sequences_built_by_torch():
+    """PackedSequence from torch.nn.utils.rnn (both enforce_sorted modes) feeds every consumer."""
+    lens = [5, 4, 4, 2, 1]
+    xs = _xs(lens)
+    exp_pad = pad_sequence(xs, batch_first=True)
+    exp_sum = torch.stack([x.sum(0) for x in xs])
+    for enforce in (False, True):
+        p = pack_sequence(xs, enforce_sorted=enforce)          # sorted_indices is None when enforce_sorted=True
+        assert torch.equal(p.left().data, exp_pad)
+        assert torch.equal(p.cat().data, torch.cat(xs))
+        assert p.cat().token_sizes.tolist() == lens
+        torch.testing.assert_close(ta.reduce_sum(p), exp_sum, rtol=1e-5, atol=1e-5)
+        assert torch.equal(p.last(), torch.stack([x[-1] for x in xs]))
+        assert torch.equal(p.roll(1).cat().data, torch.cat([x.roll(1, 0) for x in xs]))
+        bp, tp = p.ptr()
+        assert bp[:5].tolist() == [0, 1, 2, 3, 4] and tp[:5].tolist() == [0] * 5
+
+
+def test_wrong_device_and_dtype_errors():
+    c = ta.C.new(_xs([2, 3]))
+    with pytest.raises(ta.RuaError):
+        ta.segment_sum(c.data.long(), c.token_sizes)           # integer reductions are not in the reference either
+    with pytest.raises(ta.RuaError):
+        ta.scatter_sum(torch.zeros(2, 5, device=DEV), torch.tensor([0, 1, 1, 0, 0]), c.data)   # index on the CPU
+    with pytest.raises(ta.RuaError):
+        ta.scatter_max(torch.zeros(5, 2, device=DEV), torch.zeros(5, dtype=torch.long, device=DEV), c.data, dim=1)
