@@ -519,24 +519,12 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_kernel(rua_layout L, co
   const int64_t wid = blockIdx.x;
   const int64_t q = wid / n_chunks;
   if (q >= L.B) return;
-  const int64_t chunk = wid - q * n_chunks;
-  const int64_t b = (L.kind == RUA_PACK && L.sorted) ? L.sorted[q] : q;
-  const int rpw = RUA_WAVE >> lp_log2;
-  const int rsub = lane >> lp_log2;
-  const int64_t col = (chunk * RUA_WAVE + (lane & ((1 << lp_log2) - 1))) * EPL;
-  const bool colok = col < H;
-  const int64_t len = seq_len(L, b);
+  const Unit<T, EPL> U = make_unit<T, EPL, false>(L, L, perm, q, wid - q * n_chunks, H, lp_log2, lane);
+  const int64_t b = U.b, col = U.col, len = U.len, base = U.base, tb = U.tb;
+  const int64_t* __restrict__ tbl = U.tbl;
+  const int rpw = U.rpw, rsub = U.rsub;
+  const bool colok = U.colok;
   if (len <= 0) return;
-  int64_t base = 0, tb = 0;
-  const int64_t* __restrict__ tbl = nullptr;
-  switch (L.kind) {
-    case RUA_CAT:
-      if (perm) { tbl = perm; tb = cat_off(L, b); } else base = cat_off(L, b);
-      break;
-    case RUA_PACK:  tbl = L.boff; base = L.sorted ? q : (L.unsorted ? L.unsorted[b] : b); break;
-    case RUA_LEFT:  base = b * L.T_phys; break;
-    case RUA_RIGHT: base = b * L.T_phys + (L.T_log - len); break;
-  }
 
   A o[EPL], g[EPL];
 #pragma unroll
