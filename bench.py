@@ -167,7 +167,8 @@ def main():
             torch.cuda.synchronize(dev)
 
     p = out = None
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 2)):   # at least 2: the loop keeps the previous PackedSequence alive, so the
+                                           # allocator needs two steps to own both 17 GB buffers
         p, out = step()      # keep the previous result alive exactly like the timed loop does, so the caching
     sync()                   # allocator reaches its steady state (two 17 GB P buffers) before the clock starts
     timer.enabled = True
