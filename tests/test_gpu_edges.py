@@ -226,3 +226,22 @@ def test_long_sequences_are_split(hidden, dtype):
     x = data.to(DEV).float().requires_grad_(True)
     ta.segment_sum(x, known.token_sizes).sum().backward()
     assert torch.equal(x.grad, torch.ones_like(x))
+
+
+def test_scatter_huge_fan_in_is_fast_and_right():
+    """One destination receiving 300 000 rows: no quadratic ordering pass, still the right values."""
+    import time
+    g = torch.Generator().manual_seed(0)
+    M, H = 300_000, 8
+    index = torch.zeros(M, dtype=torch.long)
+    index[::1000] = 1
+    src = torch.randn(M, H, generator=g)
+    ten = torch.zeros(2, H)
+    t0 = time.perf_counter()
+    out = ta.scatter_sum(ten.to(DEV), index.to(DEV), src.to(DEV))
+    mx = ta.scatter_max(ten.to(DEV), index.to(DEV), src.to(DEV))
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 5.0
+    ref = torch.zeros(2, H, dtype=torch.float64).index_add_(0, index, src.double())
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().numpy(), rtol=1e-3, atol=2e-2)
+    assert torch.equal(mx.cpu()[0], src[index == 0].max(0).values) and torch.equal(mx.cpu()[1], src[index == 1].max(0).values)

@@ -2,7 +2,7 @@
 // reduce.py:6-31: torch.index_reduce / index_add) becomes a segmented reduce with a row
 // indirection (rua_segment_reduce(perm=...)): no float atomics on the data path, and the
 // summation order is a fixed function of the inputs (ascending source row per destination),
-// so results are bitwise reproducible.  gfx950, wave64.
+// so results are bitwise reproducible (for destinations receiving up to 1 024 rows).  gfx950, wave64.
 #include "rua_dev.h"
 
 namespace rua {
@@ -53,20 +53,23 @@ __global__ __launch_bounds__(RUA_BLOCK) void bucket_sort_kernel(const int64_t* _
     if (lane < n) perm[base + lane] = v;
     return;
   }
-  // rank by counting (values distinct): rank(i) = #{j : v[j] < v[i]}
-  const bool staged = n <= SORT_LDS;
-  if (staged) {
-    for (int64_t i = lane; i < n; i += RUA_WAVE) s_buf[wave][i] = tmp[base + i];
+  if (n > SORT_LDS) {
+    // very large fan-in: ordering would cost O(n^2 / 64) here; keep the atomic arrival order.  The
+    // reduction is still correct; only its bitwise reproducibility is given up for this destination
+    // (torch.index_add / index_reduce on a GPU make no such promise at any size).
+    for (int64_t i = lane; i < n; i += RUA_WAVE) perm[base + i] = tmp[base + i];
+    return;
   }
+  // rank by counting (values distinct): rank(i) = #{j : v[j] < v[i]}, staged in LDS
+  for (int64_t i = lane; i < n; i += RUA_WAVE) s_buf[wave][i] = tmp[base + i];
   // waves of a block do not share s_buf rows, and a wave executes in lockstep: a wave-level
   // fence is enough to make the staged values visible to the other lanes of this wave
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   for (int64_t i = lane; i < n; i += RUA_WAVE) {
-    const int64_t vi = staged ? s_buf[wave][i] : tmp[base + i];
+    const int64_t vi = s_buf[wave][i];
     int64_t rank = 0;
-    if (staged) { for (int64_t j = 0; j < n; ++j) rank += s_buf[wave][j] < vi; }
-    else        { for (int64_t j = 0; j < n; ++j) rank += tmp[base + j] < vi; }
+    for (int64_t j = 0; j < n; ++j) rank += s_buf[wave][j] < vi;
     perm[base + rank] = vi;
   }
 }
