@@ -2,7 +2,6 @@
 import json
 import os
 import subprocess
-import sys
 
 import numpy as np
 import torch

@@ -2,7 +2,6 @@
 indexing patch, the torchrua alias, PackedSequences made by torch itself."""
 import sys
 
-import numpy as np
 import pytest
 import torch
 from torch.nn.utils.rnn import pack_sequence, pad_sequence

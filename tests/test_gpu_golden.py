@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import torchrua_amd as ta
-from gpu_util import DEV, KINDS, assert_same_seq, dev_seq, host_seq
+from gpu_util import DEV, assert_same_seq, dev_seq
 from helpers import cases, golden, orc, seq_from, to_np, to_torch
 
 pytestmark = pytest.mark.gpu

@@ -82,3 +82,22 @@ def test_reductions_vs_oracle(shape):
             ref = getattr(orc, f'scatter_{name}')(ten.numpy(), index[perm].numpy(), f32[perm.numpy()], include_self=True)
             got = getattr(ta, f'scatter_{name}')(ten.to(DEV), index[perm].to(DEV), data[perm].to(DEV), include_self=True)
             np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=1e-4, err_msg=f'scatter {name}')
+
+
+def test_bf16_outputs_are_the_rounded_fp32_oracle():
+    """accumulate in fp32, round ONCE: the bf16 result equals oracle.bfloat16() up to 1 ulp
+    (the reference's own bf16 path accumulates in bf16 and is ~1.5 % off, so it cannot be the yardstick)."""
+    lens, data = _inputs((300, 1, 700, (136,), torch.bfloat16))
+    c = ta.C(data.to(DEV), lens.to(DEV))
+    p = c.pack()
+    f32 = data.float().numpy()
+    for name in ('sum', 'mean'):
+        ref = torch.from_numpy(getattr(orc, f'segment_{name}')(f32, lens.numpy())).bfloat16()
+        for got in (getattr(ta, f'segment_{name}')(c.data, c.token_sizes), getattr(ta, f'reduce_{name}')(p)):
+            a = got.cpu().view(torch.int16).to(torch.int32)
+            b = ref.view(torch.int16).to(torch.int32)
+            # adjacent bf16 values differ by 1 in their bit patterns (same sign); +-0 are 0x0000 / 0x8000
+            ulps = (a - b).abs()
+            same_sign = (a < 0) == (b < 0)
+            assert bool(((ulps <= 1) & same_sign | (ref.float().abs() < 1e-3)).all()), name
+            assert float((ulps == 0).float().mean()) > 0.97     # and almost always identical

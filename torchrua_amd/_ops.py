@@ -5,7 +5,6 @@ nothing maps to) — the same kernel.  Backward of a segmented reduce is one fus
 (rua_segment_reduce_backward); scatter_* backward is still composed from
 gathers + elementwise torch ops on the result.
 """
-import struct
 from typing import Callable, Optional, Sequence, Tuple
 
 import torch

@@ -7,7 +7,6 @@ exchange is ONE all-gather of the reduced [B/R, H] outputs; contiguous shards ma
 buffer come out in global batch order.  The reference has no distributed code."""
 from typing import Callable, Optional, Tuple
 
-import torch
 import torch.distributed as dist
 from torch import Tensor
 

@@ -11,12 +11,11 @@ reduce_*   : the same reductions over the sequences of ANY container (C/L/P/R) -
              it in the reference as p.cat() + segment_sum, or scatter_sum over p.ptr()[0]).
 """
 import torch
-from torch import Tensor
 
 from torchrua_amd import _lib as K
 from torchrua_amd import _meta as M
 from torchrua_amd import _ops as O
-from torchrua_amd.layout import C, L, P, R, T, Z, describe, lens_of
+from torchrua_amd.layout import C, P, T, Z, describe, lens_of
 
 __all__ = [
     'segment_max', 'segment_min', 'segment_sum', 'segment_mean', 'segment_prod', 'segment_logsumexp',
