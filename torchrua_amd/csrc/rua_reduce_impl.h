@@ -1,0 +1,798 @@
+// rua_reduce.hip — segmented reductions over the sequences of ANY layout (gfx950, wave64).
+//
+// One wave owns one (sequence, 64-lane column chunk): lanes are spread over the hidden
+// dimension with 16-byte loads (8 x bf16 / 4 x f32 per lane), rows of the sequence are walked
+// in t with UNROLL_T rows in flight, accumulation is fp32 (fp64 for f64) in registers, and the
+// result is rounded ONCE on the way out.  Rows narrower than 1 KiB share a wave instruction
+// (several t per instruction) and are combined with a butterfly at the end.  No atomics on the
+// data path, no LDS traffic: the kernel is a pure HBM stream of N*H*e bytes + S*H*e out.
+//
+// Row addressing per layout (include/rua.h): CAT off[b]+t (contiguous), PACK boff[t]+rank[b]
+// (stride varies with t), LEFT/RIGHT b*T+t(+pad), and CAT+perm for the bucketed scatter_*.
+#pragma once
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include "rua_dev.h"
+
+namespace rua {
+
+constexpr int UNROLL_T = 8;
+constexpr int EXTREME_SLOTS = 64;  // contention spreading for the global min/max tracker
+
+// ---------------------------------------------------------------- element conversion
+template <typename T> struct elem;
+template <> struct elem<float> {
+  using acc = float;
+  static __device__ __forceinline__ float up(float v) { return v; }
+  static __device__ __forceinline__ float down(float v) { return v; }
+};
+template <> struct elem<double> {
+  using acc = double;
+  static __device__ __forceinline__ double up(double v) { return v; }
+  static __device__ __forceinline__ double down(double v) { return v; }
+};
+template <> struct elem<__hip_bfloat16> {
+  using acc = float;
+  static __device__ __forceinline__ float up(__hip_bfloat16 v) { return __bfloat162float(v); }
+  static __device__ __forceinline__ __hip_bfloat16 down(float v) { return __float2bfloat16(v); }
+};
+template <> struct elem<__half> {
+  using acc = float;
+  static __device__ __forceinline__ float up(__half v) { return __half2float(v); }
+  static __device__ __forceinline__ __half down(float v) { return __float2half(v); }
+};
+
+template <typename A> __device__ __forceinline__ A acc_inf();
+template <> __device__ __forceinline__ float acc_inf<float>() { return __builtin_inff(); }
+template <> __device__ __forceinline__ double acc_inf<double>() { return __builtin_inf(); }
+
+// NaN-propagating max/min (torch.segment_reduce / index_reduce semantics)
+template <typename A> __device__ __forceinline__ A nmax(A a, A b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
+template <typename A> __device__ __forceinline__ A nmin(A a, A b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
+
+// NaN-ignoring max/min (one v_max_f32 / v_min_f32)
+__device__ __forceinline__ float fmaxx(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double fmaxx(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float fminx(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double fminx(double a, double b) { return fmin(a, b); }
+
+__device__ __forceinline__ float fexp(float x) { return __expf(x); }
+__device__ __forceinline__ double fexp(double x) { return exp(x); }
+__device__ __forceinline__ float flog(float x) { return logf(x); }
+__device__ __forceinline__ double flog(double x) { return log(x); }
+
+// order-preserving map float -> unsigned so integer atomics give float min/max
+__device__ __forceinline__ uint64_t ordered_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? (uint32_t)~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ uint64_t ordered_bits(double f) {
+  uint64_t u = (uint64_t)__double_as_longlong(f);
+  return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ float unordered_f32(uint64_t o) {
+  uint32_t u = (uint32_t)o;
+  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ double unordered_f64(uint64_t u) {
+  u = (u & 0x8000000000000000ull) ? (u & 0x7fffffffffffffffull) : ~u;
+  return __longlong_as_double((long long)u);
+}
+
+// ---------------------------------------------------------------- the forward kernels
+// EPL: elements per lane per load (16 B / sizeof(T) on the vector path, 1 on the scalar path)
+// COPY: every row that is read is ALSO stored to its row of a PackedSequence (layout CD, storage
+// `copy`) — pack and reduce in one pass over the payload (rua_pack_reduce): N*H*e read + N*H*e written
+// instead of 3*N*H*e for pack-then-reduce.  Sequences are then walked in CD's rank order.
+// SPLIT: sequences longer than `split` rows are cut into parts of `split` rows; the wave that owns the
+// sequence publishes the extra parts to a work list (consumed by seg_reduce_tail_kernel, launched next on
+// the stream) and every part stores a raw fp32 partial; seg_reduce_combine_kernel folds the partials in
+// part order (deterministic) and finalises.  Without it one wave streams a whole sequence (~4 GB/s).
+
+// the addressing of one (sequence slot, column chunk) unit
+template <typename T, int EPL>
+struct Unit {
+  int64_t q, b, chunk, col, len, base, tb;
+  const int64_t* tbl;
+  int rpw, rsub, lp_log2;
+  bool colok;
+};
+
+template <typename T, int EPL, bool COPY>
+__device__ __forceinline__ Unit<T, EPL> make_unit(const rua_layout& L, const rua_layout& CD, const int64_t* perm,
+                                                   int64_t q, int64_t chunk, int64_t H, int lp_log2, int lane) {
+  Unit<T, EPL> u;
+  u.q = q;
+  u.chunk = chunk;
+  // PACK is walked in rank order (longest first = LPT schedule; neighbouring workgroups read
+  // neighbouring rows of every time step), everything else in batch order.
+  u.b = COPY ? (CD.sorted ? CD.sorted[q] : q) : ((L.kind == RUA_PACK && L.sorted) ? L.sorted[q] : q);
+  u.lp_log2 = lp_log2;
+  u.rpw = RUA_WAVE >> lp_log2;
+  u.rsub = lane >> lp_log2;
+  u.col = (chunk * RUA_WAVE + (lane & ((1 << lp_log2) - 1))) * EPL;
+  u.colok = u.col < H;
+  u.len = seq_len(L, u.b);
+  u.base = 0;
+  u.tb = 0;
+  u.tbl = nullptr;   // row(t) = base + (tbl ? tbl[tb + t] : t)
+  switch (L.kind) {
+    case RUA_CAT:
+      if (perm) { u.tbl = perm; u.tb = cat_off(L, u.b); } else u.base = cat_off(L, u.b);
+      break;
+    case RUA_PACK:  u.tbl = L.boff; u.base = L.sorted ? q : (L.unsorted ? L.unsorted[u.b] : u.b); break;
+    case RUA_LEFT:  u.base = u.b * L.T_phys; break;
+    case RUA_RIGHT: u.base = u.b * L.T_phys + (L.T_log - u.len); break;
+  }
+  return u;
+}
+
+// running state of one lane
+template <typename A, int EPL>
+struct Fold {
+  A acc[EPL], aux[EPL];   // aux: running sum for LOGSUMEXP (acc holds the running max)
+  bool nan_e[EPL];
+  A ext;                  // extreme of everything read (the reference's global `initial`)
+  bool ext_nan;
+};
+
+template <typename A, int EPL, int OP>
+__device__ __forceinline__ void fold_init(Fold<A, EPL>& f) {
+  f.ext = (OP == RUA_MAX || OP == RUA_LOGSUMEXP) ? acc_inf<A>() : -acc_inf<A>();
+  f.ext_nan = false;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    f.acc[e] = (OP == RUA_PROD) ? (A)1 : (OP == RUA_MAX || OP == RUA_LOGSUMEXP) ? -acc_inf<A>()
+             : (OP == RUA_MIN) ? acc_inf<A>() : (A)0;
+    f.aux[e] = (A)0;
+    f.nan_e[e] = false;
+  }
+}
+
+// fold rows [t_lo, t_hi) of the unit's sequence
+template <typename T, int EPL, int OP, bool NT, bool COPY>
+__device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, int64_t t_hi,
+                                          const T* __restrict__ data, int64_t H,
+                                          Fold<typename elem<T>::acc, EPL>& f, const rua_layout& CD,
+                                          T* __restrict__ copy, int lane) {
+  using A = typename elem<T>::acc;
+  struct alignas(sizeof(T) * EPL) Pack { T v[EPL]; };
+  typedef unsigned int RawV __attribute__((ext_vector_type(sizeof(T) * EPL >= 4 ? sizeof(T) * EPL / 4 : 1)));
+  const int rpw = U.rpw, rsub = U.rsub;
+  const bool colok = U.colok;
+  const int64_t col = U.col, base = U.base, tb = U.tb;
+  const int64_t* __restrict__ tbl = U.tbl;
+
+  // the row table (boff / perm) is fetched 64 entries at a time with one coalesced load and
+  // handed to the lanes by ds_bpermute; the next block's entries are in flight while this
+  // block's payload streams.
+  int64_t tv = (tbl && t_lo + lane < t_hi) ? tbl[tb + t_lo + lane] : 0;
+  int64_t cv = (COPY && t_lo + lane < t_hi) ? CD.boff[t_lo + lane] : 0;      // destination rows: boff[t] + rank
+  for (int64_t tblk = t_lo; tblk < t_hi; tblk += RUA_WAVE) {
+    const int64_t nxt = tblk + RUA_WAVE + lane;
+    const int64_t tv_next = (tbl && nxt < t_hi) ? tbl[tb + nxt] : 0;
+    const int64_t cv_next = (COPY && nxt < t_hi) ? CD.boff[nxt] : 0;
+    const int nblk = (t_hi - tblk) < RUA_WAVE ? (int)(t_hi - tblk) : RUA_WAVE;
+    for (int k = 0; k < nblk; k += rpw * UNROLL_T) {
+      int64_t row[UNROLL_T];
+      int64_t crow[UNROLL_T];
+      Pack p[UNROLL_T];
+#pragma unroll
+      for (int u = 0; u < UNROLL_T; ++u) {
+        const int tl = k + u * rpw + rsub;
+        const int64_t tabv = __shfl(tv, tl & (RUA_WAVE - 1), RUA_WAVE);
+        row[u] = -1;
+        if (colok && tl < nblk) row[u] = base + (tbl ? tabv : tblk + tl);
+        if (COPY) crow[u] = __shfl(cv, tl & (RUA_WAVE - 1), RUA_WAVE) + U.q;
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL_T; ++u)
+        if (row[u] >= 0) {
+          const T* src = data + row[u] * H + col;
+          if (NT && sizeof(Pack) >= 4) {   // streaming read of a payload that cannot stay in cache
+            RawV raw = __builtin_nontemporal_load(reinterpret_cast<const RawV*>(src));
+            __builtin_memcpy(&p[u], &raw, sizeof(Pack));
+          } else {
+            p[u] = *reinterpret_cast<const Pack*>(src);
+          }
+        }
+      if (COPY) {
+#pragma unroll
+        for (int u = 0; u < UNROLL_T; ++u)
+          if (row[u] >= 0) {
+            T* dstp = copy + crow[u] * H + col;
+            if (NT && sizeof(Pack) >= 4) {
+              RawV raw;
+              __builtin_memcpy(&raw, &p[u], sizeof(Pack));
+              __builtin_nontemporal_store(raw, reinterpret_cast<RawV*>(dstp));
+            } else {
+              *reinterpret_cast<Pack*>(dstp) = p[u];
+            }
+          }
+      }
+      if (OP == RUA_LOGSUMEXP) {
+        // chunk-wise online logsumexp: the chunk's max first, ONE rescale of the running sum per
+        // chunk, then one exp per element
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          A x[UNROLL_T];
+          A cm = -acc_inf<A>();
+#pragma unroll
+          for (int u = 0; u < UNROLL_T; ++u) {
+            x[u] = row[u] >= 0 ? elem<T>::up(p[u].v[e]) : -acc_inf<A>();
+            cm = fmaxx(cm, x[u]);
+            if (row[u] >= 0) { f.ext = fminx(f.ext, x[u]); f.ext_nan |= (x[u] != x[u]); }
+          }
+          if (cm > f.acc[e]) { f.aux[e] *= fexp(f.acc[e] - cm); f.acc[e] = cm; }
+          const A m = f.acc[e];
+#pragma unroll
+          for (int u = 0; u < UNROLL_T; ++u)
+            if (row[u] >= 0) f.aux[e] += fexp(x[u] - m);   // NaN x -> NaN sum; all -inf -> NaN, as the reference
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < UNROLL_T; ++u) {
+          if (row[u] < 0) continue;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            const A x = elem<T>::up(p[u].v[e]);
+            if (OP == RUA_SUM || OP == RUA_MEAN) f.acc[e] += x;
+            else if (OP == RUA_PROD) f.acc[e] *= x;
+            else if (OP == RUA_MAX) {   // v_max ignores NaN: NaNs are tracked on the side (a scalar mask OR)
+              f.acc[e] = fmaxx(f.acc[e], x); f.nan_e[e] |= (x != x); f.ext = fminx(f.ext, x);
+            } else if (OP == RUA_MIN) {
+              f.acc[e] = fminx(f.acc[e], x); f.nan_e[e] |= (x != x); f.ext = fmaxx(f.ext, x);
+            }
+          }
+        }
+      }
+    }
+    tv = tv_next;
+    cv = cv_next;
+  }
+}
+
+// fold the NaN flags in and combine the rpw row-groups of the wave (lanes that differ in the bits above
+// lp_log2); afterwards every lane of a column holds the wave's value
+template <typename A, int EPL, int OP>
+__device__ __forceinline__ void fold_wave(Fold<A, EPL>& f, int lp_log2) {
+  if (OP == RUA_MAX || OP == RUA_MIN) {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      if (f.nan_e[e]) f.acc[e] = f.acc[e] - f.acc[e] + (A)__builtin_nanf("");   // torch: max/min propagate NaN
+      f.ext_nan |= f.nan_e[e];
+    }
+  }
+  for (int d = 1 << lp_log2; d < RUA_WAVE; d <<= 1) {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      const A o = __shfl_xor(f.acc[e], d, RUA_WAVE);
+      if (OP == RUA_SUM || OP == RUA_MEAN) f.acc[e] += o;
+      else if (OP == RUA_PROD) f.acc[e] *= o;
+      else if (OP == RUA_MAX) f.acc[e] = nmax(f.acc[e], o);
+      else if (OP == RUA_MIN) f.acc[e] = nmin(f.acc[e], o);
+      else {
+        const A os = __shfl_xor(f.aux[e], d, RUA_WAVE);
+        const A m = nmax(f.acc[e], o);
+        if (m == -acc_inf<A>()) { f.aux[e] = f.aux[e] + os; }       // both empty so far
+        else { f.aux[e] = f.aux[e] * fexp(f.acc[e] - m) + os * fexp(o - m); }
+        f.acc[e] = m;
+      }
+    }
+  }
+}
+
+// merge another part's (already wave-folded) values, in part order
+template <typename A, int EPL, int OP>
+__device__ __forceinline__ void fold_merge(Fold<A, EPL>& f, const A* acc2, const A* aux2) {
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    const A o = acc2[e];
+    if (OP == RUA_SUM || OP == RUA_MEAN) f.acc[e] += o;
+    else if (OP == RUA_PROD) f.acc[e] *= o;
+    else if (OP == RUA_MAX) f.acc[e] = nmax(f.acc[e], o);
+    else if (OP == RUA_MIN) f.acc[e] = nmin(f.acc[e], o);
+    else {
+      const A m = nmax(f.acc[e], o);
+      if (m == -acc_inf<A>()) { f.aux[e] = f.aux[e] + aux2[e]; }
+      else { f.aux[e] = f.aux[e] * fexp(f.acc[e] - m) + aux2[e] * fexp(o - m); }
+      f.acc[e] = m;
+    }
+  }
+}
+
+// include_self: 0 = overwrite (empty sequence -> empty_val), 1 = fold the old out[b] in,
+//               2 = leave out[b] untouched when the sequence is empty (index_reduce semantics)
+template <typename T, int EPL, int OP>
+__device__ __forceinline__ void fold_store(const Unit<T, EPL>& U, Fold<typename elem<T>::acc, EPL>& f,
+                                           T* __restrict__ out, int64_t H, int include_self, T empty_val) {
+  using A = typename elem<T>::acc;
+  const bool keep = include_self == 2 && U.len <= 0;
+  const bool inc = include_self == 1;
+  if (U.colok && U.rsub == 0 && !keep) {
+    T* o = out + U.b * H + U.col;
+    const int64_t cnt = U.len + (inc ? 1 : 0);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      A r = f.acc[e];
+      if (OP == RUA_LOGSUMEXP) {
+        if (inc) {  // fold exp(self) in
+          const A x = elem<T>::up(o[e]);
+          const A m = nmax(r, x);
+          f.aux[e] = f.aux[e] * fexp(r - m) + fexp(x - m);
+          r = m;
+        }
+        r = flog(f.aux[e]) + r;
+      } else if (inc) {
+        const A x = elem<T>::up(o[e]);
+        if (OP == RUA_SUM || OP == RUA_MEAN) r += x;
+        else if (OP == RUA_PROD) r *= x;
+        else if (OP == RUA_MAX) r = nmax(r, x);
+        else if (OP == RUA_MIN) r = nmin(r, x);
+      }
+      if (OP == RUA_MEAN && cnt > 0) r = r / (A)cnt;
+      o[e] = (cnt == 0) ? empty_val : elem<T>::down(r);
+    }
+  }
+}
+
+// one no-return integer atomic per wave into a hashed slot (the reference's global initial, reduce.py:35,40)
+template <typename A, int EPL, int OP>
+__device__ __forceinline__ void fold_extreme(Fold<A, EPL>& f, unsigned long long* __restrict__ extreme,
+                                             int64_t wid, int lane, bool any_rows) {
+  if (!(OP == RUA_MAX || OP == RUA_MIN || OP == RUA_LOGSUMEXP) || !extreme) return;
+  A ext = f.ext;
+#pragma unroll
+  for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {
+    const A o = __shfl_xor(ext, d, RUA_WAVE);
+    if (OP == RUA_MIN) ext = o > ext ? o : ext; else ext = o < ext ? o : ext;
+  }
+  const bool any_nan = __any(f.ext_nan);
+  if (lane == 0 && any_rows) {
+    const int slot = (int)(wid & (EXTREME_SLOTS - 1));
+    if (OP == RUA_MIN) atomicMax(&extreme[slot], (unsigned long long)ordered_bits(ext));
+    else atomicMin(&extreme[slot], (unsigned long long)ordered_bits(ext));
+    if (any_nan) atomicOr(&extreme[EXTREME_SLOTS], 1ull);
+  }
+}
+
+// ---- long-sequence splitting: workspace layout (int64 words unless noted)
+//   ctr[0] = published extra items, ctr[1] = long units, ctr[2] = partial slots handed out
+//   long_list[max_u][4] = {q, chunk, nparts, pbase};  items[max_u][4] = {q, chunk, part, slot}
+//   partials[2*max_u][2][64*EPL] of A
+struct SplitWs {
+  unsigned long long* ctr;
+  int64_t* long_list;
+  int64_t* items;
+  void* partials;
+  int64_t max_u;      // bound on extra items and on long units
+  int64_t split;      // rows per part (0 = splitting off)
+};
+
+template <typename A, int EPL>
+__device__ __forceinline__ void store_partial(void* partials, int64_t slot, int lane, const Fold<A, EPL>& f) {
+  A* p = reinterpret_cast<A*>(partials) + (slot * 2 * RUA_WAVE + lane) * EPL;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) { p[e] = f.acc[e]; p[RUA_WAVE * EPL + e] = f.aux[e]; }
+}
+
+template <typename T, int EPL, int OP, bool NT, bool COPY, bool SPLIT>
+__global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, const int64_t* __restrict__ perm,
+                                                              const T* __restrict__ data, T* __restrict__ out,
+                                                              int64_t H, int lp_log2, int64_t n_chunks,
+                                                              int include_self, T empty_val,
+                                                              unsigned long long* __restrict__ extreme,
+                                                              rua_layout CD, T* __restrict__ copy, SplitWs W) {
+  using A = typename elem<T>::acc;
+  // ONE wave per workgroup: sequences differ in length, and a multi-wave workgroup would hold
+  // its CU slots until its longest sequence is done.
+  const int lane = threadIdx.x;
+  const int64_t wid = blockIdx.x;
+  const int64_t q = wid / n_chunks;          // sequence slot
+  if (q >= L.B) return;
+  const Unit<T, EPL> U = make_unit<T, EPL, COPY>(L, CD, perm, q, wid - q * n_chunks, H, lp_log2, lane);
+  Fold<A, EPL> f;
+  fold_init<A, EPL, OP>(f);
+
+  if (SPLIT && U.len > W.split) {
+    // long sequence: this wave takes part 0 and publishes the rest
+    const int64_t nparts = (U.len + W.split - 1) / W.split;
+    int64_t pbase = 0, ibase = 0, li = 0;
+    if (lane == 0) {
+      pbase = (int64_t)atomicAdd(&W.ctr[2], (unsigned long long)nparts);
+      ibase = (int64_t)atomicAdd(&W.ctr[0], (unsigned long long)(nparts - 1));
+      li = (int64_t)atomicAdd(&W.ctr[1], 1ull);
+      int64_t* e = W.long_list + li * 4;
+      e[0] = q; e[1] = U.chunk; e[2] = nparts; e[3] = pbase;
+    }
+    pbase = __shfl(pbase, 0, RUA_WAVE);
+    ibase = __shfl(ibase, 0, RUA_WAVE);
+    for (int64_t p = 1 + lane; p < nparts; p += RUA_WAVE) {
+      int64_t* e = W.items + (ibase + p - 1) * 4;
+      e[0] = q; e[1] = U.chunk; e[2] = p; e[3] = pbase + p;
+    }
+    fold_rows<T, EPL, OP, NT, COPY>(U, 0, W.split, data, H, f, CD, copy, lane);
+    fold_wave<A, EPL, OP>(f, lp_log2);
+    store_partial<A, EPL>(W.partials, pbase, lane, f);
+  } else {
+    fold_rows<T, EPL, OP, NT, COPY>(U, 0, U.len, data, H, f, CD, copy, lane);
+    fold_wave<A, EPL, OP>(f, lp_log2);
+    fold_store<T, EPL, OP>(U, f, out, H, include_self, empty_val);
+  }
+  fold_extreme<A, EPL, OP>(f, extreme, wid, lane, U.len > 0);
+}
+
+// the published parts 1.. of long sequences
+template <typename T, int EPL, int OP, bool NT, bool COPY>
+__global__ __launch_bounds__(RUA_WAVE) void seg_reduce_tail_kernel(rua_layout L, const int64_t* __restrict__ perm,
+                                                                   const T* __restrict__ data, int64_t H,
+                                                                   int lp_log2,
+                                                                   unsigned long long* __restrict__ extreme,
+                                                                   rua_layout CD, T* __restrict__ copy, SplitWs W) {
+  using A = typename elem<T>::acc;
+  const int lane = threadIdx.x;
+  const int64_t i = blockIdx.x;
+  if ((unsigned long long)i >= W.ctr[0]) return;
+  const int64_t* e = W.items + i * 4;
+  const Unit<T, EPL> U = make_unit<T, EPL, COPY>(L, CD, perm, e[0], e[1], H, lp_log2, lane);
+  const int64_t t_lo = e[2] * W.split;
+  const int64_t t_hi = (t_lo + W.split < U.len) ? t_lo + W.split : U.len;
+  Fold<A, EPL> f;
+  fold_init<A, EPL, OP>(f);
+  fold_rows<T, EPL, OP, NT, COPY>(U, t_lo, t_hi, data, H, f, CD, copy, lane);
+  fold_wave<A, EPL, OP>(f, lp_log2);
+  store_partial<A, EPL>(W.partials, e[3], lane, f);
+  fold_extreme<A, EPL, OP>(f, extreme, i, lane, true);
+}
+
+// fold the partials of every long unit and finalise.  A 16-wave workgroup per unit: wave w folds the
+// contiguous range of parts [w*per, (w+1)*per) in order (4 partials in flight), then wave 0 folds the 16
+// range results in wave order — a fixed association that depends only on the part count, so the result is
+// bitwise reproducible.
+constexpr int COMBINE_WAVES = 16;
+
+template <typename T, int EPL, int OP>
+__global__ __launch_bounds__(RUA_WAVE * COMBINE_WAVES) void seg_reduce_combine_kernel(
+    rua_layout L, const int64_t* __restrict__ perm, T* __restrict__ out, int64_t H, int lp_log2, int include_self,
+    T empty_val, rua_layout CD, int copy_mode, SplitWs W) {
+  using A = typename elem<T>::acc;
+  __shared__ A s_acc[COMBINE_WAVES][RUA_WAVE * EPL];
+  __shared__ A s_aux[COMBINE_WAVES][RUA_WAVE * EPL];
+  const int lane = threadIdx.x & (RUA_WAVE - 1), wave = threadIdx.x >> 6;
+  const int64_t j = blockIdx.x;
+  if ((unsigned long long)j >= W.ctr[1]) return;   // block-uniform
+  const int64_t* e = W.long_list + j * 4;
+  const int64_t nparts = e[2], pbase = e[3];
+  const int64_t per = (nparts + COMBINE_WAVES - 1) / COMBINE_WAVES;
+  const int64_t p_lo = wave * per, p_hi = (p_lo + per < nparts) ? p_lo + per : nparts;
+  Fold<A, EPL> f;
+  fold_init<A, EPL, OP>(f);
+  const A* P = reinterpret_cast<const A*>(W.partials);
+  constexpr int PF = 4;
+  for (int64_t p = p_lo; p < p_hi; p += PF) {
+    A a2[PF][EPL], x2[PF][EPL];
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if (p + u < p_hi) {
+        const A* pp = P + ((pbase + p + u) * 2 * RUA_WAVE + lane) * EPL;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) { a2[u][k] = pp[k]; x2[u][k] = pp[RUA_WAVE * EPL + k]; }
+      }
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if (p + u < p_hi) fold_merge<A, EPL, OP>(f, a2[u], x2[u]);
+  }
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) { s_acc[wave][lane * EPL + k] = f.acc[k]; s_aux[wave][lane * EPL + k] = f.aux[k]; }
+  __syncthreads();
+  if (wave != 0) return;
+  for (int w = 1; w < COMBINE_WAVES; ++w) {
+    if (w * per >= nparts) break;     // ranges beyond the last part are empty
+    A a2[EPL], x2[EPL];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) { a2[k] = s_acc[w][lane * EPL + k]; x2[k] = s_aux[w][lane * EPL + k]; }
+    fold_merge<A, EPL, OP>(f, a2, x2);
+  }
+  const Unit<T, EPL> U = copy_mode ? make_unit<T, EPL, true>(L, CD, perm, e[0], e[1], H, lp_log2, lane)
+                                   : make_unit<T, EPL, false>(L, CD, perm, e[0], e[1], H, lp_log2, lane);
+  fold_store<T, EPL, OP>(U, f, out, H, include_self, empty_val);
+}
+
+// ---------------------------------------------------------------- backward of the reductions
+// One wave per (sequence, column chunk), same row addressing as the forward.  grad_in[row] is
+//   SUM  g            MEAN g / len           PROD g * out / x        LOGSUMEXP g * exp(x - out)
+//   MAX/MIN  (x == out) ? g / ties : 0   — ties counted in a first walk over the sequence (the rows are
+//   re-read from L2 by the second walk), so tied maxima share the gradient equally like torch's
+//   segment_reduce backward.  Rows of padded layouts that hold no token are not written (the caller
+//   zero-fills padded grads).
+constexpr int UNROLL_B = 4;
+
+template <typename T, int EPL, int OP>
+__global__ __launch_bounds__(RUA_WAVE) void seg_backward_kernel(rua_layout L, const int64_t* __restrict__ perm,
+                                                                const T* __restrict__ data,
+                                                                const T* __restrict__ out,
+                                                                const T* __restrict__ gout, T* __restrict__ gin,
+                                                                int64_t H, int lp_log2, int64_t n_chunks) {
+  using A = typename elem<T>::acc;
+  struct alignas(sizeof(T) * EPL) Pack { T v[EPL]; };
+  const int lane = threadIdx.x;
+  const int64_t wid = blockIdx.x;
+  const int64_t q = wid / n_chunks;
+  if (q >= L.B) return;
+  const Unit<T, EPL> U = make_unit<T, EPL, false>(L, L, perm, q, wid - q * n_chunks, H, lp_log2, lane);
+  const int64_t b = U.b, col = U.col, len = U.len, base = U.base, tb = U.tb;
+  const int64_t* __restrict__ tbl = U.tbl;
+  const int rpw = U.rpw, rsub = U.rsub;
+  const bool colok = U.colok;
+  if (len <= 0) return;
+
+  A o[EPL], g[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) { o[e] = (A)0; g[e] = (A)0; }
+  if (colok) {
+    const Pack po = *reinterpret_cast<const Pack*>(out + b * H + col);
+    const Pack pg = *reinterpret_cast<const Pack*>(gout + b * H + col);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { o[e] = elem<T>::up(po.v[e]); g[e] = elem<T>::up(pg.v[e]); }
+  }
+  if (OP == RUA_MEAN) {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) g[e] = g[e] / (A)len;
+  }
+
+  for (int pass = (OP == RUA_MAX || OP == RUA_MIN) ? 0 : 1; pass < 2; ++pass) {
+    A cnt[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) cnt[e] = (A)0;
+    int64_t tv = (tbl && lane < len) ? tbl[tb + lane] : 0;
+    for (int64_t tblk = 0; tblk < len; tblk += RUA_WAVE) {
+      const int64_t nxt = tblk + RUA_WAVE + lane;
+      const int64_t tv_next = (tbl && nxt < len) ? tbl[tb + nxt] : 0;
+      const int nblk = (len - tblk) < RUA_WAVE ? (int)(len - tblk) : RUA_WAVE;
+      for (int k = 0; k < nblk; k += rpw * UNROLL_B) {
+        int64_t row[UNROLL_B];
+        Pack p[UNROLL_B];
+#pragma unroll
+        for (int u = 0; u < UNROLL_B; ++u) {
+          const int tl = k + u * rpw + rsub;
+          const int64_t tabv = __shfl(tv, tl & (RUA_WAVE - 1), RUA_WAVE);
+          row[u] = -1;
+          if (colok && tl < nblk) row[u] = base + (tbl ? tabv : tblk + tl);
+        }
+        const bool need_x = (OP != RUA_SUM && OP != RUA_MEAN);
+#pragma unroll
+        for (int u = 0; u < UNROLL_B; ++u)
+          if (need_x && row[u] >= 0) p[u] = *reinterpret_cast<const Pack*>(data + row[u] * H + col);
+#pragma unroll
+        for (int u = 0; u < UNROLL_B; ++u) {
+          if (row[u] < 0) continue;
+          Pack r;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            const A x = need_x ? elem<T>::up(p[u].v[e]) : (A)0;
+            A gi;
+            if (OP == RUA_SUM || OP == RUA_MEAN) gi = g[e];
+            else if (OP == RUA_PROD) gi = g[e] * o[e] / x;
+            else if (OP == RUA_LOGSUMEXP) gi = g[e] * fexp(x - o[e]);
+            else {
+              const bool hit = (x == o[e]) || (x != x && o[e] != o[e]);
+              if (pass == 0) cnt[e] += hit ? (A)1 : (A)0;
+              gi = hit ? g[e] : (A)0;
+            }
+            r.v[e] = elem<T>::down(gi);
+          }
+          if (pass == 1) *reinterpret_cast<Pack*>(gin + row[u] * H + col) = r;
+        }
+      }
+      tv = tv_next;
+    }
+    if (pass == 0) {   // MAX/MIN: share the gradient among the ties of every column
+      for (int d = 1 << lp_log2; d < RUA_WAVE; d <<= 1) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) cnt[e] += __shfl_xor(cnt[e], d, RUA_WAVE);
+      }
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) g[e] = g[e] / (cnt[e] > (A)0 ? cnt[e] : (A)1);
+    } 
+  }
+}
+
+// extreme scratch: [0..63] hashed ordered-bit slots, [64] NaN flag (initialised by rua_reduce.hip)
+template <typename T>
+__global__ __launch_bounds__(RUA_BLOCK) void fill_empty_kernel(rua_layout L, T* __restrict__ out, int64_t H,
+                                                               int want_max_of_data,
+                                                               const unsigned long long* __restrict__ ext) {
+  using A = typename elem<T>::acc;
+  // decode the tracked extreme: lane i reads slot i, 6-step butterfly
+  const int lane = threadIdx.x & (RUA_WAVE - 1);
+  unsigned long long best = ext[lane];
+#pragma unroll
+  for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {
+    const unsigned long long o = __shfl_xor(best, d, RUA_WAVE);
+    best = want_max_of_data ? (o > best ? o : best) : (o < best ? o : best);
+  }
+  const bool poison = ext[EXTREME_SLOTS] != 0ull;
+  A val;
+  if (sizeof(A) == 8) val = (A)unordered_f64(best); else val = (A)unordered_f32(best);
+  if (poison) val = val - val + (A)__builtin_nanf("");
+  const T tv = elem<T>::down(val);
+
+  // one thread per sequence; only empty sequences (or everything, when a NaN poisoned `initial`) are written
+  const int64_t b = (int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x;
+  if (b >= L.B) return;
+  if (!poison && seq_len(L, b) > 0) return;
+  T* o = out + b * H;
+  for (int64_t h = 0; h < H; ++h) o[h] = tv;
+}
+
+static inline unsigned grid_for(int64_t n) { return (unsigned)((n + RUA_BLOCK - 1) / RUA_BLOCK); }
+
+// workspace carving for the long-sequence split (see SplitWs)
+static inline int64_t split_max_extra(int64_t n_rows, int64_t split) { return split > 0 ? n_rows / split : 0; }
+
+template <typename A>
+static SplitWs carve_ws(void* ws, int64_t max_u, int64_t split) {
+  SplitWs W;
+  char* p = (char*)ws;
+  W.ctr = (unsigned long long*)p;            p += 4 * sizeof(unsigned long long);
+  W.long_list = (int64_t*)p;                 p += (size_t)max_u * 4 * sizeof(int64_t);
+  W.items = (int64_t*)p;                     p += (size_t)max_u * 4 * sizeof(int64_t);
+  W.partials = (void*)p;
+  W.max_u = max_u;
+  W.split = split;
+  return W;
+}
+
+template <typename T, int EPL, bool NT, bool COPY>
+static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout& L, const int64_t* perm,
+                         const void* data, void* out, int64_t H, int lp_log2, int64_t n_chunks, int include_self,
+                         uint64_t empty_bits, void* extreme, const rua_layout& CD, void* copy, int64_t split,
+                         void* ws) {
+  using A = typename elem<T>::acc;
+  T ev;
+  __builtin_memcpy(&ev, &empty_bits, sizeof(T));
+  const dim3 g(grid), b(RUA_WAVE);
+  const int64_t max_u = split_max_extra(L.n_rows, split) * n_chunks;
+  const bool do_split = split > 0 && ws && max_u > 0;
+  SplitWs W = {};
+  if (do_split) {
+    if (max_u > 0x7fffffffLL) return RUA_ERANGE;
+    W = carve_ws<A>(ws, max_u, split);
+    hipError_t e = hipMemsetAsync(W.ctr, 0, 4 * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return (int)e;
+  }
+  unsigned long long* ext = (unsigned long long*)extreme;
+#define RUA_LAUNCH(OP)                                                                                              \
+  if (do_split) {                                                                                                   \
+    hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY, true>), g, b, 0, s, L, perm, (const T*)data,        \
+                       (T*)out, H, lp_log2, n_chunks, include_self, ev, ext, CD, (T*)copy, W);                      \
+    hipLaunchKernelGGL((seg_reduce_tail_kernel<T, EPL, OP, NT, COPY>), dim3((unsigned)max_u), b, 0, s, L, perm,     \
+                       (const T*)data, H, lp_log2, ext, CD, (T*)copy, W);                                           \
+    hipLaunchKernelGGL((seg_reduce_combine_kernel<T, EPL, OP>), dim3((unsigned)max_u),                             \
+                       dim3(RUA_WAVE * COMBINE_WAVES), 0, s, L, perm, (T*)out,                                      \
+                       H, lp_log2, include_self, ev, CD, COPY ? 1 : 0, W);                                          \
+  } else {                                                                                                          \
+    hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY, false>), g, b, 0, s, L, perm, (const T*)data,       \
+                       (T*)out, H, lp_log2, n_chunks, include_self, ev, ext, CD, (T*)copy, W);                      \
+  }
+  switch (op) {
+    case RUA_SUM: RUA_LAUNCH(RUA_SUM); break;
+    case RUA_MEAN: RUA_LAUNCH(RUA_MEAN); break;
+    case RUA_MAX: RUA_LAUNCH(RUA_MAX); break;
+    case RUA_MIN: RUA_LAUNCH(RUA_MIN); break;
+    case RUA_PROD: RUA_LAUNCH(RUA_PROD); break;
+    case RUA_LOGSUMEXP: RUA_LAUNCH(RUA_LOGSUMEXP); break;
+    default: return RUA_EINVAL;
+  }
+#undef RUA_LAUNCH
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,
+                           void* out, int64_t H, int include_self, uint64_t empty_bits, void* extreme,
+                           int64_t split, void* ws, const rua_layout* CD = nullptr, void* copy = nullptr) {
+  constexpr int FULL = 16 / sizeof(T);
+  const bool vec_ok = (H % FULL == 0) && (((uintptr_t)data | (uintptr_t)out | (uintptr_t)copy) % 16 == 0);
+  const int epl = vec_ok ? FULL : 1;
+  const int64_t lpr = (H + epl - 1) / epl;  // lanes per row
+  int lp_log2 = 0;
+  while ((1 << lp_log2) < lpr && lp_log2 < 6) ++lp_log2;
+  const int64_t n_chunks = (lpr + RUA_WAVE - 1) / RUA_WAVE;
+  const int64_t blocks = L.B * n_chunks;  // one wave per workgroup
+  if (blocks > 0x7fffffffLL) return RUA_ERANGE;
+  const bool nt = (double)L.n_rows * (double)H * sizeof(T) >= (double)(512ll << 20);
+  const unsigned g = (unsigned)blocks;
+  static const rua_layout none = {};
+  if (copy) {   // fused pack + reduce: vector path only (the caller falls back to two launches otherwise)
+    if (!vec_ok) return RUA_EALIGN;
+    return nt ? launch_reduce<T, FULL, true, true>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
+                                                   empty_bits, extreme, *CD, copy, split, ws)
+              : launch_reduce<T, FULL, false, true>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
+                                                    empty_bits, extreme, *CD, copy, split, ws);
+  }
+  if (vec_ok && nt)
+    return launch_reduce<T, FULL, true, false>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
+                                               empty_bits, extreme, none, nullptr, split, ws);
+  if (vec_ok)
+    return launch_reduce<T, FULL, false, false>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
+                                                empty_bits, extreme, none, nullptr, split, ws);
+  return launch_reduce<T, 1, false, false>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
+                                           empty_bits, extreme, none, nullptr, split, ws);
+}
+
+
+template <typename T, int EPL>
+static int launch_backward(int op, unsigned grid, hipStream_t s, const rua_layout& L, const int64_t* perm,
+                           const void* data, const void* out, const void* gout, void* gin, int64_t H, int lp_log2,
+                           int64_t n_chunks) {
+  const dim3 g(grid), b(RUA_WAVE);
+#define RUA_LAUNCH(OP)                                                                                            \
+  hipLaunchKernelGGL((seg_backward_kernel<T, EPL, OP>), g, b, 0, s, L, perm, (const T*)data, (const T*)out,       \
+                     (const T*)gout, (T*)gin, H, lp_log2, n_chunks)
+  switch (op) {
+    case RUA_SUM: RUA_LAUNCH(RUA_SUM); break;
+    case RUA_MEAN: RUA_LAUNCH(RUA_MEAN); break;
+    case RUA_MAX: RUA_LAUNCH(RUA_MAX); break;
+    case RUA_MIN: RUA_LAUNCH(RUA_MIN); break;
+    case RUA_PROD: RUA_LAUNCH(RUA_PROD); break;
+    case RUA_LOGSUMEXP: RUA_LAUNCH(RUA_LOGSUMEXP); break;
+    default: return RUA_EINVAL;
+  }
+#undef RUA_LAUNCH
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,
+                             const void* out, const void* gout, void* gin, int64_t H) {
+  constexpr int FULL = 16 / sizeof(T);
+  const uintptr_t ptrs = (uintptr_t)data | (uintptr_t)out | (uintptr_t)gout | (uintptr_t)gin;
+  const bool vec_ok = (H % FULL == 0) && (ptrs % 16 == 0);
+  const int epl = vec_ok ? FULL : 1;
+  const int64_t lpr = (H + epl - 1) / epl;
+  int lp_log2 = 0;
+  while ((1 << lp_log2) < lpr && lp_log2 < 6) ++lp_log2;
+  const int64_t n_chunks = (lpr + RUA_WAVE - 1) / RUA_WAVE;
+  const int64_t blocks = L.B * n_chunks;
+  if (blocks > 0x7fffffffLL) return RUA_ERANGE;
+  if (vec_ok) return launch_backward<T, FULL>(op, (unsigned)blocks, s, L, perm, data, out, gout, gin, H, lp_log2, n_chunks);
+  return launch_backward<T, 1>(op, (unsigned)blocks, s, L, perm, data, out, gout, gin, H, lp_log2, n_chunks);
+}
+
+
+// ---- per-dtype entry points: each element type is compiled in its own translation unit
+// (rua_reduce_<dtype>.hip) so the ~300 kernel instantiations build in parallel
+#define RUA_DECLARE_REDUCE_DTYPE(NAME)                                                                              \
+  int reduce_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data, void* out,  \
+                    int64_t H, int include_self, uint64_t empty_bits, void* extreme, int64_t split, void* ws,     \
+                    const rua_layout* CD, void* copy);                                                             \
+  int backward_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,           \
+                      const void* out, const void* gout, void* gin, int64_t H);                                    \
+  int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, const void* ext);
+RUA_DECLARE_REDUCE_DTYPE(f32)
+RUA_DECLARE_REDUCE_DTYPE(bf16)
+RUA_DECLARE_REDUCE_DTYPE(f16)
+RUA_DECLARE_REDUCE_DTYPE(f64)
+
+#define RUA_DEFINE_REDUCE_DTYPE(NAME, T)                                                                            \
+  namespace rua {                                                                                                   \
+  int reduce_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data, void* out,  \
+                    int64_t H, int include_self, uint64_t empty_bits, void* extreme, int64_t split, void* ws,     \
+                    const rua_layout* CD, void* copy) {                                                            \
+    return dispatch_reduce<T>(op, s, L, perm, data, out, H, include_self, empty_bits, extreme, split, ws, CD,      \
+                              copy);                                                                               \
+  }                                                                                                                 \
+  int backward_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,           \
+                      const void* out, const void* gout, void* gin, int64_t H) {                                   \
+    return dispatch_backward<T>(op, s, L, perm, data, out, gout, gin, H);                                          \
+  }                                                                                                                 \
+  int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, const void* ext) { \
+    hipLaunchKernelGGL(fill_empty_kernel<T>, dim3(grid_for(L.B)), dim3(RUA_BLOCK), 0, s, L, (T*)out, H, want_max,  \
+                       (const unsigned long long*)ext);                                                            \
+    return (int)hipGetLastError();                                                                                  \
+  }                                                                                                                 \
+  }
+
+}  // namespace rua
