@@ -245,3 +245,21 @@ def test_scatter_huge_fan_in_is_fast_and_right():
     ref = torch.zeros(2, H, dtype=torch.float64).index_add_(0, index, src.double())
     np.testing.assert_allclose(out.cpu().numpy(), ref.float().numpy(), rtol=1e-3, atol=2e-2)
     assert torch.equal(mx.cpu()[0], src[index == 0].max(0).values) and torch.equal(mx.cpu()[1], src[index == 1].max(0).values)
+
+
+def test_empty_batch_and_empty_rows():
+    """Degenerate shapes go through without touching the GPU with bad geometry."""
+    e = ta.C(torch.empty(0, 4, device=DEV), torch.empty(0, dtype=torch.long, device=DEV))
+    assert e.cat() is e
+    assert ta.segment_sum(e.data, e.token_sizes).shape == (0, 4)
+    assert e.roll(1).data.shape == (0, 4) and e.head(1).data.shape == (0, 4)
+    p = e.pack()
+    assert p.data.shape == (0, 4) and p.batch_sizes.numel() == 0
+    assert e.left().data.shape[0] == 0
+    assert ta.get_offsets(e.token_sizes).numel() == 0
+    z = ta.C(torch.randn(5, 0, device=DEV), torch.tensor([2, 3], device=DEV))      # rows of zero width
+    assert z.pack().data.shape == (5, 0) and z.left().data.shape == (2, 3, 0)
+    assert ta.reduce_sum(z).shape == (2, 0)
+    only_empty = ta.C(torch.empty(0, 3, device=DEV), torch.zeros(4, dtype=torch.long, device=DEV))
+    assert torch.equal(ta.segment_sum(only_empty.data, only_empty.token_sizes), torch.zeros(4, 3, device=DEV))
+    assert torch.equal(ta.segment_prod(only_empty.data, only_empty.token_sizes), torch.ones(4, 3, device=DEV))
