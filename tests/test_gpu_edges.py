@@ -263,3 +263,23 @@ def test_empty_batch_and_empty_rows():
     only_empty = ta.C(torch.empty(0, 3, device=DEV), torch.zeros(4, dtype=torch.long, device=DEV))
     assert torch.equal(ta.segment_sum(only_empty.data, only_empty.token_sizes), torch.zeros(4, 3, device=DEV))
     assert torch.equal(ta.segment_prod(only_empty.data, only_empty.token_sizes), torch.ones(4, 3, device=DEV))
+
+
+def test_inconsistent_metadata_cannot_fault_the_gpu():
+    """Lengths that sum past the payload, or a PackedSequence whose indices are garbage, read as padding /
+    nothing instead of going out of bounds (a GPU fault here can reset the whole node)."""
+    data = torch.randn(10, 16, device=DEV)
+    bad = ta.C(data, torch.tensor([6, 9, 4], device=DEV))                # sums to 19 > 10 rows
+    out = ta.segment_sum(data, bad.token_sizes)
+    assert out.shape == (3, 16) and torch.isfinite(out).all()
+    torch.testing.assert_close(out[0], data[:6].sum(0))
+    left = bad.left(-1.0)
+    assert left.data.shape == (3, 9, 16) and torch.equal(left.data[0, :6], data[:6])
+    good = ta.C(data, torch.tensor([3, 5, 2], device=DEV)).pack()
+    broken = good._replace(sorted_indices=torch.tensor([7, -3, 99], device=DEV))
+    assert broken.cat().data.shape == (10, 16)                            # no fault; contents unspecified
+    assert ta.reduce_sum(broken).shape == (3, 16)
+    key = (torch.tensor([0, 5, -1], device=DEV), torch.tensor([1, 0, 2], device=DEV))
+    got = ta.C(data, torch.tensor([3, 5, 2], device=DEV))[key]            # batch_ptr out of range -> zero rows
+    assert torch.equal(got[0], data[1]) and bool((got[1] == 0).all()) and bool((got[2] == 0).all())
+    torch.cuda.synchronize()

@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_uint
 import torch  # noqa: F401  (must be imported first: maps the HIP runtime our library binds to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'librua_hip.so')
+LIB_PATH = os.environ.get('RUA_LIB_PATH') or os.path.join(_HERE, 'librua_hip.so')   # env: developer A/B of builds
 
 # enum rua_kind
 CAT, LEFT, PACK, RIGHT, LIST = 0, 1, 2, 3, 4

@@ -54,8 +54,9 @@ __device__ __forceinline__ bool row_to_token(const rua_layout& D, int64_t j, int
     case RUA_PACK: {
       t = search_boff(D.boff, D.T, j);
       int64_t r = j - D.boff[t];
+      if (r < 0 || r >= D.B) return false;          // batch_sizes inconsistent with the storage
       b = D.sorted ? D.sorted[r] : r;
-      return true;
+      return b >= 0 && b < D.B;                     // a corrupt sorted_indices must not index out of range
     }
     case RUA_LEFT:
       b = j / D.T_phys;

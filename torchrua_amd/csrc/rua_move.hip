@@ -81,6 +81,9 @@ __global__ __launch_bounds__(RUA_BLOCK) void move_rows_kernel(rua_layout D, rua_
         const int64_t dlen = D.kind == RUA_LIST ? slen : seq_len(D, b);
         const int64_t ts = apply_tmap(tmap, targ, t, slen, dlen);
         if (ts >= 0 && ts < slen) other = token_to_row(S, b, ts, slen);
+        // metadata that does not match the storage (lengths summing past the payload, a corrupt
+        // PackedSequence) must not become an out-of-bounds access: such rows read as padding
+        if (other >= S.n_rows) other = -1;
       } else {
         other = pad_row;  // padding row: fill (-1) or a copy of one fixed source row
       }

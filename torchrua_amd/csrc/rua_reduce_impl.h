@@ -93,7 +93,7 @@ __device__ __forceinline__ double unordered_f64(uint64_t u) {
 // the addressing of one (sequence slot, column chunk) unit
 template <typename T, int EPL>
 struct Unit {
-  int64_t q, b, chunk, col, len, base, tb;
+  int64_t q, b, chunk, col, len, base, tb, n_rows;
   const int64_t* tbl;
   int rpw, rsub, lp_log2;
   bool colok;
@@ -108,12 +108,14 @@ __device__ __forceinline__ Unit<T, EPL> make_unit(const rua_layout& L, const rua
   // PACK is walked in rank order (longest first = LPT schedule; neighbouring workgroups read
   // neighbouring rows of every time step), everything else in batch order.
   u.b = COPY ? (CD.sorted ? CD.sorted[q] : q) : ((L.kind == RUA_PACK && L.sorted) ? L.sorted[q] : q);
+  if (u.b < 0 || u.b >= L.B) u.b = q;   // a corrupt sorted_indices must not index out of range
   u.lp_log2 = lp_log2;
   u.rpw = RUA_WAVE >> lp_log2;
   u.rsub = lane >> lp_log2;
   u.col = (chunk * RUA_WAVE + (lane & ((1 << lp_log2) - 1))) * EPL;
   u.colok = u.col < H;
   u.len = seq_len(L, u.b);
+  u.n_rows = L.n_rows;
   u.base = 0;
   u.tb = 0;
   u.tbl = nullptr;   // row(t) = base + (tbl ? tbl[tb + t] : t)
@@ -161,7 +163,7 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
   typedef unsigned int RawV __attribute__((ext_vector_type(sizeof(T) * EPL >= 4 ? sizeof(T) * EPL / 4 : 1)));
   const int rpw = U.rpw, rsub = U.rsub;
   const bool colok = U.colok;
-  const int64_t col = U.col, base = U.base, tb = U.tb;
+  const int64_t col = U.col, base = U.base, tb = U.tb, L_rows = U.n_rows;
   const int64_t* __restrict__ tbl = U.tbl;
 
   // the row table (boff / perm) is fetched 64 entries at a time with one coalesced load and
@@ -184,6 +186,7 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
         const int64_t tabv = __shfl(tv, tl & (RUA_WAVE - 1), RUA_WAVE);
         row[u] = -1;
         if (colok && tl < nblk) row[u] = base + (tbl ? tabv : tblk + tl);
+        if (row[u] >= L_rows) row[u] = -1;   // lengths that run past the storage read nothing
         if (COPY) crow[u] = __shfl(cv, tl & (RUA_WAVE - 1), RUA_WAVE) + U.q;
       }
 #pragma unroll
@@ -200,7 +203,7 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
       if (COPY) {
 #pragma unroll
         for (int u = 0; u < UNROLL_T; ++u)
-          if (row[u] >= 0) {
+          if (row[u] >= 0 && crow[u] < CD.n_rows) {
             T* dstp = copy + crow[u] * H + col;
             if (NT && sizeof(Pack) >= 4) {
               RawV raw;
@@ -559,6 +562,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_kernel(rua_layout L, co
           const int64_t tabv = __shfl(tv, tl & (RUA_WAVE - 1), RUA_WAVE);
           row[u] = -1;
           if (colok && tl < nblk) row[u] = base + (tbl ? tabv : tblk + tl);
+          if (row[u] >= U.n_rows) row[u] = -1;
         }
         const bool need_x = (OP != RUA_SUM && OP != RUA_MEAN);
 #pragma unroll
