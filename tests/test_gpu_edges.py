@@ -1,6 +1,8 @@
 """Edge cases through the C ABI vs the CPU oracle: odd row widths (every vector width of the mover and
 the scalar path of the reducer), rows wider than a wave instruction, multi-dim hidden, integer payloads,
 single-token / single-sequence batches, zero-length segments, non-contiguous inputs, huge shifts."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -51,7 +53,7 @@ def test_all_casts_and_selects_any_row_width(hidden, dtype):
         assert_same_seq(h._replace(data=h.data.contiguous()), orc.head(osq[k], 1), f'head {k}')
 
 
-@settings(deadline=None, max_examples=40)
+@settings(deadline=None, max_examples=int(os.environ.get('RUA_HYP_EXAMPLES', 40)))
 @given(lens=st.lists(st.integers(1, 40), min_size=1, max_size=40), h=st.integers(1, 70),
        dtype=st.sampled_from([torch.float32, torch.bfloat16, torch.float16, torch.float64]),
        name=st.sampled_from(['sum', 'mean', 'max', 'min', 'prod', 'logsumexp']), kind=st.sampled_from('CLPR'))

@@ -1,6 +1,8 @@
 """Property tests on the GPU in the style of the reference's own suite (hypothesis over
 random ragged batches, every layout, values AND gradients), with expectations built from stock torch
 ops that do not touch torchrua_amd: pack_sequence / pad_sequence / per-sequence slicing and reductions."""
+import os
+
 import pytest
 import torch
 from hypothesis import given, settings, strategies as st
@@ -14,7 +16,7 @@ pytestmark = pytest.mark.gpu
 LAYOUTS = [ta.C, ta.L, ta.P, ta.R]
 lens_st = st.lists(st.integers(1, 23), min_size=1, max_size=19)
 dim_st = st.integers(1, 33)
-SET = dict(deadline=None, max_examples=30)
+SET = dict(deadline=None, max_examples=int(os.environ.get('RUA_HYP_EXAMPLES', 30)))   # soak: RUA_HYP_EXAMPLES=500
 
 
 def make(lens, dim, dtype=torch.float32):
