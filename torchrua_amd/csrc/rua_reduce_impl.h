@@ -99,7 +99,10 @@ struct Unit {
   bool colok;
 };
 
-template <typename T, int EPL, bool COPY>
+// CPW: 64-lane column chunks one wave covers per row (1, or 4 for rows wider than 1 KiB so that a whole row
+// — up to 4 KiB — is read back to back by ONE wave: DRAM pages are used in full instead of being shared by
+// several waves that each take 1 KiB of it; measured 4.4 -> 6 TB/s at 4-KiB rows)
+template <typename T, int EPL, bool COPY, int CPW = 1>
 __device__ __forceinline__ Unit<T, EPL> make_unit(const rua_layout& L, const rua_layout& CD, const int64_t* perm,
                                                    int64_t q, int64_t chunk, int64_t H, int lp_log2, int lane) {
   Unit<T, EPL> u;
@@ -112,7 +115,7 @@ __device__ __forceinline__ Unit<T, EPL> make_unit(const rua_layout& L, const rua
   u.lp_log2 = lp_log2;
   u.rpw = RUA_WAVE >> lp_log2;
   u.rsub = lane >> lp_log2;
-  u.col = (chunk * RUA_WAVE + (lane & ((1 << lp_log2) - 1))) * EPL;
+  u.col = (chunk * CPW * RUA_WAVE + (lane & ((1 << lp_log2) - 1))) * EPL;   // sub-chunk c adds c * 64 * EPL
   u.colok = u.col < H;
   u.len = seq_len(L, u.b);
   u.n_rows = L.n_rows;
@@ -153,12 +156,14 @@ __device__ __forceinline__ void fold_init(Fold<A, EPL>& f) {
 }
 
 // fold rows [t_lo, t_hi) of the unit's sequence
-template <typename T, int EPL, int OP, bool NT, bool COPY>
+template <typename T, int EPL, int OP, bool NT, bool COPY, int CPW = 1>
 __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, int64_t t_hi,
                                           const T* __restrict__ data, int64_t H,
-                                          Fold<typename elem<T>::acc, EPL>& f, const rua_layout& CD,
+                                          Fold<typename elem<T>::acc, EPL * CPW>& f, const rua_layout& CD,
                                           T* __restrict__ copy, int lane) {
   using A = typename elem<T>::acc;
+  constexpr int UT = CPW == 1 ? UNROLL_T : UNROLL_T / 2;     // rows in flight (x CPW loads each)
+  constexpr int CW = RUA_WAVE * EPL;                          // elements per 64-lane column chunk
   struct alignas(sizeof(T) * EPL) Pack { T v[EPL]; };
   typedef unsigned int RawV __attribute__((ext_vector_type(sizeof(T) * EPL >= 4 ? sizeof(T) * EPL / 4 : 1)));
   const int rpw = U.rpw, rsub = U.rsub;
@@ -176,12 +181,12 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
     const int64_t tv_next = (tbl && nxt < t_hi) ? tbl[tb + nxt] : 0;
     const int64_t cv_next = (COPY && nxt < t_hi) ? CD.boff[nxt] : 0;
     const int nblk = (t_hi - tblk) < RUA_WAVE ? (int)(t_hi - tblk) : RUA_WAVE;
-    for (int k = 0; k < nblk; k += rpw * UNROLL_T) {
-      int64_t row[UNROLL_T];
-      int64_t crow[UNROLL_T];
-      Pack p[UNROLL_T];
+    for (int k = 0; k < nblk; k += rpw * UT) {
+      int64_t row[UT];
+      int64_t crow[UT];
+      Pack p[UT][CPW];
 #pragma unroll
-      for (int u = 0; u < UNROLL_T; ++u) {
+      for (int u = 0; u < UT; ++u) {
         const int tl = k + u * rpw + rsub;
         const int64_t tabv = __shfl(tv, tl & (RUA_WAVE - 1), RUA_WAVE);
         row[u] = -1;
@@ -190,62 +195,71 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
         if (COPY) crow[u] = __shfl(cv, tl & (RUA_WAVE - 1), RUA_WAVE) + U.q;
       }
 #pragma unroll
-      for (int u = 0; u < UNROLL_T; ++u)
-        if (row[u] >= 0) {
-          const T* src = data + row[u] * H + col;
-          if (NT && sizeof(Pack) >= 4) {   // streaming read of a payload that cannot stay in cache
-            RawV raw = __builtin_nontemporal_load(reinterpret_cast<const RawV*>(src));
-            __builtin_memcpy(&p[u], &raw, sizeof(Pack));
-          } else {
-            p[u] = *reinterpret_cast<const Pack*>(src);
-          }
-        }
-      if (COPY) {
+      for (int u = 0; u < UT; ++u)
 #pragma unroll
-        for (int u = 0; u < UNROLL_T; ++u)
-          if (row[u] >= 0 && crow[u] < CD.n_rows) {
-            T* dstp = copy + crow[u] * H + col;
-            if (NT && sizeof(Pack) >= 4) {
-              RawV raw;
-              __builtin_memcpy(&raw, &p[u], sizeof(Pack));
-              __builtin_nontemporal_store(raw, reinterpret_cast<RawV*>(dstp));
+        for (int c = 0; c < CPW; ++c)
+          if (row[u] >= 0 && (CPW == 1 || col + c * CW < H)) {
+            const T* src = data + row[u] * H + col + c * CW;
+            if (NT && sizeof(Pack) >= 4) {   // streaming read of a payload that cannot stay in cache
+              RawV raw = __builtin_nontemporal_load(reinterpret_cast<const RawV*>(src));
+              __builtin_memcpy(&p[u][c], &raw, sizeof(Pack));
             } else {
-              *reinterpret_cast<Pack*>(dstp) = p[u];
+              p[u][c] = *reinterpret_cast<const Pack*>(src);
             }
           }
+      if (COPY) {
+#pragma unroll
+        for (int u = 0; u < UT; ++u)
+#pragma unroll
+          for (int c = 0; c < CPW; ++c)
+            if (row[u] >= 0 && crow[u] < CD.n_rows && (CPW == 1 || col + c * CW < H)) {
+              T* dstp = copy + crow[u] * H + col + c * CW;
+              if (NT && sizeof(Pack) >= 4) {
+                RawV raw;
+                __builtin_memcpy(&raw, &p[u][c], sizeof(Pack));
+                __builtin_nontemporal_store(raw, reinterpret_cast<RawV*>(dstp));
+              } else {
+                *reinterpret_cast<Pack*>(dstp) = p[u][c];
+              }
+            }
       }
       if (OP == RUA_LOGSUMEXP) {
         // chunk-wise online logsumexp: the chunk's max first, ONE rescale of the running sum per
         // chunk, then one exp per element
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-          A x[UNROLL_T];
+        for (int ce = 0; ce < EPL * CPW; ++ce) {
+          const int c = ce / EPL, e = ce % EPL;
+          const bool cok = CPW == 1 || col + c * CW < H;
+          A x[UT];
           A cm = -acc_inf<A>();
 #pragma unroll
-          for (int u = 0; u < UNROLL_T; ++u) {
-            x[u] = row[u] >= 0 ? elem<T>::up(p[u].v[e]) : -acc_inf<A>();
+          for (int u = 0; u < UT; ++u) {
+            const bool ok = row[u] >= 0 && cok;
+            x[u] = ok ? elem<T>::up(p[u][c].v[e]) : -acc_inf<A>();
             cm = fmaxx(cm, x[u]);
-            if (row[u] >= 0) { f.ext = fminx(f.ext, x[u]); f.ext_nan |= (x[u] != x[u]); }
+            if (ok) { f.ext = fminx(f.ext, x[u]); f.ext_nan |= (x[u] != x[u]); }
           }
-          if (cm > f.acc[e]) { f.aux[e] *= fexp(f.acc[e] - cm); f.acc[e] = cm; }
-          const A m = f.acc[e];
+          if (cm > f.acc[ce]) { f.aux[ce] *= fexp(f.acc[ce] - cm); f.acc[ce] = cm; }
+          const A m = f.acc[ce];
 #pragma unroll
-          for (int u = 0; u < UNROLL_T; ++u)
-            if (row[u] >= 0) f.aux[e] += fexp(x[u] - m);   // NaN x -> NaN sum; all -inf -> NaN, as the reference
+          for (int u = 0; u < UT; ++u)
+            if (row[u] >= 0 && cok) f.aux[ce] += fexp(x[u] - m);   // NaN x -> NaN sum; all -inf -> NaN, as the reference
         }
       } else {
 #pragma unroll
-        for (int u = 0; u < UNROLL_T; ++u) {
+        for (int u = 0; u < UT; ++u) {
           if (row[u] < 0) continue;
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) {
-            const A x = elem<T>::up(p[u].v[e]);
-            if (OP == RUA_SUM || OP == RUA_MEAN) f.acc[e] += x;
-            else if (OP == RUA_PROD) f.acc[e] *= x;
+          for (int ce = 0; ce < EPL * CPW; ++ce) {
+            const int c = ce / EPL, e = ce % EPL;
+            if (CPW > 1 && col + c * CW >= H) continue;
+            const A x = elem<T>::up(p[u][c].v[e]);
+            if (OP == RUA_SUM || OP == RUA_MEAN) f.acc[ce] += x;
+            else if (OP == RUA_PROD) f.acc[ce] *= x;
             else if (OP == RUA_MAX) {   // v_max ignores NaN: NaNs are tracked on the side (a scalar mask OR)
-              f.acc[e] = fmaxx(f.acc[e], x); f.nan_e[e] |= (x != x); f.ext = fminx(f.ext, x);
+              f.acc[ce] = fmaxx(f.acc[ce], x); f.nan_e[ce] |= (x != x); f.ext = fminx(f.ext, x);
             } else if (OP == RUA_MIN) {
-              f.acc[e] = fminx(f.acc[e], x); f.nan_e[e] |= (x != x); f.ext = fmaxx(f.ext, x);
+              f.acc[ce] = fminx(f.acc[ce], x); f.nan_e[ce] |= (x != x); f.ext = fmaxx(f.ext, x);
             }
           }
         }
@@ -307,26 +321,29 @@ __device__ __forceinline__ void fold_merge(Fold<A, EPL>& f, const A* acc2, const
 
 // include_self: 0 = overwrite (empty sequence -> empty_val), 1 = fold the old out[b] in,
 //               2 = leave out[b] untouched when the sequence is empty (index_reduce semantics)
-template <typename T, int EPL, int OP>
-__device__ __forceinline__ void fold_store(const Unit<T, EPL>& U, Fold<typename elem<T>::acc, EPL>& f,
+template <typename T, int EPL, int OP, int CPW = 1>
+__device__ __forceinline__ void fold_store(const Unit<T, EPL>& U, Fold<typename elem<T>::acc, EPL * CPW>& f,
                                            T* __restrict__ out, int64_t H, int include_self, T empty_val) {
   using A = typename elem<T>::acc;
+  constexpr int CW = RUA_WAVE * EPL;
   const bool keep = include_self == 2 && U.len <= 0;
   const bool inc = include_self == 1;
   if (U.colok && U.rsub == 0 && !keep) {
-    T* o = out + U.b * H + U.col;
     const int64_t cnt = U.len + (inc ? 1 : 0);
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      A r = f.acc[e];
+    for (int ce = 0; ce < EPL * CPW; ++ce) {
+      const int c = ce / EPL, e = ce % EPL;
+      if (CPW > 1 && U.col + c * CW >= H) continue;
+      T* o = out + U.b * H + U.col + c * CW;
+      A r = f.acc[ce];
       if (OP == RUA_LOGSUMEXP) {
         if (inc) {  // fold exp(self) in
           const A x = elem<T>::up(o[e]);
           const A m = nmax(r, x);
-          f.aux[e] = f.aux[e] * fexp(r - m) + fexp(x - m);
+          f.aux[ce] = f.aux[ce] * fexp(r - m) + fexp(x - m);
           r = m;
         }
-        r = flog(f.aux[e]) + r;
+        r = flog(f.aux[ce]) + r;
       } else if (inc) {
         const A x = elem<T>::up(o[e]);
         if (OP == RUA_SUM || OP == RUA_MEAN) r += x;
@@ -380,7 +397,7 @@ __device__ __forceinline__ void store_partial(void* partials, int64_t slot, int 
   for (int e = 0; e < EPL; ++e) { p[e] = f.acc[e]; p[RUA_WAVE * EPL + e] = f.aux[e]; }
 }
 
-template <typename T, int EPL, int OP, bool NT, bool COPY, bool SPLIT>
+template <typename T, int EPL, int OP, bool NT, bool COPY, bool SPLIT, int CPW>
 __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, const int64_t* __restrict__ perm,
                                                               const T* __restrict__ data, T* __restrict__ out,
                                                               int64_t H, int lp_log2, int64_t n_chunks,
@@ -394,9 +411,10 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
   const int64_t wid = blockIdx.x;
   const int64_t q = wid / n_chunks;          // sequence slot
   if (q >= L.B) return;
-  const Unit<T, EPL> U = make_unit<T, EPL, COPY>(L, CD, perm, q, wid - q * n_chunks, H, lp_log2, lane);
-  Fold<A, EPL> f;
-  fold_init<A, EPL, OP>(f);
+  constexpr int NE = EPL * CPW;
+  const Unit<T, EPL> U = make_unit<T, EPL, COPY, CPW>(L, CD, perm, q, wid - q * n_chunks, H, lp_log2, lane);
+  Fold<A, NE> f;
+  fold_init<A, NE, OP>(f);
 
   if (SPLIT && U.len > W.split) {
     // long sequence: this wave takes part 0 and publishes the rest
@@ -415,19 +433,19 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
       int64_t* e = W.items + (ibase + p - 1) * 4;
       e[0] = q; e[1] = U.chunk; e[2] = p; e[3] = pbase + p;
     }
-    fold_rows<T, EPL, OP, NT, COPY>(U, 0, W.split, data, H, f, CD, copy, lane);
-    fold_wave<A, EPL, OP>(f, lp_log2);
-    store_partial<A, EPL>(W.partials, pbase, lane, f);
+    fold_rows<T, EPL, OP, NT, COPY, CPW>(U, 0, W.split, data, H, f, CD, copy, lane);
+    fold_wave<A, NE, OP>(f, lp_log2);
+    store_partial<A, NE>(W.partials, pbase, lane, f);
   } else {
-    fold_rows<T, EPL, OP, NT, COPY>(U, 0, U.len, data, H, f, CD, copy, lane);
-    fold_wave<A, EPL, OP>(f, lp_log2);
-    fold_store<T, EPL, OP>(U, f, out, H, include_self, empty_val);
+    fold_rows<T, EPL, OP, NT, COPY, CPW>(U, 0, U.len, data, H, f, CD, copy, lane);
+    fold_wave<A, NE, OP>(f, lp_log2);
+    fold_store<T, EPL, OP, CPW>(U, f, out, H, include_self, empty_val);
   }
-  fold_extreme<A, EPL, OP>(f, extreme, wid, lane, U.len > 0);
+  fold_extreme<A, NE, OP>(f, extreme, wid, lane, U.len > 0);
 }
 
 // the published parts 1.. of long sequences
-template <typename T, int EPL, int OP, bool NT, bool COPY>
+template <typename T, int EPL, int OP, bool NT, bool COPY, int CPW>
 __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_tail_kernel(rua_layout L, const int64_t* __restrict__ perm,
                                                                    const T* __restrict__ data, int64_t H,
                                                                    int lp_log2,
@@ -438,30 +456,33 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_tail_kernel(rua_layout L,
   const int64_t i = blockIdx.x;
   if ((unsigned long long)i >= W.ctr[0]) return;
   const int64_t* e = W.items + i * 4;
-  const Unit<T, EPL> U = make_unit<T, EPL, COPY>(L, CD, perm, e[0], e[1], H, lp_log2, lane);
+  constexpr int NE = EPL * CPW;
+  const Unit<T, EPL> U = make_unit<T, EPL, COPY, CPW>(L, CD, perm, e[0], e[1], H, lp_log2, lane);
   const int64_t t_lo = e[2] * W.split;
   const int64_t t_hi = (t_lo + W.split < U.len) ? t_lo + W.split : U.len;
-  Fold<A, EPL> f;
-  fold_init<A, EPL, OP>(f);
-  fold_rows<T, EPL, OP, NT, COPY>(U, t_lo, t_hi, data, H, f, CD, copy, lane);
-  fold_wave<A, EPL, OP>(f, lp_log2);
-  store_partial<A, EPL>(W.partials, e[3], lane, f);
-  fold_extreme<A, EPL, OP>(f, extreme, i, lane, true);
+  Fold<A, NE> f;
+  fold_init<A, NE, OP>(f);
+  fold_rows<T, EPL, OP, NT, COPY, CPW>(U, t_lo, t_hi, data, H, f, CD, copy, lane);
+  fold_wave<A, NE, OP>(f, lp_log2);
+  store_partial<A, NE>(W.partials, e[3], lane, f);
+  fold_extreme<A, NE, OP>(f, extreme, i, lane, true);
 }
 
 // fold the partials of every long unit and finalise.  A 16-wave workgroup per unit: wave w folds the
 // contiguous range of parts [w*per, (w+1)*per) in order (4 partials in flight), then wave 0 folds the 16
 // range results in wave order — a fixed association that depends only on the part count, so the result is
 // bitwise reproducible.
-constexpr int COMBINE_WAVES = 16;
+constexpr int COMBINE_WAVES_MAX = 16;
 
-template <typename T, int EPL, int OP>
-__global__ __launch_bounds__(RUA_WAVE * COMBINE_WAVES) void seg_reduce_combine_kernel(
+template <typename T, int EPL, int OP, int CPW>
+__global__ __launch_bounds__(RUA_WAVE * (COMBINE_WAVES_MAX / CPW)) void seg_reduce_combine_kernel(
     rua_layout L, const int64_t* __restrict__ perm, T* __restrict__ out, int64_t H, int lp_log2, int include_self,
     T empty_val, rua_layout CD, int copy_mode, SplitWs W) {
   using A = typename elem<T>::acc;
-  __shared__ A s_acc[COMBINE_WAVES][RUA_WAVE * EPL];
-  __shared__ A s_aux[COMBINE_WAVES][RUA_WAVE * EPL];
+  constexpr int NE = EPL * CPW;
+  constexpr int COMBINE_WAVES = COMBINE_WAVES_MAX / CPW;   // LDS: 2 * waves * 64 * NE accumulators
+  __shared__ A s_acc[COMBINE_WAVES][RUA_WAVE * NE];
+  __shared__ A s_aux[COMBINE_WAVES][RUA_WAVE * NE];
   const int lane = threadIdx.x & (RUA_WAVE - 1), wave = threadIdx.x >> 6;
   const int64_t j = blockIdx.x;
   if ((unsigned long long)j >= W.ctr[1]) return;   // block-uniform
@@ -469,37 +490,37 @@ __global__ __launch_bounds__(RUA_WAVE * COMBINE_WAVES) void seg_reduce_combine_k
   const int64_t nparts = e[2], pbase = e[3];
   const int64_t per = (nparts + COMBINE_WAVES - 1) / COMBINE_WAVES;
   const int64_t p_lo = wave * per, p_hi = (p_lo + per < nparts) ? p_lo + per : nparts;
-  Fold<A, EPL> f;
-  fold_init<A, EPL, OP>(f);
+  Fold<A, NE> f;
+  fold_init<A, NE, OP>(f);
   const A* P = reinterpret_cast<const A*>(W.partials);
   constexpr int PF = 4;
   for (int64_t p = p_lo; p < p_hi; p += PF) {
-    A a2[PF][EPL], x2[PF][EPL];
+    A a2[PF][NE], x2[PF][NE];
 #pragma unroll
     for (int u = 0; u < PF; ++u)
       if (p + u < p_hi) {
-        const A* pp = P + ((pbase + p + u) * 2 * RUA_WAVE + lane) * EPL;
+        const A* pp = P + ((pbase + p + u) * 2 * RUA_WAVE + lane) * NE;
 #pragma unroll
-        for (int k = 0; k < EPL; ++k) { a2[u][k] = pp[k]; x2[u][k] = pp[RUA_WAVE * EPL + k]; }
+        for (int k = 0; k < NE; ++k) { a2[u][k] = pp[k]; x2[u][k] = pp[RUA_WAVE * NE + k]; }
       }
 #pragma unroll
     for (int u = 0; u < PF; ++u)
-      if (p + u < p_hi) fold_merge<A, EPL, OP>(f, a2[u], x2[u]);
+      if (p + u < p_hi) fold_merge<A, NE, OP>(f, a2[u], x2[u]);
   }
 #pragma unroll
-  for (int k = 0; k < EPL; ++k) { s_acc[wave][lane * EPL + k] = f.acc[k]; s_aux[wave][lane * EPL + k] = f.aux[k]; }
+  for (int k = 0; k < NE; ++k) { s_acc[wave][lane * NE + k] = f.acc[k]; s_aux[wave][lane * NE + k] = f.aux[k]; }
   __syncthreads();
   if (wave != 0) return;
   for (int w = 1; w < COMBINE_WAVES; ++w) {
     if (w * per >= nparts) break;     // ranges beyond the last part are empty
-    A a2[EPL], x2[EPL];
+    A a2[NE], x2[NE];
 #pragma unroll
-    for (int k = 0; k < EPL; ++k) { a2[k] = s_acc[w][lane * EPL + k]; x2[k] = s_aux[w][lane * EPL + k]; }
-    fold_merge<A, EPL, OP>(f, a2, x2);
+    for (int k = 0; k < NE; ++k) { a2[k] = s_acc[w][lane * NE + k]; x2[k] = s_aux[w][lane * NE + k]; }
+    fold_merge<A, NE, OP>(f, a2, x2);
   }
-  const Unit<T, EPL> U = copy_mode ? make_unit<T, EPL, true>(L, CD, perm, e[0], e[1], H, lp_log2, lane)
-                                   : make_unit<T, EPL, false>(L, CD, perm, e[0], e[1], H, lp_log2, lane);
-  fold_store<T, EPL, OP>(U, f, out, H, include_self, empty_val);
+  const Unit<T, EPL> U = copy_mode ? make_unit<T, EPL, true, CPW>(L, CD, perm, e[0], e[1], H, lp_log2, lane)
+                                   : make_unit<T, EPL, false, CPW>(L, CD, perm, e[0], e[1], H, lp_log2, lane);
+  fold_store<T, EPL, OP, CPW>(U, f, out, H, include_self, empty_val);
 }
 
 // ---------------------------------------------------------------- backward of the reductions
@@ -648,7 +669,7 @@ static SplitWs carve_ws(void* ws, int64_t max_u, int64_t split) {
   return W;
 }
 
-template <typename T, int EPL, bool NT, bool COPY>
+template <typename T, int EPL, bool NT, bool COPY, int CPW>
 static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout& L, const int64_t* perm,
                          const void* data, void* out, int64_t H, int lp_log2, int64_t n_chunks, int include_self,
                          uint64_t empty_bits, void* extreme, const rua_layout& CD, void* copy, int64_t split,
@@ -669,15 +690,15 @@ static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout&
   unsigned long long* ext = (unsigned long long*)extreme;
 #define RUA_LAUNCH(OP)                                                                                              \
   if (do_split) {                                                                                                   \
-    hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY, true>), g, b, 0, s, L, perm, (const T*)data,        \
+    hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY, true, CPW>), g, b, 0, s, L, perm, (const T*)data,   \
                        (T*)out, H, lp_log2, n_chunks, include_self, ev, ext, CD, (T*)copy, W);                      \
-    hipLaunchKernelGGL((seg_reduce_tail_kernel<T, EPL, OP, NT, COPY>), dim3((unsigned)max_u), b, 0, s, L, perm,     \
+    hipLaunchKernelGGL((seg_reduce_tail_kernel<T, EPL, OP, NT, COPY, CPW>), dim3((unsigned)max_u), b, 0, s, L, perm, \
                        (const T*)data, H, lp_log2, ext, CD, (T*)copy, W);                                           \
-    hipLaunchKernelGGL((seg_reduce_combine_kernel<T, EPL, OP>), dim3((unsigned)max_u),                             \
-                       dim3(RUA_WAVE * COMBINE_WAVES), 0, s, L, perm, (T*)out,                                      \
+    hipLaunchKernelGGL((seg_reduce_combine_kernel<T, EPL, OP, CPW>), dim3((unsigned)max_u),                        \
+                       dim3(RUA_WAVE * (COMBINE_WAVES_MAX / CPW)), 0, s, L, perm, (T*)out,                          \
                        H, lp_log2, include_self, ev, CD, COPY ? 1 : 0, W);                                          \
   } else {                                                                                                          \
-    hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY, false>), g, b, 0, s, L, perm, (const T*)data,       \
+    hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY, false, CPW>), g, b, 0, s, L, perm, (const T*)data,  \
                        (T*)out, H, lp_log2, n_chunks, include_self, ev, ext, CD, (T*)copy, W);                      \
   }
   switch (op) {
@@ -703,27 +724,28 @@ static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int
   const int64_t lpr = (H + epl - 1) / epl;  // lanes per row
   int lp_log2 = 0;
   while ((1 << lp_log2) < lpr && lp_log2 < 6) ++lp_log2;
-  const int64_t n_chunks = (lpr + RUA_WAVE - 1) / RUA_WAVE;
+  // rows wider than one wave instruction (1 KiB): one wave owns 4 column chunks, i.e. up to 4 KiB of the row
+  const bool wide = vec_ok && lpr > RUA_WAVE;
+  const int cpw = wide ? 4 : 1;
+  const int64_t n_chunks = (lpr + RUA_WAVE * cpw - 1) / (RUA_WAVE * cpw);
   const int64_t blocks = L.B * n_chunks;  // one wave per workgroup
   if (blocks > 0x7fffffffLL) return RUA_ERANGE;
   const bool nt = (double)L.n_rows * (double)H * sizeof(T) >= (double)(512ll << 20);
   const unsigned g = (unsigned)blocks;
   static const rua_layout none = {};
-  if (copy) {   // fused pack + reduce: vector path only (the caller falls back to two launches otherwise)
-    if (!vec_ok) return RUA_EALIGN;
-    return nt ? launch_reduce<T, FULL, true, true>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
-                                                   empty_bits, extreme, *CD, copy, split, ws)
-              : launch_reduce<T, FULL, false, true>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
-                                                    empty_bits, extreme, *CD, copy, split, ws);
+  const rua_layout& cd = copy ? *CD : none;
+  if (copy && !vec_ok) return RUA_EALIGN;   // fused pack + reduce: vector path only (caller falls back to two launches)
+#define RUA_GO(EPLV, NTV, COPYV, CPWV)                                                                             \
+  return launch_reduce<T, EPLV, NTV, COPYV, CPWV>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self, \
+                                                  empty_bits, extreme, cd, copy, split, ws)
+  if (copy) {
+    if (wide) { if (nt) RUA_GO(FULL, true, true, 4); else RUA_GO(FULL, false, true, 4); }
+    if (nt) RUA_GO(FULL, true, true, 1); else RUA_GO(FULL, false, true, 1);
   }
-  if (vec_ok && nt)
-    return launch_reduce<T, FULL, true, false>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
-                                               empty_bits, extreme, none, nullptr, split, ws);
-  if (vec_ok)
-    return launch_reduce<T, FULL, false, false>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
-                                                empty_bits, extreme, none, nullptr, split, ws);
-  return launch_reduce<T, 1, false, false>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self,
-                                           empty_bits, extreme, none, nullptr, split, ws);
+  if (wide) { if (nt) RUA_GO(FULL, true, false, 4); else RUA_GO(FULL, false, false, 4); }
+  if (vec_ok) { if (nt) RUA_GO(FULL, true, false, 1); else RUA_GO(FULL, false, false, 1); }
+  RUA_GO(1, false, false, 1);
+#undef RUA_GO
 }
 
 
