@@ -2,8 +2,7 @@
 
 Backward of a move is the adjoint move (layouts swapped, token map inverted, zero fill for rows
 nothing maps to) — the same kernel.  Backward of a segmented reduce is one fused kernel
-(rua_segment_reduce_backward); scatter_* backward is still composed from
-gathers + elementwise torch ops on the result.
+(rua_segment_reduce_backward), which also serves scatter_* through the bucket indirection.
 """
 from typing import Callable, Optional, Sequence, Tuple
 
@@ -177,7 +176,7 @@ class _Reduce(torch.autograd.Function):
         for d in out.shape[1:]:
             H *= d
         L.check(lib.rua_segment_reduce_backward(lay.ref(), None, L.ptr(data), L.ptr(out), L.ptr(grad), L.ptr(g), H,
-                                                L.DTYPES[data.dtype], op, L.stream_ptr(dev)),
+                                                L.DTYPES[data.dtype], op, 0, L.stream_ptr(dev)),
                 'rua_segment_reduce_backward')
         return g, None, None, None, None
 

@@ -537,7 +537,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_kernel(rua_layout L, co
                                                                 const T* __restrict__ data,
                                                                 const T* __restrict__ out,
                                                                 const T* __restrict__ gout, T* __restrict__ gin,
-                                                                int64_t H, int lp_log2, int64_t n_chunks) {
+                                                                int64_t H, int lp_log2, int64_t n_chunks, int extra_count) {
   using A = typename elem<T>::acc;
   struct alignas(sizeof(T) * EPL) Pack { T v[EPL]; };
   const int lane = threadIdx.x;
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_kernel(rua_layout L, co
   }
   if (OP == RUA_MEAN) {
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) g[e] = g[e] / (A)len;
+    for (int e = 0; e < EPL; ++e) g[e] = g[e] / (A)(len + extra_count);   // +1: the old row took part (scatter_mean, include_self)
   }
 
   for (int pass = (OP == RUA_MAX || OP == RUA_MIN) ? 0 : 1; pass < 2; ++pass) {
@@ -752,11 +752,11 @@ static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int
 template <typename T, int EPL>
 static int launch_backward(int op, unsigned grid, hipStream_t s, const rua_layout& L, const int64_t* perm,
                            const void* data, const void* out, const void* gout, void* gin, int64_t H, int lp_log2,
-                           int64_t n_chunks) {
+                           int64_t n_chunks, int extra_count) {
   const dim3 g(grid), b(RUA_WAVE);
 #define RUA_LAUNCH(OP)                                                                                            \
   hipLaunchKernelGGL((seg_backward_kernel<T, EPL, OP>), g, b, 0, s, L, perm, (const T*)data, (const T*)out,       \
-                     (const T*)gout, (T*)gin, H, lp_log2, n_chunks)
+                     (const T*)gout, (T*)gin, H, lp_log2, n_chunks, extra_count)
   switch (op) {
     case RUA_SUM: RUA_LAUNCH(RUA_SUM); break;
     case RUA_MEAN: RUA_LAUNCH(RUA_MEAN); break;
@@ -772,7 +772,7 @@ static int launch_backward(int op, unsigned grid, hipStream_t s, const rua_layou
 
 template <typename T>
 static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,
-                             const void* out, const void* gout, void* gin, int64_t H) {
+                             const void* out, const void* gout, void* gin, int64_t H, int extra_count) {
   constexpr int FULL = 16 / sizeof(T);
   const uintptr_t ptrs = (uintptr_t)data | (uintptr_t)out | (uintptr_t)gout | (uintptr_t)gin;
   const bool vec_ok = (H % FULL == 0) && (ptrs % 16 == 0);
@@ -783,8 +783,10 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
   const int64_t n_chunks = (lpr + RUA_WAVE - 1) / RUA_WAVE;
   const int64_t blocks = L.B * n_chunks;
   if (blocks > 0x7fffffffLL) return RUA_ERANGE;
-  if (vec_ok) return launch_backward<T, FULL>(op, (unsigned)blocks, s, L, perm, data, out, gout, gin, H, lp_log2, n_chunks);
-  return launch_backward<T, 1>(op, (unsigned)blocks, s, L, perm, data, out, gout, gin, H, lp_log2, n_chunks);
+  if (vec_ok)
+    return launch_backward<T, FULL>(op, (unsigned)blocks, s, L, perm, data, out, gout, gin, H, lp_log2, n_chunks,
+                                    extra_count);
+  return launch_backward<T, 1>(op, (unsigned)blocks, s, L, perm, data, out, gout, gin, H, lp_log2, n_chunks, extra_count);
 }
 
 
@@ -795,7 +797,7 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
                     int64_t H, int include_self, uint64_t empty_bits, void* extreme, int64_t split, void* ws,     \
                     const rua_layout* CD, void* copy);                                                             \
   int backward_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,           \
-                      const void* out, const void* gout, void* gin, int64_t H);                                    \
+                      const void* out, const void* gout, void* gin, int64_t H, int extra_count);                   \
   int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, const void* ext);
 RUA_DECLARE_REDUCE_DTYPE(f32)
 RUA_DECLARE_REDUCE_DTYPE(bf16)
@@ -811,8 +813,8 @@ RUA_DECLARE_REDUCE_DTYPE(f64)
                               copy);                                                                               \
   }                                                                                                                 \
   int backward_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,           \
-                      const void* out, const void* gout, void* gin, int64_t H) {                                   \
-    return dispatch_backward<T>(op, s, L, perm, data, out, gout, gin, H);                                          \
+                      const void* out, const void* gout, void* gin, int64_t H, int extra_count) {                  \
+    return dispatch_backward<T>(op, s, L, perm, data, out, gout, gin, H, extra_count);                             \
   }                                                                                                                 \
   int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, const void* ext) { \
     hipLaunchKernelGGL(fill_empty_kernel<T>, dim3(grid_for(L.B)), dim3(RUA_BLOCK), 0, s, L, (T*)out, H, want_max,  \

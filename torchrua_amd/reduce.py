@@ -143,31 +143,45 @@ class _Scatter(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad: T):
+        """Gradient w.r.t. the source rows: ONE fused kernel walking every destination's bucket
+        (rua_segment_reduce_backward with the row indirection), except max/min with include_self, whose ties
+        involve the old destination row too.  The [S, H]-sized gradient w.r.t. `tensor` is elementwise torch."""
         tensor, index, source, out, counts = ctx.saved_tensors
         op, inc = ctx.op, ctx.include_self
         grad = grad.contiguous()
-        g_src = g_ten = None
         view = (-1,) + (1,) * (grad.dim() - 1)
         touched = (counts > 0).view(view)
+        untouched_pass = torch.where(touched, torch.zeros_like(grad), grad)     # rows no index names keep `tensor`
+        g_src = g_ten = None
+        fused = not (inc and op in (K.MAX, K.MIN))
+        if fused:
+            dev = K.require_device(source)
+            H = 1
+            for d in out.shape[1:]:
+                H *= d
+            g_src = torch.empty_like(source)       # every source row belongs to exactly one bucket
+            K.check(K.load().rua_segment_reduce_backward(ctx.lay.ref(), K.ptr(ctx.perm), K.ptr(source.contiguous()),
+                                                         K.ptr(out), K.ptr(grad), K.ptr(g_src), H, K.DTYPES[source.dtype],
+                                                         op, 1 if inc else 0, K.stream_ptr(dev)),
+                    'rua_segment_reduce_backward')
         if op == K.SUM:
-            g_src = grad[index]
             g_ten = grad if inc else None
         elif op == K.MEAN:
             n = (counts + (1 if inc else 0)).clamp_min(1).to(grad.dtype).view(view)
-            g_src = (grad / n)[index]
-            g_ten = grad / n if inc else torch.where(touched, torch.zeros_like(grad), grad)
+            g_ten = grad / n if inc else untouched_pass
         elif op in (K.MAX, K.MIN):
-            hit_s = (source == out[index]).to(grad.dtype)
-            hit_t = (tensor == out).to(grad.dtype) if inc else torch.zeros_like(grad)
-            ties = torch.zeros_like(grad).index_add_(0, index, hit_s) + hit_t
-            share = grad / ties.clamp_min(1)
-            g_src = share[index] * hit_s
-            g_ten = share * hit_t if inc else torch.where(touched, torch.zeros_like(grad), grad)
+            if inc:
+                hit_s = (source == out[index]).to(grad.dtype)
+                hit_t = (tensor == out).to(grad.dtype)
+                ties = torch.zeros_like(grad).index_add_(0, index, hit_s) + hit_t
+                share = grad / ties.clamp_min(1)
+                g_src = share[index] * hit_s
+                g_ten = share * hit_t
+            else:
+                g_ten = untouched_pass
         elif op == K.PROD:
-            g_src = (grad * out)[index] / source
-            g_ten = grad * out / tensor if inc else torch.where(touched, torch.zeros_like(grad), grad)
+            g_ten = grad * out / tensor if inc else untouched_pass
         else:  # LOGSUMEXP
-            g_src = grad[index] * (source - out[index]).exp()
             g_ten = grad * (tensor - out).exp() if inc else None
         return g_ten, None, g_src, None, None
 
