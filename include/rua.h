@@ -166,10 +166,11 @@ int rua_pack_reduce(const rua_layout* src, const rua_layout* pack, const void* d
  *   SUM g | MEAN g/len | PROD g*out/x | LOGSUMEXP g*exp(x-out) | MAX/MIN g/ties where x == out, else 0.
  * grad_in has the storage of `data`; rows of padded layouts that hold no token are NOT written.
  * With `perm` it is the gradient w.r.t. the SOURCE rows of scatter_* (reduce.py:6-31); include_self != 0 then
- * counts the old destination row in MEAN's divisor (MAX/MIN ties with the old row are the caller's business). */
+ * counts the old destination row in MEAN's divisor (MAX/MIN ties with the old row are the caller's business).
+ * split_rows / ws as in rua_segment_reduce (MAX/MIN keep whole sequences: their tie count spans the sequence). */
 int rua_segment_reduce_backward(const rua_layout* lay, const int64_t* perm, const void* data, const void* out,
                                 const void* grad_out, void* grad_in, int64_t H, int32_t dtype, int32_t op,
-                                int32_t include_self, void* stream);
+                                int32_t include_self, int64_t split_rows, void* ws, void* stream);
 
 /* Patch rows of empty sequences with *extreme after rua_segment_reduce (MAX/MIN), and poison
  * every row with NaN when *extreme is NaN (the reference's initial=NaN behaviour). */

@@ -224,10 +224,24 @@ def test_long_sequences_are_split(hidden, dtype):
             rtol = 1e-3 if name == 'prod' else 2e-5
             np.testing.assert_allclose(got.double().cpu().numpy(), ref.astype(np.float64), rtol=rtol + ulp,
                                        atol=1e-5 * scale + ulp, err_msg=f'{what} {name}')
-    # gradients through a split sequence
-    x = data.to(DEV).float().requires_grad_(True)
-    ta.segment_sum(x, known.token_sizes).sum().backward()
-    assert torch.equal(x.grad, torch.ones_like(x))
+    # gradients through split sequences (the backward publishes parts too; max keeps whole sequences)
+    xf = torch.randn(sum(lens), hidden, generator=g) * 0.1     # fresh fp32 values: no ties for max
+    for name, fn in (('sum', lambda t: t.sum(0)), ('mean', lambda t: t.mean(0)), ('logsumexp', lambda t: t.logsumexp(0)),
+                     ('max', lambda t: t.max(0).values)):
+        x = xf.clone().to(DEV).requires_grad_(True)
+        out = getattr(ta, f'segment_{name}')(x, known.token_sizes)
+        cot = torch.randn(out.shape, generator=g).to(DEV)
+        out.backward(cot)
+        r = xf.clone().to(DEV).requires_grad_(True)
+        torch.stack([fn(s_) for s_ in torch.split(r, lens)]).backward(cot)
+        torch.testing.assert_close(x.grad, r.grad, rtol=1e-4, atol=1e-6, msg=f'backward {name}')
+    # scatter with one huge destination: forward and backward both go through the split path
+    idx = torch.repeat_interleave(torch.arange(len(lens)), lt)
+    perm = torch.randperm(idx.numel(), generator=g)
+    src = xf[perm].clone().to(DEV).requires_grad_(True)
+    ten = torch.zeros(len(lens), hidden, device=DEV)
+    ta.scatter_sum(ten, idx[perm].to(DEV), src).sum().backward()
+    assert torch.equal(src.grad, torch.ones_like(src))
 
 
 def test_scatter_huge_fan_in_is_fast_and_right():

@@ -175,8 +175,9 @@ class _Reduce(torch.autograd.Function):
         H = 1
         for d in out.shape[1:]:
             H *= d
+        split, ws = split_workspace(lay, H, data.dtype, dev)
         L.check(lib.rua_segment_reduce_backward(lay.ref(), None, L.ptr(data), L.ptr(out), L.ptr(grad), L.ptr(g), H,
-                                                L.DTYPES[data.dtype], op, 0, L.stream_ptr(dev)),
+                                                L.DTYPES[data.dtype], op, 0, split, L.ptr(ws), L.stream_ptr(dev)),
                 'rua_segment_reduce_backward')
         return g, None, None, None, None
 

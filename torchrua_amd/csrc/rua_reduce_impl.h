@@ -532,24 +532,18 @@ __global__ __launch_bounds__(RUA_WAVE * (COMBINE_WAVES_MAX / CPW)) void seg_redu
 //   zero-fills padded grads).
 constexpr int UNROLL_B = 4;
 
+// rows [t_lo, t_hi) of one unit (MAX/MIN need the whole sequence: ties are counted in a first walk)
 template <typename T, int EPL, int OP>
-__global__ __launch_bounds__(RUA_WAVE) void seg_backward_kernel(rua_layout L, const int64_t* __restrict__ perm,
-                                                                const T* __restrict__ data,
-                                                                const T* __restrict__ out,
-                                                                const T* __restrict__ gout, T* __restrict__ gin,
-                                                                int64_t H, int lp_log2, int64_t n_chunks, int extra_count) {
+__device__ __forceinline__ void backward_unit(const Unit<T, EPL>& U, int64_t t_lo, int64_t t_hi,
+                                              const T* __restrict__ data, const T* __restrict__ out,
+                                              const T* __restrict__ gout, T* __restrict__ gin, int64_t H,
+                                              int extra_count, int lane) {
   using A = typename elem<T>::acc;
   struct alignas(sizeof(T) * EPL) Pack { T v[EPL]; };
-  const int lane = threadIdx.x;
-  const int64_t wid = blockIdx.x;
-  const int64_t q = wid / n_chunks;
-  if (q >= L.B) return;
-  const Unit<T, EPL> U = make_unit<T, EPL, false>(L, L, perm, q, wid - q * n_chunks, H, lp_log2, lane);
   const int64_t b = U.b, col = U.col, len = U.len, base = U.base, tb = U.tb;
   const int64_t* __restrict__ tbl = U.tbl;
-  const int rpw = U.rpw, rsub = U.rsub;
+  const int rpw = U.rpw, rsub = U.rsub, lp_log2 = U.lp_log2;
   const bool colok = U.colok;
-  if (len <= 0) return;
 
   A o[EPL], g[EPL];
 #pragma unroll
@@ -569,11 +563,11 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_kernel(rua_layout L, co
     A cnt[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) cnt[e] = (A)0;
-    int64_t tv = (tbl && lane < len) ? tbl[tb + lane] : 0;
-    for (int64_t tblk = 0; tblk < len; tblk += RUA_WAVE) {
+    int64_t tv = (tbl && t_lo + lane < t_hi) ? tbl[tb + t_lo + lane] : 0;
+    for (int64_t tblk = t_lo; tblk < t_hi; tblk += RUA_WAVE) {
       const int64_t nxt = tblk + RUA_WAVE + lane;
-      const int64_t tv_next = (tbl && nxt < len) ? tbl[tb + nxt] : 0;
-      const int nblk = (len - tblk) < RUA_WAVE ? (int)(len - tblk) : RUA_WAVE;
+      const int64_t tv_next = (tbl && nxt < t_hi) ? tbl[tb + nxt] : 0;
+      const int nblk = (t_hi - tblk) < RUA_WAVE ? (int)(t_hi - tblk) : RUA_WAVE;
       for (int k = 0; k < nblk; k += rpw * UNROLL_B) {
         int64_t row[UNROLL_B];
         Pack p[UNROLL_B];
@@ -619,8 +613,55 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_kernel(rua_layout L, co
       }
 #pragma unroll
       for (int e = 0; e < EPL; ++e) g[e] = g[e] / (cnt[e] > (A)0 ? cnt[e] : (A)1);
-    } 
+    }
   }
+}
+
+// SPLIT: long sequences are cut into parts like in the forward (the parts of a gradient are independent, so
+// there is nothing to combine); MAX/MIN keep whole sequences because the tie count spans the sequence.
+template <typename T, int EPL, int OP, bool SPLIT>
+__global__ __launch_bounds__(RUA_WAVE) void seg_backward_kernel(rua_layout L, const int64_t* __restrict__ perm,
+                                                                const T* __restrict__ data,
+                                                                const T* __restrict__ out,
+                                                                const T* __restrict__ gout, T* __restrict__ gin,
+                                                                int64_t H, int lp_log2, int64_t n_chunks,
+                                                                int extra_count, SplitWs W) {
+  const int lane = threadIdx.x;
+  const int64_t wid = blockIdx.x;
+  const int64_t q = wid / n_chunks;
+  if (q >= L.B) return;
+  const Unit<T, EPL> U = make_unit<T, EPL, false>(L, L, perm, q, wid - q * n_chunks, H, lp_log2, lane);
+  if (U.len <= 0) return;
+  int64_t t_hi = U.len;
+  if (SPLIT && OP != RUA_MAX && OP != RUA_MIN && U.len > W.split) {
+    const int64_t nparts = (U.len + W.split - 1) / W.split;
+    int64_t ibase = 0;
+    if (lane == 0) ibase = (int64_t)atomicAdd(&W.ctr[0], (unsigned long long)(nparts - 1));
+    ibase = __shfl(ibase, 0, RUA_WAVE);
+    for (int64_t p = 1 + lane; p < nparts; p += RUA_WAVE) {
+      int64_t* e = W.items + (ibase + p - 1) * 4;
+      e[0] = q; e[1] = U.chunk; e[2] = p; e[3] = 0;
+    }
+    t_hi = W.split;
+  }
+  backward_unit<T, EPL, OP>(U, 0, t_hi, data, out, gout, gin, H, extra_count, lane);
+}
+
+template <typename T, int EPL, int OP>
+__global__ __launch_bounds__(RUA_WAVE) void seg_backward_tail_kernel(rua_layout L, const int64_t* __restrict__ perm,
+                                                                     const T* __restrict__ data,
+                                                                     const T* __restrict__ out,
+                                                                     const T* __restrict__ gout,
+                                                                     T* __restrict__ gin, int64_t H, int lp_log2,
+                                                                     int extra_count, SplitWs W) {
+  const int lane = threadIdx.x;
+  const int64_t i = blockIdx.x;
+  if ((unsigned long long)i >= W.ctr[0]) return;
+  const int64_t* e = W.items + i * 4;
+  const Unit<T, EPL> U = make_unit<T, EPL, false>(L, L, perm, e[0], e[1], H, lp_log2, lane);
+  const int64_t t_lo = e[2] * W.split;
+  const int64_t t_hi = (t_lo + W.split < U.len) ? t_lo + W.split : U.len;
+  backward_unit<T, EPL, OP>(U, t_lo, t_hi, data, out, gout, gin, H, extra_count, lane);
 }
 
 // extreme scratch: [0..63] hashed ordered-bit slots, [64] NaN flag (initialised by rua_reduce.hip)
@@ -752,11 +793,28 @@ static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int
 template <typename T, int EPL>
 static int launch_backward(int op, unsigned grid, hipStream_t s, const rua_layout& L, const int64_t* perm,
                            const void* data, const void* out, const void* gout, void* gin, int64_t H, int lp_log2,
-                           int64_t n_chunks, int extra_count) {
+                           int64_t n_chunks, int extra_count, int64_t split, void* ws) {
+  using A = typename elem<T>::acc;
   const dim3 g(grid), b(RUA_WAVE);
+  const int64_t max_u = split_max_extra(L.n_rows, split) * n_chunks;
+  const bool do_split = split > 0 && ws && max_u > 0 && op != RUA_MAX && op != RUA_MIN;
+  SplitWs W = {};
+  if (do_split) {
+    if (max_u > 0x7fffffffLL) return RUA_ERANGE;
+    W = carve_ws<A>(ws, max_u, split);
+    hipError_t e = hipMemsetAsync(W.ctr, 0, 4 * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return (int)e;
+  }
 #define RUA_LAUNCH(OP)                                                                                            \
-  hipLaunchKernelGGL((seg_backward_kernel<T, EPL, OP>), g, b, 0, s, L, perm, (const T*)data, (const T*)out,       \
-                     (const T*)gout, (T*)gin, H, lp_log2, n_chunks, extra_count)
+  if (do_split) {                                                                                                 \
+    hipLaunchKernelGGL((seg_backward_kernel<T, EPL, OP, true>), g, b, 0, s, L, perm, (const T*)data,              \
+                       (const T*)out, (const T*)gout, (T*)gin, H, lp_log2, n_chunks, extra_count, W);            \
+    hipLaunchKernelGGL((seg_backward_tail_kernel<T, EPL, OP>), dim3((unsigned)max_u), b, 0, s, L, perm,           \
+                       (const T*)data, (const T*)out, (const T*)gout, (T*)gin, H, lp_log2, extra_count, W);      \
+  } else {                                                                                                        \
+    hipLaunchKernelGGL((seg_backward_kernel<T, EPL, OP, false>), g, b, 0, s, L, perm, (const T*)data,             \
+                       (const T*)out, (const T*)gout, (T*)gin, H, lp_log2, n_chunks, extra_count, W);            \
+  }
   switch (op) {
     case RUA_SUM: RUA_LAUNCH(RUA_SUM); break;
     case RUA_MEAN: RUA_LAUNCH(RUA_MEAN); break;
@@ -772,7 +830,8 @@ static int launch_backward(int op, unsigned grid, hipStream_t s, const rua_layou
 
 template <typename T>
 static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,
-                             const void* out, const void* gout, void* gin, int64_t H, int extra_count) {
+                             const void* out, const void* gout, void* gin, int64_t H, int extra_count,
+                             int64_t split, void* ws) {
   constexpr int FULL = 16 / sizeof(T);
   const uintptr_t ptrs = (uintptr_t)data | (uintptr_t)out | (uintptr_t)gout | (uintptr_t)gin;
   const bool vec_ok = (H % FULL == 0) && (ptrs % 16 == 0);
@@ -785,10 +844,10 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
   if (blocks > 0x7fffffffLL) return RUA_ERANGE;
   if (vec_ok)
     return launch_backward<T, FULL>(op, (unsigned)blocks, s, L, perm, data, out, gout, gin, H, lp_log2, n_chunks,
-                                    extra_count);
-  return launch_backward<T, 1>(op, (unsigned)blocks, s, L, perm, data, out, gout, gin, H, lp_log2, n_chunks, extra_count);
+                                    extra_count, split, ws);
+  return launch_backward<T, 1>(op, (unsigned)blocks, s, L, perm, data, out, gout, gin, H, lp_log2, n_chunks, extra_count,
+                               split, ws);
 }
-
 
 // ---- per-dtype entry points: each element type is compiled in its own translation unit
 // (rua_reduce_<dtype>.hip) so the ~300 kernel instantiations build in parallel
@@ -797,7 +856,8 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
                     int64_t H, int include_self, uint64_t empty_bits, void* extreme, int64_t split, void* ws,     \
                     const rua_layout* CD, void* copy);                                                             \
   int backward_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,           \
-                      const void* out, const void* gout, void* gin, int64_t H, int extra_count);                   \
+                      const void* out, const void* gout, void* gin, int64_t H, int extra_count, int64_t split,    \
+                      void* ws);                                                                                   \
   int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, const void* ext);
 RUA_DECLARE_REDUCE_DTYPE(f32)
 RUA_DECLARE_REDUCE_DTYPE(bf16)
@@ -813,8 +873,9 @@ RUA_DECLARE_REDUCE_DTYPE(f64)
                               copy);                                                                               \
   }                                                                                                                 \
   int backward_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,           \
-                      const void* out, const void* gout, void* gin, int64_t H, int extra_count) {                  \
-    return dispatch_backward<T>(op, s, L, perm, data, out, gout, gin, H, extra_count);                             \
+                      const void* out, const void* gout, void* gin, int64_t H, int extra_count, int64_t split,    \
+                      void* ws) {                                                                                  \
+    return dispatch_backward<T>(op, s, L, perm, data, out, gout, gin, H, extra_count, split, ws);                  \
   }                                                                                                                 \
   int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, const void* ext) { \
     hipLaunchKernelGGL(fill_empty_kernel<T>, dim3(grid_for(L.B)), dim3(RUA_BLOCK), 0, s, L, (T*)out, H, want_max,  \

@@ -160,9 +160,10 @@ class _Scatter(torch.autograd.Function):
             for d in out.shape[1:]:
                 H *= d
             g_src = torch.empty_like(source)       # every source row belongs to exactly one bucket
+            split, ws = O.split_workspace(ctx.lay, H, source.dtype, dev)
             K.check(K.load().rua_segment_reduce_backward(ctx.lay.ref(), K.ptr(ctx.perm), K.ptr(source.contiguous()),
                                                          K.ptr(out), K.ptr(grad), K.ptr(g_src), H, K.DTYPES[source.dtype],
-                                                         op, 1 if inc else 0, K.stream_ptr(dev)),
+                                                         op, 1 if inc else 0, split, K.ptr(ws), K.stream_ptr(dev)),
                     'rua_segment_reduce_backward')
         if op == K.SUM:
             g_ten = grad if inc else None
