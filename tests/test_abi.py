@@ -33,8 +33,8 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_layout_struct_matches_header_size():
-    # 15 fields, all 8-byte aligned after the two int32s
-    assert ctypes.sizeof(_lib.RuaLayout) == 8 + 13 * 8
+    # 19 fields, all 8-byte aligned after the two int32s
+    assert ctypes.sizeof(_lib.RuaLayout) == 8 + 17 * 8
 
 
 def test_reference_surface_is_present():

@@ -33,6 +33,7 @@ class RuaLayout(Structure):
         ('lens', c_void_p), ('len_add', c_int64), ('off', c_void_p),
         ('boff', c_void_p), ('T', c_int64), ('sorted', c_void_p), ('unsorted', c_void_p),
         ('bptr', c_void_p), ('tptr', c_void_p),
+        ('bsz', c_void_p), ('tile_start', c_void_p), ('n_tchunks', c_int64), ('n_tiles', c_int64),
     ]
 
 

@@ -238,15 +238,50 @@ def lay_padded(kind: int, lens: Optional[Tensor], B: int, T_phys: int, T_log: in
     return Lay(keep, max_len=mx if lens is None or mx is None else mx + len_add, **f)
 
 
+TILE_R, TILE_T = 16, 16     # (rank x time) tile of the narrow-row pack kernel
+NARROW_ROW_BYTES = 128
+
+
+class PackTiling:
+    """Tile table for the narrow-row C/L/R <-> P kernel, derived on the host from batch_sizes (a CPU tensor by
+    PackedSequence's contract): tile_start[c] = number of 16-rank tiles before time chunk c."""
+    __slots__ = ('bsz', 'tile_start', 'n_tchunks', 'n_tiles')
+
+    def __init__(self, batch_sizes: Tensor, bsz_dev: Tensor, dev: torch.device):
+        with host_serial():
+            counts = (batch_sizes[::TILE_T] + (TILE_R - 1)) // TILE_R
+            start = torch.zeros(counts.numel() + 1, dtype=torch.long)
+            torch.cumsum(counts, 0, out=start[1:])
+        self.n_tchunks = int(counts.numel())
+        self.n_tiles = int(start[-1])
+        self.tile_start = to_device_async(start, dev)
+        self.bsz = bsz_dev
+
+
+def pack_tiling(p) -> 'PackTiling':
+    dev = p.data.device
+    key = f'tiling:{dev}'
+    hit = _memo_get(p.batch_sizes, key)
+    if hit is not None:
+        return hit
+    return _memo_put(p.batch_sizes, key, PackTiling(p.batch_sizes, pack_bsz_dev(p), dev))
+
+
 def lay_pack(p, lens: Optional[Tensor] = None, len_add: int = 0, boff: Optional[Tensor] = None,
-             T: Optional[int] = None, n_rows: Optional[int] = None) -> Lay:
+             T: Optional[int] = None, n_rows: Optional[int] = None, row_bytes: Optional[int] = None) -> Lay:
     lens = pack_lens(p) if lens is None else _as_lens(lens)
     boff = pack_boff(p) if boff is None else boff
     T = p.batch_sizes.numel() if T is None else T
     n_rows = int(p.data.size(0)) if n_rows is None else n_rows
-    return Lay([lens, boff, p.sorted_indices, p.unsorted_indices], max_len=T, kind=L.PACK, n_rows=n_rows, B=pack_B(p),
+    keep = [lens, boff, p.sorted_indices, p.unsorted_indices]
+    extra = {}
+    if row_bytes is not None and 0 < row_bytes <= NARROW_ROW_BYTES and T == p.batch_sizes.numel() and len_add == 0:
+        t = pack_tiling(p)       # narrow rows: hand the (rank x time) tile table to the mover
+        keep += [t.bsz, t.tile_start]
+        extra = dict(bsz=L.ptr(t.bsz), tile_start=L.ptr(t.tile_start), n_tchunks=t.n_tchunks, n_tiles=t.n_tiles)
+    return Lay(keep, max_len=T, kind=L.PACK, n_rows=n_rows, B=pack_B(p),
                lens=L.ptr(lens), len_add=len_add, boff=L.ptr(boff), T=T, sorted=L.ptr(p.sorted_indices),
-               unsorted=L.ptr(p.unsorted_indices))
+               unsorted=L.ptr(p.unsorted_indices), **extra)
 
 
 class _StagingRing:

@@ -151,7 +151,8 @@ def _to_pack(self: Union[C, L, R]) -> P:
     n = int(self.data.size(0)) if isinstance(self, C) else M.total_len(self.token_sizes)
     shell = P(data=self.data, batch_sizes=batch_sizes, sorted_indices=sorted_indices, unsorted_indices=unsorted)
     M.adopt_pack(shell, lens, boff, bsz_dev)
-    dst = M.lay_pack(shell, lens=lens, boff=boff, T=batch_sizes.numel(), n_rows=n)
+    dst = M.lay_pack(shell, lens=lens, boff=boff, T=batch_sizes.numel(), n_rows=n,
+                     row_bytes=M.row_bytes(self.data, 1 if isinstance(self, C) else 2))
     data = O.move(self.data, O.MovePlan(dst, describe(self), (n,) + _hidden(self), name='to_pack'))
     return shell._replace(data=data)
 
