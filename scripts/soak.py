@@ -1,0 +1,67 @@
+"""Randomized soak (developer tool; uses the CPU oracle as the checker like tests/ do): random batch shapes
+large enough to cross tile / scan / table-block boundaries, every cast, roll, rev, last, reductions, fused
+pack_reduce, against oracle/rua_oracle.  Usage: python scripts/soak.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import torchrua_amd as ta  # noqa: E402
+from gpu_util import DEV, assert_same_seq, dev_seq, host_sort  # noqa: E402
+from helpers import orc, to_np  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+rng = np.random.RandomState(seed)
+print('seed', seed)
+t_end = time.time() + budget
+n = 0
+while time.time() < t_end:
+    B = int(rng.choice([1, 2, 7, 63, 64, 65, 255, 257, 1000, 2049, 3000]))
+    hi = int(rng.choice([1, 2, 5, 17, 63, 64, 65, 130, 300, 700]))
+    lo = int(rng.randint(1, hi + 1))
+    H = int(rng.choice([1, 2, 3, 4, 8, 16, 24, 31, 32, 64, 96, 128, 136, 256, 520, 1024]))
+    dtype = [torch.float32, torch.bfloat16, torch.float16, torch.float64, torch.int64][int(rng.randint(0, 5))]
+    if B * hi * H > 6e7:
+        continue
+    lens = torch.from_numpy(rng.randint(lo, hi + 1, size=B).astype(np.int64))
+    g = torch.Generator().manual_seed(int(rng.randint(0, 2 ** 31)))
+    N = int(lens.sum())
+    data = torch.randint(-99, 99, (N, H), generator=g) if dtype == torch.int64 else (torch.randn(N, H, generator=g) * 0.5).to(dtype)
+    bf = dtype == torch.bfloat16
+    tag = f'B={B} len=[{lo},{hi}] H={H} {dtype}'
+    try:
+        srt = host_sort(lens)
+        oc = orc.C(to_np(data), lens.numpy())
+        osq = {'C': oc, 'L': orc.to_left(oc, 0), 'P': orc.to_pack(oc, srt), 'R': orc.to_right(oc, 0)}
+        dsq = {k: dev_seq(v, bf16=bf) for k, v in osq.items()}
+        for k, z in dsq.items():
+            for dst in 'CLPR':
+                out = {'C': z.cat, 'P': z.pack, 'L': z.left, 'R': z.right}[dst]()
+                assert_same_seq(out, orc.to_kind(osq[k], dst, 0, srt), f'{k}->{dst}')
+            s = int(rng.randint(-hi - 2, hi + 3))
+            assert_same_seq(z.roll(s), orc.roll(osq[k], s, srt), f'roll {k} {s}')
+            assert_same_seq(z.rev(), orc.rev(osq[k], srt), f'rev {k}')
+            assert np.array_equal(to_np(z.last()), orc.last(osq[k])), f'last {k}'
+        if dtype != torch.int64:
+            f = data.double().numpy() if dtype == torch.float64 else data.float().numpy()
+            ulp = {torch.float32: 0.0, torch.float64: 0.0, torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dtype]
+            for name in ('sum', 'mean', 'max', 'min', 'logsumexp'):
+                ref = getattr(orc, f'segment_{name}')(f, lens.numpy()).astype(np.float64)
+                scale = float(np.abs(f).max()) * (hi if name == 'sum' else 1)
+                outs = [getattr(ta, f'reduce_{name}')(dsq[k]) for k in 'CLPR']
+                if H % (16 // data.element_size()) == 0:
+                    outs.append(ta.pack_reduce(dsq['C'], name)[1])
+                for o in outs:
+                    np.testing.assert_allclose(o.double().cpu().numpy(), ref, rtol=2e-5 + ulp, atol=2e-5 * scale + ulp + 1e-6,
+                                               err_msg=name)
+    except Exception:
+        print('FAILED at', tag)
+        raise
+    n += 1
+print(f'soak ok: {n} random configurations')
