@@ -118,12 +118,17 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-    dev = torch.device('cuda', local_rank)
+    # rehearsal knobs (1-GPU box): RUA_BENCH_DEVICE pins every rank to one card, RUA_BENCH_BACKEND=gloo replaces RCCL
+    dev = torch.device('cuda', int(os.environ.get('RUA_BENCH_DEVICE', local_rank)))
     torch.cuda.set_device(dev)
     import torch.distributed as dist
     use_dist = world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ)   # under torchrun
     if use_dist:
-        dist.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('RUA_BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import torchrua_amd as ta
     from torchrua_amd import _ops
@@ -242,12 +247,12 @@ def main():
             with open(tpath) as f:
                 traffic = json.load(f).get('to_pack_hbm_bytes_per_launch')
         line = {
-            'metric': 'pack->reduce throughput, 65536 seqs/GPU h=512 bf16 (M elements/s) + % HBM roofline',
+            'metric': f'pack->reduce throughput, {B} seqs/GPU h={H} bf16 (M elements/s) + % HBM roofline',
             'value': round(value, 1), 'unit': 'M elements/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': f'pack->reduce_sum: {B} seqs/GPU, len~U({args.lo},{args.hi}), hidden={H}, bf16 '
-                                   f'(north-star shape; N={N} rows on rank 0)',
+                                   f'({"north-star shape" if (B, H, args.lo, args.hi) == (65536, 512, 8, 512) else "custom shape"}; N={N} rows on rank 0)',
                        'sharding': f'{world} x contiguous batch shards, one all-gather of [B,H]' if world > 1 else 'none',
                        'lens_source': 'host (C.new-style hand-over)'},
             'roofline': {'bound': 'hbm', 'kernel': 'move_rows_kernel<16,false,NT> (C->P pack)',
