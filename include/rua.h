@@ -169,7 +169,8 @@ int rua_pack_reduce(const rua_layout* src, const rua_layout* pack, const void* d
 
 /* Backward of rua_segment_reduce in one kernel (semantics of torch's
  * segment_reduce backward, which the reference inherits through autograd: reduce.py:34-61):
- *   SUM g | MEAN g/len | PROD g*out/x | LOGSUMEXP g*exp(x-out) | MAX/MIN g/ties where x == out, else 0.
+ *   SUM g | MEAN g/len | PROD g*prod(others) (zero factors handled like torch) | LOGSUMEXP g*exp(x-out) |
+ *   MAX/MIN g/ties where x == out, else 0.
  * grad_in has the storage of `data`; rows of padded layouts that hold no token are NOT written.
  * With `perm` it is the gradient w.r.t. the SOURCE rows of scatter_* (reduce.py:6-31); include_self != 0 then
  * counts the old destination row in MEAN's divisor (MAX/MIN ties with the old row are the caller's business).

@@ -299,3 +299,26 @@ def test_inconsistent_metadata_cannot_fault_the_gpu():
     got = ta.C(data, torch.tensor([3, 5, 2], device=DEV))[key]            # batch_ptr out of range -> zero rows
     assert torch.equal(got[0], data[1]) and bool((got[1] == 0).all()) and bool((got[2] == 0).all())
     torch.cuda.synchronize()
+
+
+def test_prod_backward_with_zeros_matches_torch():
+    """d prod / d x_i = prod of the OTHER factors, also when x_i == 0 (torch.segment_reduce special-cases zeros)."""
+    x = torch.tensor([[2.0, 0.0, 3.0, 0.0], [0.0, 5.0, 4.0, 0.0], [3.0, 2.0, 0.0, 7.0],        # seq 0 (3 rows)
+                      [1.5, 2.5, 3.5, 4.5], [0.0, 0.0, 1.0, 2.0]], device=DEV)                  # seq 1 (2 rows)
+    lens = torch.tensor([3, 2], device=DEV)
+    for kind in 'CLPR':
+        a = x.clone().requires_grad_(True)
+        c = ta.C(a, lens)
+        z = {'C': lambda: c, 'L': c.left, 'P': c.pack, 'R': c.right}[kind]()
+        out = ta.reduce_prod(z)
+        cot = torch.tensor([[1.0, 2.0, 3.0, 4.0], [0.5, 1.5, 2.5, 3.5]], device=DEV)
+        out.backward(cot)
+        b = x.clone().requires_grad_(True)
+        ref = torch.stack([b[:3].prod(0), b[3:].prod(0)])
+        ref.backward(cot)
+        torch.testing.assert_close(out, ref)
+        torch.testing.assert_close(a.grad, b.grad, msg=kind)
+    # and through the reference's own op on the CPU
+    r = x.cpu().clone().requires_grad_(True)
+    torch.segment_reduce(r, 'prod', lengths=lens.cpu(), unsafe=True, initial=1).backward(cot.cpu())
+    torch.testing.assert_close(a.grad.cpu(), r.grad)

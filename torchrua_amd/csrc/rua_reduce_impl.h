@@ -559,7 +559,18 @@ __device__ __forceinline__ void backward_unit(const Unit<T, EPL>& U, int64_t t_l
     for (int e = 0; e < EPL; ++e) g[e] = g[e] / (A)(len + extra_count);   // +1: the old row took part (scatter_mean, include_self)
   }
 
-  for (int pass = (OP == RUA_MAX || OP == RUA_MIN) ? 0 : 1; pass < 2; ++pass) {
+  // PROD with zeros: d/dx_i = g * prod_{j != i} x_j, which g*out/x cannot give when x_i == 0.  Whole-sequence
+  // launches (t_lo == 0 && t_hi == len) take a first walk that counts the zeros of every column and multiplies
+  // the non-zero factors, exactly torch's special case; split parts keep g*out/x (documented).
+  A zeros[EPL];   // PROD: zero factors per column (pass 0)
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) zeros[e] = (A)0;
+  const bool whole = t_lo == 0 && t_hi >= len;
+  const bool two_pass = (OP == RUA_MAX || OP == RUA_MIN) || (OP == RUA_PROD && whole);
+  A nz[EPL];      // PROD: product of the non-zero factors
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) nz[e] = (A)1;
+  for (int pass = two_pass ? 0 : 1; pass < 2; ++pass) {
     A cnt[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) cnt[e] = (A)0;
@@ -592,7 +603,12 @@ __device__ __forceinline__ void backward_unit(const Unit<T, EPL>& U, int64_t t_l
             const A x = need_x ? elem<T>::up(p[u].v[e]) : (A)0;
             A gi;
             if (OP == RUA_SUM || OP == RUA_MEAN) gi = g[e];
-            else if (OP == RUA_PROD) gi = g[e] * o[e] / x;
+            else if (OP == RUA_PROD) {
+              if (pass == 0) { if (x == (A)0) cnt[e] += (A)1; else nz[e] *= x; }
+              if (!two_pass || zeros[e] == (A)0) gi = g[e] * o[e] / x;            // no zero in this column
+              else if (zeros[e] == (A)1) gi = (x == (A)0) ? g[e] * nz[e] : (A)0;  // the single zero gets it all
+              else gi = (A)0;                                                      // two zeros: every product is 0
+            }
             else if (OP == RUA_LOGSUMEXP) gi = g[e] * fexp(x - o[e]);
             else {
               const bool hit = (x == o[e]) || (x != x && o[e] != o[e]);
@@ -606,13 +622,19 @@ __device__ __forceinline__ void backward_unit(const Unit<T, EPL>& U, int64_t t_l
       }
       tv = tv_next;
     }
-    if (pass == 0) {   // MAX/MIN: share the gradient among the ties of every column
+    if (pass == 0) {   // combine the row-groups of the wave
       for (int d = 1 << lp_log2; d < RUA_WAVE; d <<= 1) {
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) cnt[e] += __shfl_xor(cnt[e], d, RUA_WAVE);
+        for (int e = 0; e < EPL; ++e) {
+          cnt[e] += __shfl_xor(cnt[e], d, RUA_WAVE);
+          if (OP == RUA_PROD) nz[e] *= __shfl_xor(nz[e], d, RUA_WAVE);
+        }
       }
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) g[e] = g[e] / (cnt[e] > (A)0 ? cnt[e] : (A)1);
+      for (int e = 0; e < EPL; ++e) {
+        if (OP == RUA_PROD) zeros[e] = cnt[e];
+        else g[e] = g[e] / (cnt[e] > (A)0 ? cnt[e] : (A)1);   // MAX/MIN: ties share the gradient equally
+      }
     }
   }
 }
