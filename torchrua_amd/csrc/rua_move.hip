@@ -16,8 +16,17 @@
 
 namespace rua {
 
-constexpr int TILE_ROWS = 256;  // == RUA_BLOCK: one lane per row in phase 1
-constexpr int UNROLL = 4;       // row groups in flight per wave in phase 2
+#ifndef RUA_MOVE_BLOCK        // developer knobs for A/B builds (scripts/pack_ab.py)
+#define RUA_MOVE_BLOCK 256
+#endif
+#ifndef RUA_MOVE_UNROLL
+#define RUA_MOVE_UNROLL 4
+#endif
+constexpr int MOVE_BLOCK = RUA_MOVE_BLOCK;          // threads per workgroup of the generic mover
+constexpr int MOVE_WAVES = MOVE_BLOCK / RUA_WAVE;
+constexpr int MOVE_TILE = MOVE_BLOCK;               // one lane per row in phase 1
+constexpr int TILE_ROWS = 256;                      // the (rank x time) tile of pack_tile_kernel: 16 x 16
+constexpr int UNROLL = RUA_MOVE_UNROLL;             // row groups in flight per wave in phase 2
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -54,18 +63,18 @@ template <typename V, bool NT> __device__ __forceinline__ void st_row(char* p, V
 //            1 KiB share a wave instruction (64 >> lp_log2 rows at a time)
 // cpr      : 64-lane column chunks per row (1 unless row_bytes > 64*VEC)
 template <int VEC, bool SCATTER, bool NT>
-__global__ __launch_bounds__(RUA_BLOCK) void move_rows_kernel(rua_layout D, rua_layout S, int32_t tmap,
+__global__ __launch_bounds__(MOVE_BLOCK) void move_rows_kernel(rua_layout D, rua_layout S, int32_t tmap,
                                                               int64_t targ, char* __restrict__ dst,
                                                               const char* __restrict__ src, int64_t row_bytes,
                                                               int64_t lpr, int lp_log2, int cpr, uint4 fillpat,
                                                               int64_t pad_row) {
   using V = typename vec_of<VEC>::type;
-  __shared__ int64_t s_ld[TILE_ROWS];
-  __shared__ int64_t s_st[TILE_ROWS];
+  __shared__ int64_t s_ld[MOVE_TILE];
+  __shared__ int64_t s_st[MOVE_TILE];
 
-  const int64_t tile0 = (int64_t)blockIdx.x * TILE_ROWS;
+  const int64_t tile0 = (int64_t)blockIdx.x * MOVE_TILE;
   const int64_t left = D.n_rows - tile0;
-  const int nrows = left < TILE_ROWS ? (int)left : TILE_ROWS;
+  const int nrows = left < MOVE_TILE ? (int)left : MOVE_TILE;
 
   // ---- phase 1: one lane per destination row
   {
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(RUA_BLOCK) void move_rows_kernel(rua_layout D, rua_
   const int64_t col0 = lane & ((1 << lp_log2) - 1);
   const V fillv = fill_of<VEC>(fillpat);
 
-  for (int g0 = wave; g0 * rpw < nrows; g0 += RUA_WAVES_PER_BLOCK * UNROLL) {
+  for (int g0 = wave; g0 * rpw < nrows; g0 += MOVE_WAVES * UNROLL) {
     for (int c = 0; c < cpr; ++c) {
       const int64_t col = col0 + (int64_t)c * RUA_WAVE;
       const bool colok = col < lpr;
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(RUA_BLOCK) void move_rows_kernel(rua_layout D, rua_
       int64_t st[UNROLL];
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
-        const int r = (g0 + u * RUA_WAVES_PER_BLOCK) * rpw + rsub;
+        const int r = (g0 + u * MOVE_WAVES) * rpw + rsub;
         st[u] = -1;
         val[u] = fillv;
         if (colok && r < nrows) {
@@ -249,7 +258,7 @@ static int launch_move(int vec, unsigned grid, hipStream_t s, const rua_layout& 
   int lp_log2 = 0;
   while ((1 << lp_log2) < lpr && lp_log2 < 6) ++lp_log2;
   const int cpr = (int)((lpr + RUA_WAVE - 1) / RUA_WAVE);
-  const dim3 g(grid), b(RUA_BLOCK);
+  const dim3 g(grid), b(MOVE_BLOCK);
 #define RUA_LAUNCH(VEC) \
   hipLaunchKernelGGL((move_rows_kernel<VEC, SCATTER, NT>), g, b, 0, s, D, S, tmap, targ, dst, src, row_bytes, lpr, lp_log2, cpr, fp, pad_row)
   switch (vec) {
@@ -277,7 +286,7 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
   if (dst->n_rows == 0 || row_bytes == 0) return 0;
   if (!dst_data || !src_data) return RUA_EINVAL;
   if (pad_row < -1 || pad_row >= src->n_rows) return RUA_EINVAL;
-  const int64_t ntiles = (dst->n_rows + TILE_ROWS - 1) / TILE_ROWS;
+  const int64_t ntiles = (dst->n_rows + MOVE_TILE - 1) / MOVE_TILE;
   if (ntiles > 0x7fffffffLL) return RUA_ERANGE;
 
   // widest power-of-two access that divides the row size and both base addresses
