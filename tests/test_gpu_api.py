@@ -105,3 +105,28 @@ def test_wrong_device_and_dtype_errors():
         ta.scatter_sum(torch.zeros(2, 5, device=DEV), torch.tensor([0, 1, 1, 0, 0]), c.data)   # index on the CPU
     with pytest.raises(ta.RuaError):
         ta.scatter_max(torch.zeros(5, 2, device=DEV), torch.zeros(5, dtype=torch.long, device=DEV), c.data, dim=1)
+
+
+def test_product_process_never_loads_the_oracle(tmp_path):
+    """A process that only uses the product maps librua_hip.so and nothing from oracle/ (checked in /proc/self/maps)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = '''
+import sys, torch
+sys.path.insert(0, %r)
+import torchrua_amd as ta
+xs = [torch.randn(n, 8, device="cuda:0", requires_grad=True) for n in (3, 5, 2)]
+p = ta.P.new(xs)
+out = ta.reduce_max(p.roll(1).left().pack())
+out.sum().backward()
+ta.scatter_sum(torch.zeros(3, 8, device="cuda:0"), torch.tensor([0, 2, 2, 1], device="cuda:0"), torch.randn(4, 8, device="cuda:0"))
+torch.cuda.synchronize()
+maps = open("/proc/self/maps").read()
+assert "librua_hip.so" in maps, "the HIP library is not loaded"
+assert "librua_oracle" not in maps, "the oracle library is mapped in a product-only process"
+assert not any(m == "oracle" or m.startswith("oracle.") for m in sys.modules), "oracle imported"
+print("ok")
+''' % root
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stdout + out.stderr
