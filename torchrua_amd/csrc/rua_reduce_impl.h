@@ -453,19 +453,21 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_tail_kernel(rua_layout L,
                                                                    rua_layout CD, T* __restrict__ copy, SplitWs W) {
   using A = typename elem<T>::acc;
   const int lane = threadIdx.x;
-  const int64_t i = blockIdx.x;
-  if ((unsigned long long)i >= W.ctr[0]) return;
-  const int64_t* e = W.items + i * 4;
   constexpr int NE = EPL * CPW;
-  const Unit<T, EPL> U = make_unit<T, EPL, COPY, CPW>(L, CD, perm, e[0], e[1], H, lp_log2, lane);
-  const int64_t t_lo = e[2] * W.split;
-  const int64_t t_hi = (t_lo + W.split < U.len) ? t_lo + W.split : U.len;
-  Fold<A, NE> f;
-  fold_init<A, NE, OP>(f);
-  fold_rows<T, EPL, OP, NT, COPY, CPW>(U, t_lo, t_hi, data, H, f, CD, copy, lane);
-  fold_wave<A, NE, OP>(f, lp_log2);
-  store_partial<A, NE>(W.partials, e[3], lane, f);
-  fold_extreme<A, NE, OP>(f, extreme, i, lane, true);
+  const int64_t n_items = (int64_t)W.ctr[0];
+  // the grid is capped (SPLIT_GRID_CAP): every workgroup strides over the published items
+  for (int64_t i = blockIdx.x; i < n_items; i += gridDim.x) {
+    const int64_t* e = W.items + i * 4;
+    const Unit<T, EPL> U = make_unit<T, EPL, COPY, CPW>(L, CD, perm, e[0], e[1], H, lp_log2, lane);
+    const int64_t t_lo = e[2] * W.split;
+    const int64_t t_hi = (t_lo + W.split < U.len) ? t_lo + W.split : U.len;
+    Fold<A, NE> f;
+    fold_init<A, NE, OP>(f);
+    fold_rows<T, EPL, OP, NT, COPY, CPW>(U, t_lo, t_hi, data, H, f, CD, copy, lane);
+    fold_wave<A, NE, OP>(f, lp_log2);
+    store_partial<A, NE>(W.partials, e[3], lane, f);
+    fold_extreme<A, NE, OP>(f, extreme, i, lane, true);
+  }
 }
 
 // fold the partials of every long unit and finalise.  A 16-wave workgroup per unit: wave w folds the
@@ -484,8 +486,9 @@ __global__ __launch_bounds__(RUA_WAVE * (COMBINE_WAVES_MAX / CPW)) void seg_redu
   __shared__ A s_acc[COMBINE_WAVES][RUA_WAVE * NE];
   __shared__ A s_aux[COMBINE_WAVES][RUA_WAVE * NE];
   const int lane = threadIdx.x & (RUA_WAVE - 1), wave = threadIdx.x >> 6;
-  const int64_t j = blockIdx.x;
-  if ((unsigned long long)j >= W.ctr[1]) return;   // block-uniform
+  const int64_t n_long = (int64_t)W.ctr[1];
+  for (int64_t j = blockIdx.x; j < n_long; j += gridDim.x) {   // block-uniform loop (capped grid)
+  __syncthreads();                                             // s_acc / s_aux are reused per unit
   const int64_t* e = W.long_list + j * 4;
   const int64_t nparts = e[2], pbase = e[3];
   const int64_t per = (nparts + COMBINE_WAVES - 1) / COMBINE_WAVES;
@@ -510,17 +513,19 @@ __global__ __launch_bounds__(RUA_WAVE * (COMBINE_WAVES_MAX / CPW)) void seg_redu
 #pragma unroll
   for (int k = 0; k < NE; ++k) { s_acc[wave][lane * NE + k] = f.acc[k]; s_aux[wave][lane * NE + k] = f.aux[k]; }
   __syncthreads();
-  if (wave != 0) return;
-  for (int w = 1; w < COMBINE_WAVES; ++w) {
-    if (w * per >= nparts) break;     // ranges beyond the last part are empty
-    A a2[NE], x2[NE];
+  if (wave == 0) {
+    for (int w = 1; w < COMBINE_WAVES; ++w) {
+      if (w * per >= nparts) break;     // ranges beyond the last part are empty
+      A a2[NE], x2[NE];
 #pragma unroll
-    for (int k = 0; k < NE; ++k) { a2[k] = s_acc[w][lane * NE + k]; x2[k] = s_aux[w][lane * NE + k]; }
-    fold_merge<A, NE, OP>(f, a2, x2);
+      for (int k = 0; k < NE; ++k) { a2[k] = s_acc[w][lane * NE + k]; x2[k] = s_aux[w][lane * NE + k]; }
+      fold_merge<A, NE, OP>(f, a2, x2);
+    }
+    const Unit<T, EPL> U = copy_mode ? make_unit<T, EPL, true, CPW>(L, CD, perm, e[0], e[1], H, lp_log2, lane)
+                                     : make_unit<T, EPL, false, CPW>(L, CD, perm, e[0], e[1], H, lp_log2, lane);
+    fold_store<T, EPL, OP, CPW>(U, f, out, H, include_self, empty_val);
   }
-  const Unit<T, EPL> U = copy_mode ? make_unit<T, EPL, true, CPW>(L, CD, perm, e[0], e[1], H, lp_log2, lane)
-                                   : make_unit<T, EPL, false, CPW>(L, CD, perm, e[0], e[1], H, lp_log2, lane);
-  fold_store<T, EPL, OP, CPW>(U, f, out, H, include_self, empty_val);
+  }
 }
 
 // ---------------------------------------------------------------- backward of the reductions
@@ -677,13 +682,14 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_tail_kernel(rua_layout 
                                                                      T* __restrict__ gin, int64_t H, int lp_log2,
                                                                      int extra_count, SplitWs W) {
   const int lane = threadIdx.x;
-  const int64_t i = blockIdx.x;
-  if ((unsigned long long)i >= W.ctr[0]) return;
-  const int64_t* e = W.items + i * 4;
-  const Unit<T, EPL> U = make_unit<T, EPL, false>(L, L, perm, e[0], e[1], H, lp_log2, lane);
-  const int64_t t_lo = e[2] * W.split;
-  const int64_t t_hi = (t_lo + W.split < U.len) ? t_lo + W.split : U.len;
-  backward_unit<T, EPL, OP>(U, t_lo, t_hi, data, out, gout, gin, H, extra_count, lane);
+  const int64_t n_items = (int64_t)W.ctr[0];
+  for (int64_t i = blockIdx.x; i < n_items; i += gridDim.x) {
+    const int64_t* e = W.items + i * 4;
+    const Unit<T, EPL> U = make_unit<T, EPL, false>(L, L, perm, e[0], e[1], H, lp_log2, lane);
+    const int64_t t_lo = e[2] * W.split;
+    const int64_t t_hi = (t_lo + W.split < U.len) ? t_lo + W.split : U.len;
+    backward_unit<T, EPL, OP>(U, t_lo, t_hi, data, out, gout, gin, H, extra_count, lane);
+  }
 }
 
 // extreme scratch: [0..63] hashed ordered-bit slots, [64] NaN flag (initialised by rua_reduce.hip)
@@ -718,6 +724,8 @@ static inline unsigned grid_for(int64_t n) { return (unsigned)((n + RUA_BLOCK - 
 
 // workspace carving for the long-sequence split (see SplitWs)
 static inline int64_t split_max_extra(int64_t n_rows, int64_t split) { return split > 0 ? n_rows / split : 0; }
+constexpr int64_t SPLIT_GRID_CAP = 16384;   // tail / combine grids: 2x the wave slots of the chip, then stride
+static inline unsigned split_grid(int64_t max_u) { return (unsigned)(max_u < SPLIT_GRID_CAP ? max_u : SPLIT_GRID_CAP); }
 
 template <typename A>
 static SplitWs carve_ws(void* ws, int64_t max_u, int64_t split) {
@@ -755,9 +763,9 @@ static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout&
   if (do_split) {                                                                                                   \
     hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY, true, CPW>), g, b, 0, s, L, perm, (const T*)data,   \
                        (T*)out, H, lp_log2, n_chunks, include_self, ev, ext, CD, (T*)copy, W);                      \
-    hipLaunchKernelGGL((seg_reduce_tail_kernel<T, EPL, OP, NT, COPY, CPW>), dim3((unsigned)max_u), b, 0, s, L, perm, \
+    hipLaunchKernelGGL((seg_reduce_tail_kernel<T, EPL, OP, NT, COPY, CPW>), dim3(split_grid(max_u)), b, 0, s, L, perm, \
                        (const T*)data, H, lp_log2, ext, CD, (T*)copy, W);                                           \
-    hipLaunchKernelGGL((seg_reduce_combine_kernel<T, EPL, OP, CPW>), dim3((unsigned)max_u),                        \
+    hipLaunchKernelGGL((seg_reduce_combine_kernel<T, EPL, OP, CPW>), dim3(split_grid(max_u)),                     \
                        dim3(RUA_WAVE * (COMBINE_WAVES_MAX / CPW)), 0, s, L, perm, (T*)out,                          \
                        H, lp_log2, include_self, ev, CD, COPY ? 1 : 0, W);                                          \
   } else {                                                                                                          \
@@ -831,7 +839,7 @@ static int launch_backward(int op, unsigned grid, hipStream_t s, const rua_layou
   if (do_split) {                                                                                                 \
     hipLaunchKernelGGL((seg_backward_kernel<T, EPL, OP, true>), g, b, 0, s, L, perm, (const T*)data,              \
                        (const T*)out, (const T*)gout, (T*)gin, H, lp_log2, n_chunks, extra_count, W);            \
-    hipLaunchKernelGGL((seg_backward_tail_kernel<T, EPL, OP>), dim3((unsigned)max_u), b, 0, s, L, perm,           \
+    hipLaunchKernelGGL((seg_backward_tail_kernel<T, EPL, OP>), dim3(split_grid(max_u)), b, 0, s, L, perm,         \
                        (const T*)data, (const T*)out, (const T*)gout, (T*)gin, H, lp_log2, extra_count, W);      \
   } else {                                                                                                        \
     hipLaunchKernelGGL((seg_backward_kernel<T, EPL, OP, false>), g, b, 0, s, L, perm, (const T*)data,             \
