@@ -184,10 +184,11 @@ int rua_segment_reduce_backward(const rua_layout* lay, const int64_t* perm, cons
 int rua_fill_empty(const rua_layout* lay, void* out, int64_t H, int32_t dtype, int32_t op,
                    const void* extreme, void* stream);
 
-/* Counting sort of `index` (values in [0,S)) giving for every destination its contribution
- * rows in ascending source order (deterministic): counts[S], off[S] (exclusive scan),
- * perm[M].  `ws` holds rua_scan_ws_elems(S) + S + M int64.  Feeds rua_segment_reduce(perm=..)
- * for scatter_* (reduce.py:6-31). */
+/* Bucket `index` (values in [0,S); others are ignored): counts[S], off[S] (exclusive scan) and perm[M] such that
+ * perm[off[s] .. off[s]+counts[s]) are the rows i with index[i] == s IN ASCENDING ORDER — a stable LSD radix sort
+ * on the destination (8-bit digits), deterministic for any fan-in.  `ws` holds rua_bucket_ws_elems(M, S) int64.
+ * Feeds rua_segment_reduce(perm=..) for scatter_* (reduce.py:6-31). */
+int64_t rua_bucket_ws_elems(int64_t M, int64_t S);
 int rua_index_buckets(const int64_t* index, int64_t M, int64_t S, int64_t* counts, int64_t* off,
                       int64_t* perm, int64_t* ws, void* stream);
 

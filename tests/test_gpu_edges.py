@@ -244,8 +244,24 @@ def test_long_sequences_are_split(hidden, dtype):
     assert torch.equal(src.grad, torch.ones_like(src))
 
 
+def test_bucketing_is_a_stable_sort():
+    """rua_index_buckets == a stable sort of the rows by destination (checked against torch.sort(stable=True)),
+    for few / many destinations, 1-3 radix passes, out-of-range indices ignored."""
+    from torchrua_amd.reduce import _buckets
+    g = torch.Generator().manual_seed(1)
+    for S, M in ((1, 10), (7, 5000), (255, 70000), (257, 70000), (65536, 300000), (70000, 123457), (3, 2049)):
+        index = torch.randint(0, S, (M,), generator=g).to(DEV)
+        counts, perm = _buckets(index, S)
+        order = torch.sort(index, stable=True)[1]
+        assert torch.equal(perm, order), (S, M)
+        assert torch.equal(counts, torch.bincount(index, minlength=S)), (S, M)
+    index = torch.tensor([2, -1, 0, 9, 2, 0, 5], device=DEV)          # -1, 9, 5 are out of range for S = 3
+    counts, perm = _buckets(index, 3)
+    assert counts.tolist() == [2, 0, 2] and perm[:4].tolist() == [2, 5, 0, 4]
+
+
 def test_scatter_huge_fan_in_is_fast_and_right():
-    """One destination receiving 300 000 rows: no quadratic ordering pass, still the right values."""
+    """One destination receiving 300 000 rows: deterministic order, right values, twice bit-identical."""
     import time
     g = torch.Generator().manual_seed(0)
     M, H = 300_000, 8
@@ -256,6 +272,7 @@ def test_scatter_huge_fan_in_is_fast_and_right():
     t0 = time.perf_counter()
     out = ta.scatter_sum(ten.to(DEV), index.to(DEV), src.to(DEV))
     mx = ta.scatter_max(ten.to(DEV), index.to(DEV), src.to(DEV))
+    assert torch.equal(out, ta.scatter_sum(ten.to(DEV), index.to(DEV), src.to(DEV)))   # bitwise reproducible
     torch.cuda.synchronize()
     assert time.perf_counter() - t0 < 5.0
     ref = torch.zeros(2, H, dtype=torch.float64).index_add_(0, index, src.double())

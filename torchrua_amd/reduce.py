@@ -3,9 +3,9 @@
 segment_*  : torch.segment_reduce(..., lengths=sizes, unsafe=True, initial=..) in the reference
              (reduce.py:34-61) -> rua_segment_reduce over a CAT layout (fp32 accumulation, one pass;
              the reference's extra full read for `initial = tensor.min()` is folded into that pass).
-scatter_*  : torch.index_reduce / index_add (reduce.py:6-31) -> bucket the index (counting sort,
+scatter_*  : torch.index_reduce / index_add (reduce.py:6-31) -> bucket the index (stable radix sort,
              rua_index_buckets) and run the same segmented kernel through the row indirection:
-             no float atomics, bitwise reproducible.
+             no float atomics, bitwise reproducible for any fan-in.
 reduce_*   : the same reductions over the sequences of ANY container (C/L/P/R) -> [B, *H] in batch
              order, without first converting to C (BASELINE.json's `reduce_sum`; SURVEY.md §8d spells
              it in the reference as p.cat() + segment_sum, or scatter_sum over p.ptr()[0]).
@@ -112,7 +112,7 @@ def _buckets(index: T, S: int):
     counts = torch.empty(S, dtype=torch.long, device=dev)
     off = torch.empty(S, dtype=torch.long, device=dev)
     perm = torch.empty(m, dtype=torch.long, device=dev)
-    ws = torch.empty(lib.rua_scan_ws_elems(S) + S + m, dtype=torch.long, device=dev)
+    ws = torch.empty(lib.rua_bucket_ws_elems(m, S), dtype=torch.long, device=dev)
     K.check(lib.rua_index_buckets(K.ptr(index), m, S, K.ptr(counts), K.ptr(off), K.ptr(perm), K.ptr(ws),
                                   K.stream_ptr(dev)), 'rua_index_buckets')
     M._memo_put(counts, 'off', off)
