@@ -186,7 +186,8 @@ int rua_fill_empty(const rua_layout* lay, void* out, int64_t H, int32_t dtype, i
 
 /* Bucket `index` (values in [0,S); others are ignored): counts[S], off[S] (exclusive scan) and perm[M] such that
  * perm[off[s] .. off[s]+counts[s]) are the rows i with index[i] == s IN ASCENDING ORDER — a stable LSD radix sort
- * on the destination (8-bit digits), deterministic for any fan-in.  `ws` holds rua_bucket_ws_elems(M, S) int64.
+ * of packed (destination, row) words on the destination (<= 9-bit digits), deterministic for any fan-in;
+ * needs bits(S) + bits(M) <= 62 (RUA_ERANGE otherwise).  `ws` holds rua_bucket_ws_elems(M, S) int64.
  * Feeds rua_segment_reduce(perm=..) for scatter_* (reduce.py:6-31). */
 int64_t rua_bucket_ws_elems(int64_t M, int64_t S);
 int rua_index_buckets(const int64_t* index, int64_t M, int64_t S, int64_t* counts, int64_t* off,
