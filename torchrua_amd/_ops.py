@@ -8,6 +8,7 @@ from typing import Callable, Optional, Sequence, Tuple
 
 import torch
 from torch import Tensor
+from torch.autograd.function import once_differentiable
 
 from torchrua_amd import _lib as L
 from torchrua_amd import _meta as M
@@ -96,6 +97,7 @@ class _ListGather(torch.autograd.Function):
         return launch_move(plan, src_data)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad: Tensor):
         flat = ctx.flat_fn()
         g = torch.zeros(ctx.src_shape, dtype=grad.dtype, device=grad.device)
@@ -162,6 +164,7 @@ class _Reduce(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad: Tensor):
         """One fused kernel (rua_segment_reduce_backward): reads the payload once (twice for max/min: the tie
         count), writes the gradient once — no [N, H] temporaries."""

@@ -11,6 +11,7 @@ reduce_*   : the same reductions over the sequences of ANY container (C/L/P/R) -
              it in the reference as p.cat() + segment_sum, or scatter_sum over p.ptr()[0]).
 """
 import torch
+from torch.autograd.function import once_differentiable
 
 from torchrua_amd import _lib as K
 from torchrua_amd import _meta as M
@@ -142,6 +143,7 @@ class _Scatter(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad: T):
         """Gradient w.r.t. the source rows: ONE fused kernel walking every destination's bucket
         (rua_segment_reduce_backward with the row indirection), except max/min with include_self, whose ties
