@@ -21,6 +21,7 @@ rng = np.random.RandomState(seed)
 print('seed', seed)
 t_end = time.time() + budget
 n = 0
+last_report = time.time()
 while time.time() < t_end:
     B = int(rng.choice([1, 2, 7, 63, 64, 65, 255, 257, 1000, 2049, 3000]))
     hi = int(rng.choice([1, 2, 5, 17, 63, 64, 65, 130, 300, 700]))
@@ -60,8 +61,29 @@ while time.time() < t_end:
                 for o in outs:
                     np.testing.assert_allclose(o.double().cpu().numpy(), ref, rtol=2e-5 + ulp, atol=2e-5 * scale + ulp + 1e-6,
                                                err_msg=name)
+            if dtype == torch.float32 and N * H < 4e6:
+                # scatter_* over shuffled rows (both include_self values) and gradients of a reduce / a cast chain
+                index = torch.repeat_interleave(torch.arange(B), lens)
+                perm = torch.randperm(N, generator=g)
+                ten = torch.randn(B, H, generator=g)
+                for name in ('sum', 'max', 'mean'):
+                    for inc in (False, True):
+                        ref = getattr(orc, f'scatter_{name}')(ten.numpy(), index[perm].numpy(), f[perm.numpy()], include_self=inc)
+                        got = getattr(ta, f'scatter_{name}')(ten.to(DEV), index[perm].to(DEV), data[perm].to(DEV), include_self=inc)
+                        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * max(1.0, scale), err_msg=f'scatter {name}')
+                x = data.clone().to(DEV).requires_grad_(True)
+                c = ta.C(x, lens.to(DEV))
+                out = ta.reduce_logsumexp(c.pack().roll(1).left().pack())
+                cot = torch.randn(out.shape, generator=g).to(DEV)
+                out.backward(cot)
+                r = data.clone().to(DEV).requires_grad_(True)
+                torch.stack([t_.logsumexp(0) for t_ in torch.split(r, lens.tolist())]).backward(cot)
+                torch.testing.assert_close(x.grad, r.grad, rtol=1e-4, atol=1e-5)
     except Exception:
         print('FAILED at', tag)
         raise
     n += 1
+    if time.time() - last_report > 30:
+        print(f'  {n} configurations so far', flush=True)
+        last_report = time.time()
 print(f'soak ok: {n} random configurations')
