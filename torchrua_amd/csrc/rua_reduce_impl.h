@@ -102,10 +102,20 @@ struct Unit {
 // CPW: 64-lane column chunks one wave covers per row (1, or 4 for rows wider than 1 KiB so that a whole row
 // — up to 4 KiB — is read back to back by ONE wave: DRAM pages are used in full instead of being shared by
 // several waves that each take 1 KiB of it; measured 4.4 -> 6 TB/s at 4-KiB rows)
-template <typename T, int EPL, bool COPY, int CPW = 1>
+// RANKS (PackedSequence input, rows narrower than 1 KiB): the 64 >> lp_log2 row groups of a wave serve ADJACENT
+// RANKS at the same time step instead of consecutive time steps of one sequence — adjacent ranks are adjacent
+// rows of every time step, so a wave instruction reads one contiguous run (a 32-byte row no longer costs a
+// whole 128-byte line).  Each group then owns its own sequence: no cross-group combine.
+template <typename T, int EPL, bool COPY, int CPW = 1, bool RANKS = false>
 __device__ __forceinline__ Unit<T, EPL> make_unit(const rua_layout& L, const rua_layout& CD, const int64_t* perm,
                                                    int64_t q, int64_t chunk, int64_t H, int lp_log2, int lane) {
   Unit<T, EPL> u;
+  bool live = true;
+  if (RANKS) {
+    q = q * (RUA_WAVE >> lp_log2) + (lane >> lp_log2);
+    live = q < L.B;
+    if (!live) q = L.B - 1;
+  }
   u.q = q;
   u.chunk = chunk;
   // PACK is walked in rank order (longest first = LPT schedule; neighbouring workgroups read
@@ -116,8 +126,8 @@ __device__ __forceinline__ Unit<T, EPL> make_unit(const rua_layout& L, const rua
   u.rpw = RUA_WAVE >> lp_log2;
   u.rsub = lane >> lp_log2;
   u.col = (chunk * CPW * RUA_WAVE + (lane & ((1 << lp_log2) - 1))) * EPL;   // sub-chunk c adds c * 64 * EPL
-  u.colok = u.col < H;
-  u.len = seq_len(L, u.b);
+  u.colok = u.col < H && live;
+  u.len = live ? seq_len(L, u.b) : 0;
   u.n_rows = L.n_rows;
   u.base = 0;
   u.tb = 0;
@@ -156,7 +166,7 @@ __device__ __forceinline__ void fold_init(Fold<A, EPL>& f) {
 }
 
 // fold rows [t_lo, t_hi) of the unit's sequence
-template <typename T, int EPL, int OP, bool NT, bool COPY, int CPW = 1>
+template <typename T, int EPL, int OP, bool NT, bool COPY, int CPW = 1, bool RANKS = false>
 __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, int64_t t_hi,
                                           const T* __restrict__ data, int64_t H,
                                           Fold<typename elem<T>::acc, EPL * CPW>& f, const rua_layout& CD,
@@ -181,16 +191,16 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
     const int64_t tv_next = (tbl && nxt < t_hi) ? tbl[tb + nxt] : 0;
     const int64_t cv_next = (COPY && nxt < t_hi) ? CD.boff[nxt] : 0;
     const int nblk = (t_hi - tblk) < RUA_WAVE ? (int)(t_hi - tblk) : RUA_WAVE;
-    for (int k = 0; k < nblk; k += rpw * UT) {
+    for (int k = 0; k < nblk; k += (RANKS ? 1 : rpw) * UT) {
       int64_t row[UT];
       int64_t crow[UT];
       Pack p[UT][CPW];
 #pragma unroll
       for (int u = 0; u < UT; ++u) {
-        const int tl = k + u * rpw + rsub;
+        const int tl = RANKS ? k + u : k + u * rpw + rsub;   // RANKS: every group walks the same time steps
         const int64_t tabv = __shfl(tv, tl & (RUA_WAVE - 1), RUA_WAVE);
         row[u] = -1;
-        if (colok && tl < nblk) row[u] = base + (tbl ? tabv : tblk + tl);
+        if (colok && tl < nblk && (!RANKS || tblk + tl < U.len)) row[u] = base + (tbl ? tabv : tblk + tl);
         if (row[u] >= L_rows) row[u] = -1;   // lengths that run past the storage read nothing
         if (COPY) crow[u] = __shfl(cv, tl & (RUA_WAVE - 1), RUA_WAVE) + U.q;
       }
@@ -272,7 +282,7 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
 
 // fold the NaN flags in and combine the rpw row-groups of the wave (lanes that differ in the bits above
 // lp_log2); afterwards every lane of a column holds the wave's value
-template <typename A, int EPL, int OP>
+template <typename A, int EPL, int OP, bool RANKS = false>
 __device__ __forceinline__ void fold_wave(Fold<A, EPL>& f, int lp_log2) {
   if (OP == RUA_MAX || OP == RUA_MIN) {
 #pragma unroll
@@ -281,7 +291,7 @@ __device__ __forceinline__ void fold_wave(Fold<A, EPL>& f, int lp_log2) {
       f.ext_nan |= f.nan_e[e];
     }
   }
-  for (int d = 1 << lp_log2; d < RUA_WAVE; d <<= 1) {
+  for (int d = RANKS ? RUA_WAVE : (1 << lp_log2); d < RUA_WAVE; d <<= 1) {   // RANKS: groups are separate sequences
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
       const A o = __shfl_xor(f.acc[e], d, RUA_WAVE);
@@ -321,14 +331,14 @@ __device__ __forceinline__ void fold_merge(Fold<A, EPL>& f, const A* acc2, const
 
 // include_self: 0 = overwrite (empty sequence -> empty_val), 1 = fold the old out[b] in,
 //               2 = leave out[b] untouched when the sequence is empty (index_reduce semantics)
-template <typename T, int EPL, int OP, int CPW = 1>
+template <typename T, int EPL, int OP, int CPW = 1, bool RANKS = false>
 __device__ __forceinline__ void fold_store(const Unit<T, EPL>& U, Fold<typename elem<T>::acc, EPL * CPW>& f,
                                            T* __restrict__ out, int64_t H, int include_self, T empty_val) {
   using A = typename elem<T>::acc;
   constexpr int CW = RUA_WAVE * EPL;
   const bool keep = include_self == 2 && U.len <= 0;
   const bool inc = include_self == 1;
-  if (U.colok && U.rsub == 0 && !keep) {
+  if (U.colok && (RANKS || U.rsub == 0) && !keep) {
     const int64_t cnt = U.len + (inc ? 1 : 0);
 #pragma unroll
     for (int ce = 0; ce < EPL * CPW; ++ce) {
@@ -442,6 +452,29 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
     fold_store<T, EPL, OP, CPW>(U, f, out, H, include_self, empty_val);
   }
   fold_extreme<A, NE, OP>(f, extreme, wid, lane, U.len > 0);
+}
+
+// reduce over a PackedSequence with narrow rows: adjacent ranks side by side (see make_unit)
+template <typename T, int EPL, int OP, bool NT>
+__global__ __launch_bounds__(RUA_WAVE) void seg_reduce_ranks_kernel(rua_layout L, const T* __restrict__ data,
+                                                                    T* __restrict__ out, int64_t H, int lp_log2,
+                                                                    int include_self, T empty_val,
+                                                                    unsigned long long* __restrict__ extreme) {
+  using A = typename elem<T>::acc;
+  const int lane = threadIdx.x;
+  const Unit<T, EPL> U = make_unit<T, EPL, false, 1, true>(L, L, nullptr, blockIdx.x, 0, H, lp_log2, lane);
+  int64_t t_hi = U.len;                       // the wave walks to its longest sequence
+#pragma unroll
+  for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {
+    const int64_t o = __shfl_xor(t_hi, d, RUA_WAVE);
+    t_hi = o > t_hi ? o : t_hi;
+  }
+  Fold<A, EPL> f;
+  fold_init<A, EPL, OP>(f);
+  fold_rows<T, EPL, OP, NT, false, 1, true>(U, 0, t_hi, data, H, f, L, nullptr, lane);
+  fold_wave<A, EPL, OP, true>(f, lp_log2);
+  fold_store<T, EPL, OP, 1, true>(U, f, out, H, include_self, empty_val);
+  fold_extreme<A, EPL, OP>(f, extreme, blockIdx.x, lane, t_hi > 0);
 }
 
 // the published parts 1.. of long sequences
@@ -806,6 +839,34 @@ static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int
   static const rua_layout none = {};
   const rua_layout& cd = copy ? *CD : none;
   if (copy && !vec_ok) return RUA_EALIGN;   // fused pack + reduce: vector path only (caller falls back to two launches)
+  if (L.kind == RUA_PACK && L.sorted && !copy && !perm && lp_log2 < 6 && !(split > 0 && ws)) {
+    // narrow rows of a PackedSequence: adjacent ranks share a wave instruction
+    const int64_t rpw = RUA_WAVE >> lp_log2;
+    const int64_t nblk = (L.B + rpw - 1) / rpw;
+    if (nblk > 0x7fffffffLL) return RUA_ERANGE;
+    T ev;
+    __builtin_memcpy(&ev, &empty_bits, sizeof(T));
+    const dim3 gg((unsigned)nblk), bb(RUA_WAVE);
+    unsigned long long* ext = (unsigned long long*)extreme;
+#define RUA_RANKS(EPLV, NTV, OPV)                                                                                  \
+  hipLaunchKernelGGL((seg_reduce_ranks_kernel<T, EPLV, OPV, NTV>), gg, bb, 0, s, L, (const T*)data, (T*)out, H,    \
+                     lp_log2, include_self, ev, ext)
+#define RUA_RANKS_OP(EPLV, NTV)                                  \
+  switch (op) {                                                  \
+    case RUA_SUM: RUA_RANKS(EPLV, NTV, RUA_SUM); break;          \
+    case RUA_MEAN: RUA_RANKS(EPLV, NTV, RUA_MEAN); break;        \
+    case RUA_MAX: RUA_RANKS(EPLV, NTV, RUA_MAX); break;          \
+    case RUA_MIN: RUA_RANKS(EPLV, NTV, RUA_MIN); break;          \
+    case RUA_PROD: RUA_RANKS(EPLV, NTV, RUA_PROD); break;        \
+    case RUA_LOGSUMEXP: RUA_RANKS(EPLV, NTV, RUA_LOGSUMEXP); break; \
+    default: return RUA_EINVAL;                                  \
+  }
+    if (vec_ok) { if (nt) { RUA_RANKS_OP(FULL, true) } else { RUA_RANKS_OP(FULL, false) } }
+    else { RUA_RANKS_OP(1, false) }
+#undef RUA_RANKS_OP
+#undef RUA_RANKS
+    return (int)hipGetLastError();
+  }
 #define RUA_GO(EPLV, NTV, COPYV, CPWV)                                                                             \
   return launch_reduce<T, EPLV, NTV, COPYV, CPWV>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self, \
                                                   empty_bits, extreme, cd, copy, split, ws)
