@@ -275,10 +275,14 @@ def lay_pack(p, lens: Optional[Tensor] = None, len_add: int = 0, boff: Optional[
     n_rows = int(p.data.size(0)) if n_rows is None else n_rows
     keep = [lens, boff, p.sorted_indices, p.unsorted_indices]
     extra = {}
+    if T == p.batch_sizes.numel():      # the device copy of batch_sizes (made together with boff)
+        bsz = pack_bsz_dev(p)
+        keep.append(bsz)
+        extra['bsz'] = L.ptr(bsz)
     if row_bytes is not None and 0 < row_bytes <= NARROW_ROW_BYTES and T == p.batch_sizes.numel() and len_add == 0:
         t = pack_tiling(p)       # narrow rows: hand the (rank x time) tile table to the mover
         keep += [t.bsz, t.tile_start]
-        extra = dict(bsz=L.ptr(t.bsz), tile_start=L.ptr(t.tile_start), n_tchunks=t.n_tchunks, n_tiles=t.n_tiles)
+        extra.update(bsz=L.ptr(t.bsz), tile_start=L.ptr(t.tile_start), n_tchunks=t.n_tchunks, n_tiles=t.n_tiles)
     return Lay(keep, max_len=T, kind=L.PACK, n_rows=n_rows, B=pack_B(p),
                lens=L.ptr(lens), len_add=len_add, boff=L.ptr(boff), T=T, sorted=L.ptr(p.sorted_indices),
                unsorted=L.ptr(p.unsorted_indices), **extra)

@@ -77,12 +77,28 @@ __global__ __launch_bounds__(MOVE_BLOCK) void move_rows_kernel(rua_layout D, rua
   const int nrows = left < MOVE_TILE ? (int)left : MOVE_TILE;
 
   // ---- phase 1: one lane per destination row
+  const bool same_pack = !SCATTER && D.kind == RUA_PACK && S.kind == RUA_PACK && D.bsz && D.boff == S.boff &&
+                         D.sorted == S.sorted && D.len_add == 0 && S.len_add == 0 && D.T == S.T;
   {
     const int i = threadIdx.x;
     if (i < nrows) {
       const int64_t j = tile0 + i;
       int64_t b, t, other = -1;
-      if (row_to_token(D, j, b, t)) {
+      if (same_pack) {
+        // roll / rev inside ONE PackedSequence: the rank r of a row is its own source rank, and its length is
+        // #{t : bsz[t] > r} — a search in the (L1-resident) batch_sizes instead of two random gathers per row
+        t = search_boff(D.boff, D.T, j);
+        const int64_t r = j - D.boff[t];
+        int64_t lo = 0, hi = D.T;
+        while (lo < hi) {
+          const int64_t mid = (lo + hi) >> 1;
+          if (D.bsz[mid] > r) lo = mid + 1; else hi = mid;
+        }
+        const int64_t len = lo;
+        const int64_t ts = apply_tmap(tmap, targ, t, len, len);
+        if (ts >= 0 && ts < len) other = S.boff[ts] + r;
+        if (other >= S.n_rows) other = -1;
+      } else if (row_to_token(D, j, b, t)) {
         // caller-supplied (batch_ptr, token_ptr) pairs are range-checked: a bad pair yields the fill /
         // is skipped instead of faulting the GPU (the reference raises an IndexError there)
         if (D.kind == RUA_LIST && (b < 0 || b >= S.B)) { b = 0; t = -1; }
