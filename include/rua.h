@@ -174,10 +174,15 @@ int rua_pack_reduce(const rua_layout* src, const rua_layout* pack, const void* d
  * grad_in has the storage of `data`; rows of padded layouts that hold no token are NOT written.
  * With `perm` it is the gradient w.r.t. the SOURCE rows of scatter_* (reduce.py:6-31); include_self != 0 then
  * counts the old destination row in MEAN's divisor (MAX/MIN ties with the old row are the caller's business).
- * split_rows / ws as in rua_segment_reduce (MAX/MIN keep whole sequences: their tie count spans the sequence). */
+ * split_rows / ws as in rua_segment_reduce.
+ * ties (MAX/MIN; may be NULL): [B, H] accumulators (f32, f64 for RUA_F64) that the caller pre-sets to the ties
+ * the rows of `data` do not see (0, or 1 where the old destination row of a scatter_max/min with include_self
+ * equals `out`).  The kernel adds every sequence's own ties (integer-valued float atomics: exact), then divides
+ * the gradient by the total — which lets long sequences be split, and leaves the totals for the caller.
+ * With ties == NULL each sequence is counted and applied by one wave (no splitting for MAX/MIN). */
 int rua_segment_reduce_backward(const rua_layout* lay, const int64_t* perm, const void* data, const void* out,
                                 const void* grad_out, void* grad_in, int64_t H, int32_t dtype, int32_t op,
-                                int32_t include_self, int64_t split_rows, void* ws, void* stream);
+                                int32_t include_self, int64_t split_rows, void* ws, void* ties, void* stream);
 
 /* Patch rows of empty sequences with *extreme after rua_segment_reduce (MAX/MIN), and poison
  * every row with NaN when *extreme is NaN (the reference's initial=NaN behaviour). */

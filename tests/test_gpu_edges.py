@@ -224,7 +224,7 @@ def test_long_sequences_are_split(hidden, dtype):
             rtol = 1e-3 if name == 'prod' else 2e-5
             np.testing.assert_allclose(got.double().cpu().numpy(), ref.astype(np.float64), rtol=rtol + ulp,
                                        atol=1e-5 * scale + ulp, err_msg=f'{what} {name}')
-    # gradients through split sequences (the backward publishes parts too; max keeps whole sequences)
+    # gradients through split sequences (the backward publishes parts too)
     xf = torch.randn(sum(lens), hidden, generator=g) * 0.1     # fresh fp32 values: no ties for max
     for name, fn in (('sum', lambda t: t.sum(0)), ('mean', lambda t: t.mean(0)), ('logsumexp', lambda t: t.logsumexp(0)),
                      ('max', lambda t: t.max(0).values)):
@@ -235,6 +235,31 @@ def test_long_sequences_are_split(hidden, dtype):
         r = xf.clone().to(DEV).requires_grad_(True)
         torch.stack([fn(s_) for s_ in torch.split(r, lens)]).backward(cot)
         torch.testing.assert_close(x.grad, r.grad, rtol=1e-4, atol=1e-6, msg=f'backward {name}')
+    # max/min with ties spread over several parts of a split sequence (phased backward: count, then apply)
+    xt = torch.randint(0, 3, (sum(lens), hidden), generator=g).float()
+    for name, fn in (('max', torch.amax), ('min', torch.amin)):
+        x = xt.clone().to(DEV).requires_grad_(True)
+        out = getattr(ta, f'segment_{name}')(x, known.token_sizes)
+        cot = torch.randn(out.shape, generator=g).to(DEV)
+        out.backward(cot)
+        r = xt.clone().to(DEV).requires_grad_(True)
+        torch.stack([fn(s_, 0) for s_ in torch.split(r, lens)]).backward(cot)     # amax/amin share among ties
+        torch.testing.assert_close(x.grad, r.grad, rtol=1e-5, atol=1e-7, msg=f'tied backward {name}')
+    # scatter_max/min with include_self over huge buckets: both gradients vs torch.index_reduce
+    idx_t = torch.repeat_interleave(torch.arange(len(lens)), lt)[torch.randperm(sum(lens), generator=g)].to(DEV)
+    for name, red in (('max', 'amax'), ('min', 'amin')):
+        for inc in (True, False):
+            a = torch.randint(0, 3, (len(lens), hidden), generator=g).float().to(DEV).requires_grad_(True)
+            s_ = xt.clone().to(DEV).requires_grad_(True)
+            out = getattr(ta, f'scatter_{name}')(a, idx_t, s_, include_self=inc)
+            cot = torch.randn(out.shape, generator=g).to(DEV)
+            out.backward(cot)
+            a2, s2 = a.detach().clone().requires_grad_(True), s_.detach().clone().requires_grad_(True)
+            ref = a2.index_reduce(0, idx_t, s2, red, include_self=inc)
+            ref.backward(cot)
+            assert torch.equal(out, ref)
+            torch.testing.assert_close(s_.grad, s2.grad, rtol=1e-5, atol=1e-7, msg=f'scatter_{name} src inc={inc}')
+            torch.testing.assert_close(a.grad, a2.grad, rtol=1e-5, atol=1e-7, msg=f'scatter_{name} self inc={inc}')
     # scatter with one huge destination: forward and backward both go through the split path
     idx = torch.repeat_interleave(torch.arange(len(lens)), lt)
     perm = torch.randperm(idx.numel(), generator=g)

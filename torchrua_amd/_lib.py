@@ -57,7 +57,7 @@ SYMBOLS = {
     'rua_pack_reduce': (c_int, [POINTER(RuaLayout), POINTER(RuaLayout), c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                 c_int32, c_uint64, c_void_p, c_int64, c_void_p, c_void_p]),
     'rua_segment_reduce_backward': (c_int, [POINTER(RuaLayout), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                            c_int64, c_int32, c_int32, c_int32, c_int64, c_void_p, c_void_p]),
+                                            c_int64, c_int32, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p]),
     'rua_fill_empty': (c_int, [POINTER(RuaLayout), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     'rua_bucket_ws_elems': (c_int64, [c_int64, c_int64]),
     'rua_index_buckets': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

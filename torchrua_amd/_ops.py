@@ -179,9 +179,13 @@ class _Reduce(torch.autograd.Function):
         for d in out.shape[1:]:
             H *= d
         split, ws = split_workspace(lay, H, data.dtype, dev)
+        ties = None
+        if split and op in (L.MAX, L.MIN):     # long sequences: count ties across parts first, then apply
+            ties = torch.zeros(out.shape, dtype=torch.float64 if data.dtype == torch.float64 else torch.float32,
+                               device=dev)
         L.check(lib.rua_segment_reduce_backward(lay.ref(), None, L.ptr(data), L.ptr(out), L.ptr(grad), L.ptr(g), H,
-                                                L.DTYPES[data.dtype], op, 0, split, L.ptr(ws), L.stream_ptr(dev)),
-                'rua_segment_reduce_backward')
+                                                L.DTYPES[data.dtype], op, 0, split, L.ptr(ws), L.ptr(ties),
+                                                L.stream_ptr(dev)), 'rua_segment_reduce_backward')
         return g, None, None, None, None
 
 

@@ -17,7 +17,7 @@ __global__ void extreme_init_entry_kernel(unsigned long long* ext, int want_max_
                     const rua_layout* CD, void* copy);                                                             \
   int backward_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,           \
                       const void* out, const void* gout, void* gin, int64_t H, int extra_count, int64_t split,    \
-                      void* ws);                                                                                   \
+                      void* ws, void* ties);                                                                       \
   int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, const void* ext);
 RUA_DECL(f32) RUA_DECL(bf16) RUA_DECL(f16) RUA_DECL(f64)
 #undef RUA_DECL
@@ -29,7 +29,7 @@ extern "C" {
 
 int rua_segment_reduce_backward(const rua_layout* lay, const int64_t* perm, const void* data, const void* out,
                                 const void* grad_out, void* grad_in, int64_t H, int32_t dtype, int32_t op,
-                                int32_t include_self, int64_t split_rows, void* ws, void* stream) {
+                                int32_t include_self, int64_t split_rows, void* ws, void* ties, void* stream) {
   if (!lay || H < 0 || lay->B < 0) return RUA_EINVAL;
   if (lay->kind != RUA_CAT && lay->kind != RUA_PACK && lay->kind != RUA_LEFT && lay->kind != RUA_RIGHT)
     return RUA_EINVAL;
@@ -40,10 +40,10 @@ int rua_segment_reduce_backward(const rua_layout* lay, const int64_t* perm, cons
   if (!data || !out || !grad_out || !grad_in) return RUA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
-    case RUA_F32: return backward_f32(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self ? 1 : 0, split_rows, ws);
-    case RUA_BF16: return backward_bf16(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self ? 1 : 0, split_rows, ws);
-    case RUA_F16: return backward_f16(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self ? 1 : 0, split_rows, ws);
-    case RUA_F64: return backward_f64(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self ? 1 : 0, split_rows, ws);
+    case RUA_F32: return backward_f32(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self ? 1 : 0, split_rows, ws, ties);
+    case RUA_BF16: return backward_bf16(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self ? 1 : 0, split_rows, ws, ties);
+    case RUA_F16: return backward_f16(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self ? 1 : 0, split_rows, ws, ties);
+    case RUA_F64: return backward_f64(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self ? 1 : 0, split_rows, ws, ties);
   }
   return RUA_EINVAL;
 }

@@ -570,12 +570,18 @@ __global__ __launch_bounds__(RUA_WAVE * (COMBINE_WAVES_MAX / CPW)) void seg_redu
 //   zero-fills padded grads).
 constexpr int UNROLL_B = 4;
 
-// rows [t_lo, t_hi) of one unit (MAX/MIN need the whole sequence: ties are counted in a first walk)
-template <typename T, int EPL, int OP>
+// rows [t_lo, t_hi) of one unit.  MAX/MIN need the tie count of the WHOLE sequence:
+//   TIES == 0  self-contained: a first walk over the whole sequence counts, a second writes (t_lo/t_hi = all);
+//   TIES == 1  count only: this part's ties are added into ties[b, :] (integer-valued float atomics: exact and
+//              order-independent), nothing is written to grad_in;
+//   TIES == 2  apply only: ties[b, :] is complete (possibly including the old destination row of a
+//              scatter_max/min with include_self); one walk writes the gradient.
+template <typename T, int EPL, int OP, int TIES = 0>
 __device__ __forceinline__ void backward_unit(const Unit<T, EPL>& U, int64_t t_lo, int64_t t_hi,
                                               const T* __restrict__ data, const T* __restrict__ out,
                                               const T* __restrict__ gout, T* __restrict__ gin, int64_t H,
-                                              int extra_count, int lane) {
+                                              int extra_count, int lane,
+                                              typename elem<T>::acc* __restrict__ ties = nullptr) {
   using A = typename elem<T>::acc;
   struct alignas(sizeof(T) * EPL) Pack { T v[EPL]; };
   const int64_t b = U.b, col = U.col, len = U.len, base = U.base, tb = U.tb;
@@ -604,11 +610,18 @@ __device__ __forceinline__ void backward_unit(const Unit<T, EPL>& U, int64_t t_l
 #pragma unroll
   for (int e = 0; e < EPL; ++e) zeros[e] = (A)0;
   const bool whole = t_lo == 0 && t_hi >= len;
-  const bool two_pass = (OP == RUA_MAX || OP == RUA_MIN) || (OP == RUA_PROD && whole);
+  const bool two_pass = ((OP == RUA_MAX || OP == RUA_MIN) && TIES != 2) || (OP == RUA_PROD && whole);
+  if (TIES == 2 && colok) {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      const A c = ties[b * H + col + e];
+      g[e] = g[e] / (c > (A)0 ? c : (A)1);
+    }
+  }
   A nz[EPL];      // PROD: product of the non-zero factors
 #pragma unroll
   for (int e = 0; e < EPL; ++e) nz[e] = (A)1;
-  for (int pass = two_pass ? 0 : 1; pass < 2; ++pass) {
+  for (int pass = two_pass ? 0 : 1; pass < (TIES == 1 ? 1 : 2); ++pass) {
     A cnt[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) cnt[e] = (A)0;
@@ -671,6 +684,7 @@ __device__ __forceinline__ void backward_unit(const Unit<T, EPL>& U, int64_t t_l
 #pragma unroll
       for (int e = 0; e < EPL; ++e) {
         if (OP == RUA_PROD) zeros[e] = cnt[e];
+        else if (TIES == 1) { if (colok && rsub == 0 && cnt[e] > (A)0) atomicAdd(&ties[b * H + col + e], cnt[e]); }
         else g[e] = g[e] / (cnt[e] > (A)0 ? cnt[e] : (A)1);   // MAX/MIN: ties share the gradient equally
       }
     }
@@ -678,14 +692,16 @@ __device__ __forceinline__ void backward_unit(const Unit<T, EPL>& U, int64_t t_l
 }
 
 // SPLIT: long sequences are cut into parts like in the forward (the parts of a gradient are independent, so
-// there is nothing to combine); MAX/MIN keep whole sequences because the tie count spans the sequence.
-template <typename T, int EPL, int OP, bool SPLIT>
+// there is nothing to combine).  MAX/MIN split only in the phased form (TIES 1 then 2: the tie count spans the
+// sequence, so it is accumulated in `ties` first); with TIES == 0 they keep whole sequences.
+template <typename T, int EPL, int OP, bool SPLIT, int TIES>
 __global__ __launch_bounds__(RUA_WAVE) void seg_backward_kernel(rua_layout L, const int64_t* __restrict__ perm,
                                                                 const T* __restrict__ data,
                                                                 const T* __restrict__ out,
                                                                 const T* __restrict__ gout, T* __restrict__ gin,
                                                                 int64_t H, int lp_log2, int64_t n_chunks,
-                                                                int extra_count, SplitWs W) {
+                                                                int extra_count, SplitWs W,
+                                                                typename elem<T>::acc* __restrict__ ties) {
   const int lane = threadIdx.x;
   const int64_t wid = blockIdx.x;
   const int64_t q = wid / n_chunks;
@@ -693,7 +709,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_kernel(rua_layout L, co
   const Unit<T, EPL> U = make_unit<T, EPL, false>(L, L, perm, q, wid - q * n_chunks, H, lp_log2, lane);
   if (U.len <= 0) return;
   int64_t t_hi = U.len;
-  if (SPLIT && OP != RUA_MAX && OP != RUA_MIN && U.len > W.split) {
+  if (SPLIT && (TIES != 0 || (OP != RUA_MAX && OP != RUA_MIN)) && U.len > W.split) {
     const int64_t nparts = (U.len + W.split - 1) / W.split;
     int64_t ibase = 0;
     if (lane == 0) ibase = (int64_t)atomicAdd(&W.ctr[0], (unsigned long long)(nparts - 1));
@@ -704,16 +720,17 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_kernel(rua_layout L, co
     }
     t_hi = W.split;
   }
-  backward_unit<T, EPL, OP>(U, 0, t_hi, data, out, gout, gin, H, extra_count, lane);
+  backward_unit<T, EPL, OP, TIES>(U, 0, t_hi, data, out, gout, gin, H, extra_count, lane, ties);
 }
 
-template <typename T, int EPL, int OP>
+template <typename T, int EPL, int OP, int TIES>
 __global__ __launch_bounds__(RUA_WAVE) void seg_backward_tail_kernel(rua_layout L, const int64_t* __restrict__ perm,
                                                                      const T* __restrict__ data,
                                                                      const T* __restrict__ out,
                                                                      const T* __restrict__ gout,
                                                                      T* __restrict__ gin, int64_t H, int lp_log2,
-                                                                     int extra_count, SplitWs W) {
+                                                                     int extra_count, SplitWs W,
+                                                                     typename elem<T>::acc* __restrict__ ties) {
   const int lane = threadIdx.x;
   const int64_t n_items = (int64_t)W.ctr[0];
   for (int64_t i = blockIdx.x; i < n_items; i += gridDim.x) {
@@ -721,7 +738,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_tail_kernel(rua_layout 
     const Unit<T, EPL> U = make_unit<T, EPL, false>(L, L, perm, e[0], e[1], H, lp_log2, lane);
     const int64_t t_lo = e[2] * W.split;
     const int64_t t_hi = (t_lo + W.split < U.len) ? t_lo + W.split : U.len;
-    backward_unit<T, EPL, OP>(U, t_lo, t_hi, data, out, gout, gin, H, extra_count, lane);
+    backward_unit<T, EPL, OP, TIES>(U, t_lo, t_hi, data, out, gout, gin, H, extra_count, lane, ties);
   }
 }
 
@@ -884,47 +901,55 @@ static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int
 template <typename T, int EPL>
 static int launch_backward(int op, unsigned grid, hipStream_t s, const rua_layout& L, const int64_t* perm,
                            const void* data, const void* out, const void* gout, void* gin, int64_t H, int lp_log2,
-                           int64_t n_chunks, int extra_count, int64_t split, void* ws) {
+                           int64_t n_chunks, int extra_count, int64_t split, void* ws, void* ties) {
   using A = typename elem<T>::acc;
   const dim3 g(grid), b(RUA_WAVE);
+  const bool extreme_op = op == RUA_MAX || op == RUA_MIN;
+  const bool phased = extreme_op && ties != nullptr;        // count phase, then apply phase
   const int64_t max_u = split_max_extra(L.n_rows, split) * n_chunks;
-  const bool do_split = split > 0 && ws && max_u > 0 && op != RUA_MAX && op != RUA_MIN;
+  const bool do_split = split > 0 && ws && max_u > 0 && (!extreme_op || phased);
   SplitWs W = {};
   if (do_split) {
     if (max_u > 0x7fffffffLL) return RUA_ERANGE;
     W = carve_ws<A>(ws, max_u, split);
-    hipError_t e = hipMemsetAsync(W.ctr, 0, 4 * sizeof(unsigned long long), s);
-    if (e != hipSuccess) return (int)e;
   }
-#define RUA_LAUNCH(OP)                                                                                            \
-  if (do_split) {                                                                                                 \
-    hipLaunchKernelGGL((seg_backward_kernel<T, EPL, OP, true>), g, b, 0, s, L, perm, (const T*)data,              \
-                       (const T*)out, (const T*)gout, (T*)gin, H, lp_log2, n_chunks, extra_count, W);            \
-    hipLaunchKernelGGL((seg_backward_tail_kernel<T, EPL, OP>), dim3(split_grid(max_u)), b, 0, s, L, perm,         \
-                       (const T*)data, (const T*)out, (const T*)gout, (T*)gin, H, lp_log2, extra_count, W);      \
-  } else {                                                                                                        \
-    hipLaunchKernelGGL((seg_backward_kernel<T, EPL, OP, false>), g, b, 0, s, L, perm, (const T*)data,             \
-                       (const T*)out, (const T*)gout, (T*)gin, H, lp_log2, n_chunks, extra_count, W);            \
+  A* tp = (A*)ties;
+#define RUA_PHASE(OP, TIESV)                                                                                       \
+  {                                                                                                                \
+    if (do_split) {                                                                                                \
+      hipError_t e_ = hipMemsetAsync(W.ctr, 0, 4 * sizeof(unsigned long long), s);                                 \
+      if (e_ != hipSuccess) return (int)e_;                                                                        \
+      hipLaunchKernelGGL((seg_backward_kernel<T, EPL, OP, true, TIESV>), g, b, 0, s, L, perm, (const T*)data,      \
+                         (const T*)out, (const T*)gout, (T*)gin, H, lp_log2, n_chunks, extra_count, W, tp);        \
+      hipLaunchKernelGGL((seg_backward_tail_kernel<T, EPL, OP, TIESV>), dim3(split_grid(max_u)), b, 0, s, L, perm, \
+                         (const T*)data, (const T*)out, (const T*)gout, (T*)gin, H, lp_log2, extra_count, W, tp);  \
+    } else {                                                                                                       \
+      hipLaunchKernelGGL((seg_backward_kernel<T, EPL, OP, false, TIESV>), g, b, 0, s, L, perm, (const T*)data,     \
+                         (const T*)out, (const T*)gout, (T*)gin, H, lp_log2, n_chunks, extra_count, W, tp);        \
+    }                                                                                                              \
   }
+#define RUA_EXTREME(OP)                                       \
+  if (phased) { RUA_PHASE(OP, 1) RUA_PHASE(OP, 2) } else RUA_PHASE(OP, 0)
   switch (op) {
-    case RUA_SUM: RUA_LAUNCH(RUA_SUM); break;
-    case RUA_MEAN: RUA_LAUNCH(RUA_MEAN); break;
-    case RUA_MAX: RUA_LAUNCH(RUA_MAX); break;
-    case RUA_MIN: RUA_LAUNCH(RUA_MIN); break;
-    case RUA_PROD: RUA_LAUNCH(RUA_PROD); break;
-    case RUA_LOGSUMEXP: RUA_LAUNCH(RUA_LOGSUMEXP); break;
+    case RUA_SUM: RUA_PHASE(RUA_SUM, 0); break;
+    case RUA_MEAN: RUA_PHASE(RUA_MEAN, 0); break;
+    case RUA_MAX: RUA_EXTREME(RUA_MAX); break;
+    case RUA_MIN: RUA_EXTREME(RUA_MIN); break;
+    case RUA_PROD: RUA_PHASE(RUA_PROD, 0); break;
+    case RUA_LOGSUMEXP: RUA_PHASE(RUA_LOGSUMEXP, 0); break;
     default: return RUA_EINVAL;
   }
-#undef RUA_LAUNCH
+#undef RUA_EXTREME
+#undef RUA_PHASE
   return (int)hipGetLastError();
 }
 
 template <typename T>
 static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,
                              const void* out, const void* gout, void* gin, int64_t H, int extra_count,
-                             int64_t split, void* ws) {
+                             int64_t split, void* ws, void* ties) {
   constexpr int FULL = 16 / sizeof(T);
-  const uintptr_t ptrs = (uintptr_t)data | (uintptr_t)out | (uintptr_t)gout | (uintptr_t)gin;
+  const uintptr_t ptrs = (uintptr_t)data | (uintptr_t)out | (uintptr_t)gout | (uintptr_t)gin | (uintptr_t)ties;
   const bool vec_ok = (H % FULL == 0) && (ptrs % 16 == 0);
   const int epl = vec_ok ? FULL : 1;
   const int64_t lpr = (H + epl - 1) / epl;
@@ -935,9 +960,9 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
   if (blocks > 0x7fffffffLL) return RUA_ERANGE;
   if (vec_ok)
     return launch_backward<T, FULL>(op, (unsigned)blocks, s, L, perm, data, out, gout, gin, H, lp_log2, n_chunks,
-                                    extra_count, split, ws);
+                                    extra_count, split, ws, ties);
   return launch_backward<T, 1>(op, (unsigned)blocks, s, L, perm, data, out, gout, gin, H, lp_log2, n_chunks, extra_count,
-                               split, ws);
+                               split, ws, ties);
 }
 
 // ---- per-dtype entry points: each element type is compiled in its own translation unit
@@ -948,7 +973,7 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
                     const rua_layout* CD, void* copy);                                                             \
   int backward_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,           \
                       const void* out, const void* gout, void* gin, int64_t H, int extra_count, int64_t split,    \
-                      void* ws);                                                                                   \
+                      void* ws, void* ties);                                                                       \
   int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, const void* ext);
 RUA_DECLARE_REDUCE_DTYPE(f32)
 RUA_DECLARE_REDUCE_DTYPE(bf16)
@@ -965,8 +990,8 @@ RUA_DECLARE_REDUCE_DTYPE(f64)
   }                                                                                                                 \
   int backward_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,           \
                       const void* out, const void* gout, void* gin, int64_t H, int extra_count, int64_t split,    \
-                      void* ws) {                                                                                  \
-    return dispatch_backward<T>(op, s, L, perm, data, out, gout, gin, H, extra_count, split, ws);                  \
+                      void* ws, void* ties) {                                                                      \
+    return dispatch_backward<T>(op, s, L, perm, data, out, gout, gin, H, extra_count, split, ws, ties);            \
   }                                                                                                                 \
   int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, const void* ext) { \
     hipLaunchKernelGGL(fill_empty_kernel<T>, dim3(grid_for(L.B)), dim3(RUA_BLOCK), 0, s, L, (T*)out, H, want_max,  \

@@ -145,9 +145,9 @@ class _Scatter(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad: T):
-        """Gradient w.r.t. the source rows: ONE fused kernel walking every destination's bucket
-        (rua_segment_reduce_backward with the row indirection), except max/min with include_self, whose ties
-        involve the old destination row too.  The [S, H]-sized gradient w.r.t. `tensor` is elementwise torch."""
+        """Gradient w.r.t. the source rows: the fused kernel walking every destination's bucket
+        (rua_segment_reduce_backward with the row indirection; for max/min the tie count is seeded with the old
+        destination row when include_self).  The [S, H]-sized gradient w.r.t. `tensor` is elementwise torch."""
         tensor, index, source, out, counts = ctx.saved_tensors
         op, inc = ctx.op, ctx.include_self
         grad = grad.contiguous()
@@ -155,33 +155,33 @@ class _Scatter(torch.autograd.Function):
         touched = (counts > 0).view(view)
         untouched_pass = torch.where(touched, torch.zeros_like(grad), grad)     # rows no index names keep `tensor`
         g_src = g_ten = None
-        fused = not (inc and op in (K.MAX, K.MIN))
-        if fused:
-            dev = K.require_device(source)
-            H = 1
-            for d in out.shape[1:]:
-                H *= d
-            g_src = torch.empty_like(source)       # every source row belongs to exactly one bucket
-            split, ws = O.split_workspace(ctx.lay, H, source.dtype, dev)
-            K.check(K.load().rua_segment_reduce_backward(ctx.lay.ref(), K.ptr(ctx.perm), K.ptr(source.contiguous()),
-                                                         K.ptr(out), K.ptr(grad), K.ptr(g_src), H, K.DTYPES[source.dtype],
-                                                         op, 1 if inc else 0, split, K.ptr(ws), K.stream_ptr(dev)),
-                    'rua_segment_reduce_backward')
+        dev = K.require_device(source)
+        H = 1
+        for d in out.shape[1:]:
+            H *= d
+        ties = None
+        if op in (K.MAX, K.MIN):
+            # ties the source rows do not see: the old destination row where it equals the result.  torch's
+            # index_reduce backward counts it even when include_self=False (FunctionsManual index_reduce_backward:
+            # N = self_is_result.index_add(source_is_result)) and the reference inherits that (reduce.py:6-11),
+            # so it is reproduced here.
+            acc = torch.float64 if source.dtype == torch.float64 else torch.float32
+            ties = (tensor == out).to(acc)
+            hit_t = ties.clone() if inc else None
+        g_src = torch.empty_like(source)       # every source row belongs to exactly one bucket
+        split, ws = O.split_workspace(ctx.lay, H, source.dtype, dev)
+        K.check(K.load().rua_segment_reduce_backward(ctx.lay.ref(), K.ptr(ctx.perm), K.ptr(source.contiguous()),
+                                                     K.ptr(out), K.ptr(grad), K.ptr(g_src), H, K.DTYPES[source.dtype],
+                                                     op, 1 if inc else 0, split, K.ptr(ws), K.ptr(ties),
+                                                     K.stream_ptr(dev)), 'rua_segment_reduce_backward')
         if op == K.SUM:
             g_ten = grad if inc else None
         elif op == K.MEAN:
             n = (counts + (1 if inc else 0)).clamp_min(1).to(grad.dtype).view(view)
             g_ten = grad / n if inc else untouched_pass
         elif op in (K.MAX, K.MIN):
-            if inc:
-                hit_s = (source == out[index]).to(grad.dtype)
-                hit_t = (tensor == out).to(grad.dtype)
-                ties = torch.zeros_like(grad).index_add_(0, index, hit_s) + hit_t
-                share = grad / ties.clamp_min(1)
-                g_src = share[index] * hit_s
-                g_ten = share * hit_t
-            else:
-                g_ten = untouched_pass
+            # `ties` now holds the total tie count of every destination (the kernel added the sources' share)
+            g_ten = (grad / ties.clamp_min(1).to(grad.dtype)) * hit_t.to(grad.dtype) if inc else untouched_pass
         elif op == K.PROD:
             g_ten = grad * out / tensor if inc else untouched_pass
         else:  # LOGSUMEXP
