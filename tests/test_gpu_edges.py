@@ -245,6 +245,15 @@ def test_long_sequences_are_split(hidden, dtype):
         r = xt.clone().to(DEV).requires_grad_(True)
         torch.stack([fn(s_, 0) for s_ in torch.split(r, lens)]).backward(cot)     # amax/amin share among ties
         torch.testing.assert_close(x.grad, r.grad, rtol=1e-5, atol=1e-7, msg=f'tied backward {name}')
+    # prod with a single zero factor deep inside the longest sequence: its gradient is the product of the others
+    xp = 1.0 + torch.randn(sum(lens), hidden, generator=g) * 1e-3
+    xp[12345] = 0.0
+    x = xp.clone().to(DEV).requires_grad_(True)
+    ta.segment_prod(x, known.token_sizes).sum().backward()
+    r = xp.clone().to(DEV).requires_grad_(True)
+    torch.stack([s_.prod(0) for s_ in torch.split(r, lens)]).sum().backward()
+    torch.testing.assert_close(x.grad, r.grad, rtol=1e-3, atol=1e-6, msg='prod backward with a zero factor')
+    assert float(x.grad[12345].abs().min()) > 0.5 and float(x.grad[:20000].abs().sum(0).min()) == float(x.grad[12345].abs().min())
     # scatter_max/min with include_self over huge buckets: both gradients vs torch.index_reduce
     idx_t = torch.repeat_interleave(torch.arange(len(lens)), lt)[torch.randperm(sum(lens), generator=g)].to(DEV)
     for name, red in (('max', 'amax'), ('min', 'amin')):

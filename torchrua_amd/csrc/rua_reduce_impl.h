@@ -576,7 +576,9 @@ constexpr int UNROLL_B = 4;
 //              order-independent), nothing is written to grad_in;
 //   TIES == 2  apply only: ties[b, :] is complete (possibly including the old destination row of a
 //              scatter_max/min with include_self); one walk writes the gradient.
-template <typename T, int EPL, int OP, int TIES = 0>
+//   RANKS: as in the forward (make_unit) — the wave's row groups are adjacent ranks of a PackedSequence walking the
+//   same time steps; every group is its own sequence (per-lane len, no cross-group combine).
+template <typename T, int EPL, int OP, int TIES = 0, bool RANKS = false>
 __device__ __forceinline__ void backward_unit(const Unit<T, EPL>& U, int64_t t_lo, int64_t t_hi,
                                               const T* __restrict__ data, const T* __restrict__ out,
                                               const T* __restrict__ gout, T* __restrict__ gin, int64_t H,
@@ -604,12 +606,12 @@ __device__ __forceinline__ void backward_unit(const Unit<T, EPL>& U, int64_t t_l
   }
 
   // PROD with zeros: d/dx_i = g * prod_{j != i} x_j, which g*out/x cannot give when x_i == 0.  Whole-sequence
-  // launches (t_lo == 0 && t_hi == len) take a first walk that counts the zeros of every column and multiplies
-  // the non-zero factors, exactly torch's special case; split parts keep g*out/x (documented).
+  // launches (t_lo == 0 && t_hi == len; PROD is never split by launch_backward) take a first walk that counts the
+  // zeros of every column and multiplies the non-zero factors, exactly torch's special case.
   A zeros[EPL];   // PROD: zero factors per column (pass 0)
 #pragma unroll
   for (int e = 0; e < EPL; ++e) zeros[e] = (A)0;
-  const bool whole = t_lo == 0 && t_hi >= len;
+  const bool whole = RANKS || (t_lo == 0 && t_hi >= len);
   const bool two_pass = ((OP == RUA_MAX || OP == RUA_MIN) && TIES != 2) || (OP == RUA_PROD && whole);
   if (TIES == 2 && colok) {
 #pragma unroll
@@ -630,15 +632,15 @@ __device__ __forceinline__ void backward_unit(const Unit<T, EPL>& U, int64_t t_l
       const int64_t nxt = tblk + RUA_WAVE + lane;
       const int64_t tv_next = (tbl && nxt < t_hi) ? tbl[tb + nxt] : 0;
       const int nblk = (t_hi - tblk) < RUA_WAVE ? (int)(t_hi - tblk) : RUA_WAVE;
-      for (int k = 0; k < nblk; k += rpw * UNROLL_B) {
+      for (int k = 0; k < nblk; k += (RANKS ? 1 : rpw) * UNROLL_B) {
         int64_t row[UNROLL_B];
         Pack p[UNROLL_B];
 #pragma unroll
         for (int u = 0; u < UNROLL_B; ++u) {
-          const int tl = k + u * rpw + rsub;
+          const int tl = RANKS ? k + u : k + u * rpw + rsub;
           const int64_t tabv = __shfl(tv, tl & (RUA_WAVE - 1), RUA_WAVE);
           row[u] = -1;
-          if (colok && tl < nblk) row[u] = base + (tbl ? tabv : tblk + tl);
+          if (colok && tl < nblk && (!RANKS || tblk + tl < len)) row[u] = base + (tbl ? tabv : tblk + tl);
           if (row[u] >= U.n_rows) row[u] = -1;
         }
         const bool need_x = (OP != RUA_SUM && OP != RUA_MEAN);
@@ -674,7 +676,7 @@ __device__ __forceinline__ void backward_unit(const Unit<T, EPL>& U, int64_t t_l
       tv = tv_next;
     }
     if (pass == 0) {   // combine the row-groups of the wave
-      for (int d = 1 << lp_log2; d < RUA_WAVE; d <<= 1) {
+      for (int d = RANKS ? RUA_WAVE : (1 << lp_log2); d < RUA_WAVE; d <<= 1) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
           cnt[e] += __shfl_xor(cnt[e], d, RUA_WAVE);
@@ -740,6 +742,24 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_tail_kernel(rua_layout 
     const int64_t t_hi = (t_lo + W.split < U.len) ? t_lo + W.split : U.len;
     backward_unit<T, EPL, OP, TIES>(U, t_lo, t_hi, data, out, gout, gin, H, extra_count, lane, ties);
   }
+}
+
+// backward over a PackedSequence with narrow rows: adjacent ranks side by side (see seg_reduce_ranks_kernel)
+template <typename T, int EPL, int OP>
+__global__ __launch_bounds__(RUA_WAVE) void seg_backward_ranks_kernel(rua_layout L, const T* __restrict__ data,
+                                                                      const T* __restrict__ out,
+                                                                      const T* __restrict__ gout,
+                                                                      T* __restrict__ gin, int64_t H, int lp_log2) {
+  const int lane = threadIdx.x;
+  const Unit<T, EPL> U = make_unit<T, EPL, false, 1, true>(L, L, nullptr, blockIdx.x, 0, H, lp_log2, lane);
+  int64_t t_hi = U.len;                       // the wave walks to its longest sequence
+#pragma unroll
+  for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {
+    const int64_t o = __shfl_xor(t_hi, d, RUA_WAVE);
+    t_hi = o > t_hi ? o : t_hi;
+  }
+  if (t_hi <= 0) return;
+  backward_unit<T, EPL, OP, 0, true>(U, 0, t_hi, data, out, gout, gin, H, 0, lane);
 }
 
 // extreme scratch: [0..63] hashed ordered-bit slots, [64] NaN flag (initialised by rua_reduce.hip)
@@ -907,7 +927,9 @@ static int launch_backward(int op, unsigned grid, hipStream_t s, const rua_layou
   const bool extreme_op = op == RUA_MAX || op == RUA_MIN;
   const bool phased = extreme_op && ties != nullptr;        // count phase, then apply phase
   const int64_t max_u = split_max_extra(L.n_rows, split) * n_chunks;
-  const bool do_split = split > 0 && ws && max_u > 0 && (!extreme_op || phased);
+  // PROD keeps whole sequences: its zero-factor special case needs the zero count and the product of the other
+  // factors of the whole sequence, and a product combined by atomics would not be reproducible
+  const bool do_split = split > 0 && ws && max_u > 0 && (!extreme_op || phased) && op != RUA_PROD;
   SplitWs W = {};
   if (do_split) {
     if (max_u > 0x7fffffffLL) return RUA_ERANGE;
@@ -958,6 +980,30 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
   const int64_t n_chunks = (lpr + RUA_WAVE - 1) / RUA_WAVE;
   const int64_t blocks = L.B * n_chunks;
   if (blocks > 0x7fffffffLL) return RUA_ERANGE;
+  if (L.kind == RUA_PACK && L.sorted && !perm && !ties && lp_log2 < 6 && !(split > 0 && ws) && !extra_count) {
+    // narrow rows of a PackedSequence: adjacent ranks share a wave instruction
+    const int64_t rpw = RUA_WAVE >> lp_log2;
+    const int64_t nblk = (L.B + rpw - 1) / rpw;
+    if (nblk > 0x7fffffffLL) return RUA_ERANGE;
+    const dim3 gg((unsigned)nblk), bb(RUA_WAVE);
+#define RUA_BRANKS(EPLV, OPV)                                                                                     \
+  hipLaunchKernelGGL((seg_backward_ranks_kernel<T, EPLV, OPV>), gg, bb, 0, s, L, (const T*)data, (const T*)out,   \
+                     (const T*)gout, (T*)gin, H, lp_log2)
+#define RUA_BRANKS_OP(EPLV)                                     \
+  switch (op) {                                                 \
+    case RUA_SUM: RUA_BRANKS(EPLV, RUA_SUM); break;             \
+    case RUA_MEAN: RUA_BRANKS(EPLV, RUA_MEAN); break;           \
+    case RUA_MAX: RUA_BRANKS(EPLV, RUA_MAX); break;             \
+    case RUA_MIN: RUA_BRANKS(EPLV, RUA_MIN); break;             \
+    case RUA_PROD: RUA_BRANKS(EPLV, RUA_PROD); break;           \
+    case RUA_LOGSUMEXP: RUA_BRANKS(EPLV, RUA_LOGSUMEXP); break; \
+    default: return RUA_EINVAL;                                 \
+  }
+    if (vec_ok) { RUA_BRANKS_OP(FULL) } else { RUA_BRANKS_OP(1) }
+#undef RUA_BRANKS_OP
+#undef RUA_BRANKS
+    return (int)hipGetLastError();
+  }
   if (vec_ok)
     return launch_backward<T, FULL>(op, (unsigned)blocks, s, L, perm, data, out, gout, gin, H, lp_log2, n_chunks,
                                     extra_count, split, ws, ties);
