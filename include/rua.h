@@ -143,10 +143,12 @@ enum rua_op {
  * `perm` (may be NULL) indirects CAT rows: row = perm[off[b]+t] — the sorted-by-destination
  * form of scatter_* (reduce.py:6-31).
  * Empty sequence -> `empty_bits` (the reference's `initial`: 0, 1, or the global min/max).
- * If `extreme` != NULL (MAX/MIN only) the kernel also folds every element it reads into
- * *extreme (65 uint64 of scratch, initialised by the library) so that the reference's
- * `initial = tensor.min()` (reduce.py:35,40) costs no extra pass; rua_fill_empty then
- * patches the empty segments.
+ * If `extreme` != NULL (MAX/MIN/LOGSUMEXP; 65 uint64 of scratch, initialised by the library) the call reproduces
+ * the reference's `initial = tensor.min()` / `.max()` (reduce.py:35,40,57) without its extra pass over the data:
+ * the reduce only raises flags in extreme[64] — bit 0: some element is NaN (then `initial` is NaN and poisons every
+ * segment), bit 1: some segment is empty — and a second walk for the global extreme (into extreme[0..63]) runs, on
+ * the device's own decision, only when a segment is empty.  rua_fill_empty then patches the output; with no NaN
+ * and no empty segment (the common case) both extra launches exit at once.
  * include_self: 0 overwrite | 1 `out` already holds values that take part (scatter_* include_self) |
  *               2 rows of empty sequences are left untouched (torch.index_reduce semantics).
  * split_rows > 0 (with `ws` of rua_reduce_ws_bytes(lay->n_rows, H, dtype, split_rows) bytes) cuts sequences
@@ -184,8 +186,8 @@ int rua_segment_reduce_backward(const rua_layout* lay, const int64_t* perm, cons
                                 const void* grad_out, void* grad_in, int64_t H, int32_t dtype, int32_t op,
                                 int32_t include_self, int64_t split_rows, void* ws, void* ties, void* stream);
 
-/* Patch rows of empty sequences with *extreme after rua_segment_reduce (MAX/MIN), and poison
- * every row with NaN when *extreme is NaN (the reference's initial=NaN behaviour). */
+/* After rua_segment_reduce / rua_pack_reduce with `extreme` (MAX/MIN/LOGSUMEXP): write the global extreme into the
+ * rows of empty sequences, or NaN into every row when the NaN flag is up (the reference's initial=NaN behaviour). */
 int rua_fill_empty(const rua_layout* lay, void* out, int64_t H, int32_t dtype, int32_t op,
                    const void* extreme, void* stream);
 

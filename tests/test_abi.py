@@ -98,12 +98,17 @@ def test_reducer_split_policy():
             self.n_rows, self.B, self.max_len = n_rows, B, max_len
 
     ns = FakeLay(17_046_960, 65536, 512)               # north-star shape: nothing to split
-    assert M.reduce_split_rows(ns) == 0
-    assert M.reduce_split_rows(FakeLay(34_000_000, 65536, 1024)) == 0          # cfg4
-    assert M.reduce_split_rows(FakeLay(1_131_008, 2048, 1_000_000)) == 256     # one giant sequence
-    assert M.reduce_split_rows(FakeLay(100_000_000, 64, 5_000_000)) == 4096
-    assert M.reduce_split_rows(FakeLay(536_149, 16384, None)) == 0             # cfg3, device-only lengths
-    assert M.reduce_split_rows(FakeLay(5_000_000, 100, None)) == 610           # few long sequences, lengths unknown
-    assert M.reduce_split_rows(FakeLay(200, 3, 150)) == 0
+    assert M.reduce_split_rows(ns, 1024) == 0
+    assert M.reduce_split_rows(FakeLay(34_000_000, 65536, 1024), 2048) == 0    # cfg4
+    assert M.reduce_split_rows(FakeLay(1_070_000, 4096, 512), 512) == 0        # cfg2: LPT hides 512-row sequences
+    assert M.reduce_split_rows(FakeLay(133_000, 512, 512), 1024) == 64         # few units: fill the chip
+    assert M.reduce_split_rows(FakeLay(533_000, 2048, 512), 128) == 0          # narrow rows: the longest walk is 16 us
+    assert 64 <= M.reduce_split_rows(FakeLay(1_131_008, 2048, 1_000_000), 1024) <= 256   # one giant sequence
+    assert M.reduce_split_rows(FakeLay(100_000_000, 64, 5_000_000), 1024) == 4096
+    assert M.reduce_split_rows(FakeLay(536_149, 16384, None), 1024) == 0       # cfg3, device-only lengths
+    assert M.reduce_split_rows(FakeLay(5_000_000, 100, None), 1024) == 610     # few long sequences, lengths unknown
+    blind = M.reduce_split_rows(FakeLay(1_070_000, 4096, None), 512)           # cfg2 with device-only lengths:
+    assert blind > 512                                                         # armed, but nothing of cfg2 is cut
+    assert M.reduce_split_rows(FakeLay(200, 3, 150), 1024) == 0
     t = torch.tensor([3, 9, 2])
     assert M.known_max_len(t) == 9 and M.known_max_len(None) is None

@@ -71,6 +71,33 @@ def test_reduce_any_width_dtype_layout(lens, h, dtype, name, kind):
     np.testing.assert_allclose(out.double().cpu().numpy(), ref.astype(np.float64), rtol=1e-5 + ulp, atol=1e-5 + ulp)
 
 
+@pytest.mark.parametrize('h,dtype', [(16, torch.bfloat16), (24, torch.float32), (3, torch.float32)])
+def test_reduce_packed_many_narrow_sequences(h, dtype):
+    """Enough narrow-row sequences that reduce(P) and its backward take the adjacent-rank kernels
+    (B / ranks-per-wave >= 4096 waves): forward vs the oracle, backward vs the same op over the C layout."""
+    B = 140_000 if h != 24 else 40_000
+    g = torch.Generator().manual_seed(h)
+    lt = torch.randint(1, 6, (B,), generator=g)
+    data = (torch.randn(int(lt.sum()), h, generator=g) * 0.5).to(dtype)
+    f = data.float().numpy()
+    ulp = {torch.float32: 0.0, torch.bfloat16: 2.0 ** -8}[dtype]
+    c = ta.with_host_sizes(data.to(DEV), lt)
+    p = c.pack()
+    for name in ('sum', 'mean', 'max', 'min', 'prod', 'logsumexp'):
+        ref = getattr(orc, f'segment_{name}')(f, lt.numpy())
+        xp = p.data.detach().clone().requires_grad_(True)
+        out = getattr(ta, f'reduce_{name}')(p._replace(data=xp))
+        np.testing.assert_allclose(out.detach().double().cpu().numpy(), ref.astype(np.float64), rtol=1e-5 + ulp,
+                                   atol=1e-5 + ulp, err_msg=name)
+        cot = torch.randn(out.shape, generator=g).to(dtype).to(DEV)
+        out.backward(cot)
+        xc = c.data.detach().clone().requires_grad_(True)
+        getattr(ta, f'segment_{name}')(xc, c.token_sizes).backward(cot)
+        # the gradient of the packed rows, brought back to C order, is the gradient over the C layout
+        back = p._replace(data=xp.grad).cat().data
+        torch.testing.assert_close(back.float(), xc.grad.float(), rtol=1e-5 + 4 * ulp, atol=1e-6 + 4 * ulp, msg=name)
+
+
 def test_zero_length_segments_and_initial():
     """Empty segments take the reference's `initial`: 0 / 1 / the GLOBAL min (max) resp. max (min)."""
     lens = [0, 3, 0, 0, 2, 5, 0]
@@ -200,8 +227,9 @@ def test_long_sequences_are_split(hidden, dtype):
     ulp = {torch.float32: 0.0, torch.float64: 0.0, torch.bfloat16: 2.0 ** -8}[dtype]
     known = ta.with_host_sizes(data.to(DEV), lt)          # host mirror: the split is chosen from max(len)
     blind = ta.C(data.to(DEV), lt.to(DEV))                # device-only lengths: armed by the heuristic
-    assert M.reduce_split_rows(M.lay_cat(known.token_sizes, len(lens), sum(lens))) == M.SPLIT_MIN_ROWS
-    assert M.reduce_split_rows(M.lay_cat(blind.token_sizes, len(lens), sum(lens))) == M.SPLIT_MIN_ROWS
+    rb = hidden * data.element_size()
+    part = M.reduce_split_rows(M.lay_cat(known.token_sizes, len(lens), sum(lens)), rb)
+    assert 0 < part < 20000 and part == M.reduce_split_rows(M.lay_cat(blind.token_sizes, len(lens), sum(lens)), rb)
     p = known.pack()
     for name in ('sum', 'mean', 'max', 'min', 'logsumexp', 'prod'):
         src = f if name != 'prod' else np.where(np.abs(f) > 0, 1.0 + f * 1e-3, 1.0).astype(f.dtype)

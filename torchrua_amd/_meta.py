@@ -360,20 +360,39 @@ def row_bytes(data: Tensor, lead: int) -> int:
 
 
 # ------------------------------------------------------------------ long-sequence splitting of the reducer
-SPLIT_ROWS = 4096      # upper bound on rows per part
-SPLIT_MIN_ROWS = 256   # lower bound: a part still streams 256 KiB at 1 KiB rows, partials stay < 2 % of traffic
-FILL_WAVES = 8192      # 256 CUs x 32 waves
+SPLIT_ROWS = 4096            # upper bound on rows per part
+SPLIT_MIN_BYTES = 64 << 10   # lower bound on a part's bytes per wave: its 4-KiB fp32 partial stays a few % of traffic
+SPLIT_MIN_ROWS = 32
+FILL_WAVES = 8192            # 256 CUs x 32 waves
+ENOUGH_UNITS = 4096          # (sequence, column chunk) units that keep every SIMD busy without splitting
+WAVE_RATE = 4e9              # bytes/s ONE wave streams (8 KiB in flight / ~2 us; profiles/r01_skew.txt)
+STREAM_RATE = 5e12           # bytes/s the whole chip reads through the reducer
+SPLIT_FIXED_S = 30e-6        # what arming costs: one memset, a tail and a combine launch
 
 
-def reduce_split_rows(lay: Lay) -> int:
-    """Rows per part for rua_segment_reduce, or 0 (= one wave streams each whole sequence, ~4 GB/s per wave).
-    The part size is chosen so that even ONE sequence holding all the rows yields enough parts to fill the
-    chip (n_rows / 8192, clamped to [256, 4096]); sequences no longer than that are never split.  When the
-    host does not know the longest sequence (device-only lengths) the machinery (one memset + two near-empty
-    launches) is armed only where a tail could matter: long average sequences or few of them."""
-    target = max(SPLIT_MIN_ROWS, min(SPLIT_ROWS, lay.n_rows // FILL_WAVES))
-    if lay.n_rows <= target:
+def reduce_split_rows(lay: Lay, row_bytes: int = 1024) -> int:
+    """Rows per part for rua_segment_reduce, or 0 (= one wave streams each whole sequence).
+
+    Splitting pays only when the longest sequence would show: one wave walks a sequence at ~WAVE_RATE, the balanced
+    chip needs n_rows*row_bytes/STREAM_RATE for everything, so a sequence is a problem when
+    len * min(row_bytes, 1 KiB) / WAVE_RATE exceeds ~3/4 of that (`ideal_rows`) plus the fixed cost of the
+    machinery (`fixed_rows`).  Measured on the mid-size BASELINE shapes (profiles/r01_mid_sizes.txt): splitting sequences that
+    do not need it halves the rate.  The part size fills the chip (n_rows / 8192) when there are few units, and is
+    raised to that threshold when there are plenty, so that only real outliers are cut.  When the host does not know
+    the longest sequence (device-only lengths) the machinery is armed only where a tail could matter: long average
+    sequences or few of them."""
+    n = lay.n_rows
+    rb_unit = max(1, min(int(row_bytes), 1024))        # wider rows: 4 KiB per wave, 4x the loads in flight
+    n_chunks = -(-int(row_bytes) // (1024 if row_bytes <= 1024 else 4096)) if row_bytes > 0 else 1
+    ideal_rows = int(0.75 * n * row_bytes / STREAM_RATE * WAVE_RATE / rb_unit)   # rows a wave walks in 3/4 of the balanced time
+    fixed_rows = int(SPLIT_FIXED_S * WAVE_RATE / rb_unit)
+    part_min = max(SPLIT_MIN_ROWS, SPLIT_MIN_BYTES // rb_unit)
+    part = max(part_min, min(SPLIT_ROWS, n // FILL_WAVES))
+    if max(lay.B, 1) * n_chunks >= ENOUGH_UNITS:
+        part = max(part, min(SPLIT_ROWS, ideal_rows + fixed_rows))
+    if n <= part:
         return 0
     if lay.max_len is not None:
-        return target if lay.max_len > target else 0
-    return target if (lay.n_rows >= 256 * max(lay.B, 1) or lay.B < 1024) else 0
+        # worth it when the longest walk exceeds what remains after splitting (a part, or the balanced time) + the fixed cost
+        return part if lay.max_len > max(part, ideal_rows) + fixed_rows else 0
+    return part if (n >= 256 * max(lay.B, 1) or lay.B < 1024) else 0

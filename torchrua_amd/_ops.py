@@ -117,7 +117,7 @@ def _bits(value: float, dtype: torch.dtype) -> int:
 
 def split_workspace(lay: M.Lay, H: int, dtype: torch.dtype, dev) -> Tuple[int, Optional[Tensor]]:
     """(split_rows, workspace) for the reducer's long-sequence splitting (0, None when it is off)."""
-    split = M.reduce_split_rows(lay)
+    split = M.reduce_split_rows(lay, H * torch.empty((), dtype=dtype).element_size())
     if not split:
         return 0, None
     nbytes = L.load().rua_reduce_ws_bytes(lay.n_rows, H, L.DTYPES[dtype], split)

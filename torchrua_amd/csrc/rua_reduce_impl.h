@@ -47,8 +47,10 @@ template <> __device__ __forceinline__ float acc_inf<float>() { return __builtin
 template <> __device__ __forceinline__ double acc_inf<double>() { return __builtin_inf(); }
 
 // NaN-propagating max/min (torch.segment_reduce / index_reduce semantics)
-template <typename A> __device__ __forceinline__ A nmax(A a, A b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
-template <typename A> __device__ __forceinline__ A nmin(A a, A b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
+// — IEEE-754-2019 maximum/minimum: ONE v_maximum3_f32 / v_minimum3_f32 on gfx950, so the hot loops need no NaN
+// side-tracking
+template <typename A> __device__ __forceinline__ A nmax(A a, A b) { return __builtin_elementwise_maximum(a, b); }
+template <typename A> __device__ __forceinline__ A nmin(A a, A b) { return __builtin_elementwise_minimum(a, b); }
 
 // NaN-ignoring max/min (one v_max_f32 / v_min_f32)
 __device__ __forceinline__ float fmaxx(float a, float b) { return fmaxf(a, b); }
@@ -96,7 +98,7 @@ struct Unit {
   int64_t q, b, chunk, col, len, base, tb, n_rows;
   const int64_t* tbl;
   int rpw, rsub, lp_log2;
-  bool colok;
+  bool colok, live;   // live: false for the padding groups of a RANKS wave past the last sequence
 };
 
 // CPW: 64-lane column chunks one wave covers per row (1, or 4 for rows wider than 1 KiB so that a whole row
@@ -127,6 +129,7 @@ __device__ __forceinline__ Unit<T, EPL> make_unit(const rua_layout& L, const rua
   u.rsub = lane >> lp_log2;
   u.col = (chunk * CPW * RUA_WAVE + (lane & ((1 << lp_log2) - 1))) * EPL;   // sub-chunk c adds c * 64 * EPL
   u.colok = u.col < H && live;
+  u.live = live;
   u.len = live ? seq_len(L, u.b) : 0;
   u.n_rows = L.n_rows;
   u.base = 0;
@@ -147,21 +150,15 @@ __device__ __forceinline__ Unit<T, EPL> make_unit(const rua_layout& L, const rua
 template <typename A, int EPL>
 struct Fold {
   A acc[EPL], aux[EPL];   // aux: running sum for LOGSUMEXP (acc holds the running max)
-  bool nan_e[EPL];
-  A ext;                  // extreme of everything read (the reference's global `initial`)
-  bool ext_nan;
 };
 
 template <typename A, int EPL, int OP>
 __device__ __forceinline__ void fold_init(Fold<A, EPL>& f) {
-  f.ext = (OP == RUA_MAX || OP == RUA_LOGSUMEXP) ? acc_inf<A>() : -acc_inf<A>();
-  f.ext_nan = false;
 #pragma unroll
   for (int e = 0; e < EPL; ++e) {
     f.acc[e] = (OP == RUA_PROD) ? (A)1 : (OP == RUA_MAX || OP == RUA_LOGSUMEXP) ? -acc_inf<A>()
              : (OP == RUA_MIN) ? acc_inf<A>() : (A)0;
     f.aux[e] = (A)0;
-    f.nan_e[e] = false;
   }
 }
 
@@ -246,10 +243,12 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
           for (int u = 0; u < UT; ++u) {
             const bool ok = row[u] >= 0 && cok;
             x[u] = ok ? elem<T>::up(p[u][c].v[e]) : -acc_inf<A>();
-            cm = fmaxx(cm, x[u]);
-            if (ok) { f.ext = fminx(f.ext, x[u]); f.ext_nan |= (x[u] != x[u]); }
+            cm = nmax(cm, x[u]);
           }
-          if (cm > f.acc[ce]) { f.aux[ce] *= fexp(f.acc[ce] - cm); f.acc[ce] = cm; }
+          // NaN-propagating and sticky: once an element is NaN the running max stays NaN (that is how the
+          // reference's NaN-poisoned `initial` is detected: fold_flags) and the sum turns NaN
+          const A nm = nmax(f.acc[ce], cm);
+          if (nm != f.acc[ce]) { f.aux[ce] *= fexp(f.acc[ce] - nm); f.acc[ce] = nm; }
           const A m = f.acc[ce];
 #pragma unroll
           for (int u = 0; u < UT; ++u)
@@ -266,11 +265,8 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
             const A x = elem<T>::up(p[u][c].v[e]);
             if (OP == RUA_SUM || OP == RUA_MEAN) f.acc[ce] += x;
             else if (OP == RUA_PROD) f.acc[ce] *= x;
-            else if (OP == RUA_MAX) {   // v_max ignores NaN: NaNs are tracked on the side (a scalar mask OR)
-              f.acc[ce] = fmaxx(f.acc[ce], x); f.nan_e[ce] |= (x != x); f.ext = fminx(f.ext, x);
-            } else if (OP == RUA_MIN) {
-              f.acc[ce] = fminx(f.acc[ce], x); f.nan_e[ce] |= (x != x); f.ext = fmaxx(f.ext, x);
-            }
+            else if (OP == RUA_MAX) f.acc[ce] = nmax(f.acc[ce], x);   // v_maximum3_f32: NaN-propagating like torch
+            else if (OP == RUA_MIN) f.acc[ce] = nmin(f.acc[ce], x);
           }
         }
       }
@@ -284,13 +280,6 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
 // lp_log2); afterwards every lane of a column holds the wave's value
 template <typename A, int EPL, int OP, bool RANKS = false>
 __device__ __forceinline__ void fold_wave(Fold<A, EPL>& f, int lp_log2) {
-  if (OP == RUA_MAX || OP == RUA_MIN) {
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      if (f.nan_e[e]) f.acc[e] = f.acc[e] - f.acc[e] + (A)__builtin_nanf("");   // torch: max/min propagate NaN
-      f.ext_nan |= f.nan_e[e];
-    }
-  }
   for (int d = RANKS ? RUA_WAVE : (1 << lp_log2); d < RUA_WAVE; d <<= 1) {   // RANKS: groups are separate sequences
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
@@ -368,27 +357,30 @@ __device__ __forceinline__ void fold_store(const Unit<T, EPL>& U, Fold<typename 
 }
 
 // one no-return integer atomic per wave into a hashed slot (the reference's global initial, reduce.py:35,40)
+// The reference's `initial` for max / min / logsumexp is a GLOBAL extreme of the data (reduce.py:35,40: tensor.min()
+// resp. tensor.max()).  It only shows in two rare cases, so the hot loops do not track it; they raise flags
+// (extreme[EXTREME_SLOTS]) instead, after the wave's fold:
+//   bit 0  some element is NaN (the running max/min is NaN-propagating, so a NaN accumulator says so; for
+//          logsumexp the accumulator is the running max, which inf - inf cannot turn NaN): `initial` is NaN and
+//          poisons EVERY segment — rua_fill_empty writes NaN everywhere;
+//   bit 1  some segment is empty: seg_extreme_kernel (launched after the reduce, exits at once otherwise) takes a
+//          second walk over the data for the global extreme, rua_fill_empty writes it into the empty segments.
+// The flag word is read before the atomic: once it is set nobody touches it again.
 template <typename A, int EPL, int OP>
-__device__ __forceinline__ void fold_extreme(Fold<A, EPL>& f, unsigned long long* __restrict__ extreme,
-                                             int64_t wid, int lane, bool any_rows) {
+__device__ __forceinline__ void fold_flags(const Fold<A, EPL>& f, unsigned long long* __restrict__ extreme,
+                                           int lane, bool empty_unit) {
   if (!(OP == RUA_MAX || OP == RUA_MIN || OP == RUA_LOGSUMEXP) || !extreme) return;
-  A ext = f.ext;
+  bool nan = false;
 #pragma unroll
-  for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {
-    const A o = __shfl_xor(ext, d, RUA_WAVE);
-    if (OP == RUA_MIN) ext = o > ext ? o : ext; else ext = o < ext ? o : ext;
-  }
-  const bool any_nan = __any(f.ext_nan);
-  if (lane == 0 && any_rows) {
-    const int slot = (int)(wid & (EXTREME_SLOTS - 1));
-    if (OP == RUA_MIN) atomicMax(&extreme[slot], (unsigned long long)ordered_bits(ext));
-    else atomicMin(&extreme[slot], (unsigned long long)ordered_bits(ext));
-    if (any_nan) atomicOr(&extreme[EXTREME_SLOTS], 1ull);
-  }
+  for (int e = 0; e < EPL; ++e) nan |= (f.acc[e] != f.acc[e]);
+  const unsigned long long want = (__any(nan) ? 1ull : 0ull) | (__any(empty_unit) ? 2ull : 0ull);
+  if (want == 0ull || lane != 0) return;
+  const unsigned long long have = __atomic_load_n(&extreme[EXTREME_SLOTS], __ATOMIC_RELAXED);
+  if ((have & want) != want) atomicOr(&extreme[EXTREME_SLOTS], want);
 }
 
 // ---- long-sequence splitting: workspace layout (int64 words unless noted)
-//   ctr[0] = published extra items, ctr[1] = long units, ctr[2] = partial slots handed out
+//   forward: ctr[0] = (long units << 32) | published extra items (one atomic per long unit); backward: ctr[0] = items
 //   long_list[max_u][4] = {q, chunk, nparts, pbase};  items[max_u][4] = {q, chunk, part, slot}
 //   partials[2*max_u][2][64*EPL] of A
 struct SplitWs {
@@ -429,11 +421,15 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
   if (SPLIT && U.len > W.split) {
     // long sequence: this wave takes part 0 and publishes the rest
     const int64_t nparts = (U.len + W.split - 1) / W.split;
-    int64_t pbase = 0, ibase = 0, li = 0;
+    // ONE returning atomic per long unit (same-address atomics serialise in L2: ~20 ns each, and a batch of
+    // moderately long sequences publishes thousands): low 32 bits count the extra parts, high 32 bits the long
+    // units; the partial slots of a unit start at (extra parts before it) + (long units before it).
+    int64_t pbase = 0, ibase = 0;
     if (lane == 0) {
-      pbase = (int64_t)atomicAdd(&W.ctr[2], (unsigned long long)nparts);
-      ibase = (int64_t)atomicAdd(&W.ctr[0], (unsigned long long)(nparts - 1));
-      li = (int64_t)atomicAdd(&W.ctr[1], 1ull);
+      const unsigned long long old = atomicAdd(&W.ctr[0], (1ull << 32) | (unsigned long long)(nparts - 1));
+      ibase = (int64_t)(old & 0xffffffffull);
+      const int64_t li = (int64_t)(old >> 32);
+      pbase = ibase + li;
       int64_t* e = W.long_list + li * 4;
       e[0] = q; e[1] = U.chunk; e[2] = nparts; e[3] = pbase;
     }
@@ -451,7 +447,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
     fold_wave<A, NE, OP>(f, lp_log2);
     fold_store<T, EPL, OP, CPW>(U, f, out, H, include_self, empty_val);
   }
-  fold_extreme<A, NE, OP>(f, extreme, wid, lane, U.len > 0);
+  fold_flags<A, NE, OP>(f, extreme, lane, U.len <= 0);
 }
 
 // reduce over a PackedSequence with narrow rows: adjacent ranks side by side (see make_unit)
@@ -474,7 +470,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_ranks_kernel(rua_layout L
   fold_rows<T, EPL, OP, NT, false, 1, true>(U, 0, t_hi, data, H, f, L, nullptr, lane);
   fold_wave<A, EPL, OP, true>(f, lp_log2);
   fold_store<T, EPL, OP, 1, true>(U, f, out, H, include_self, empty_val);
-  fold_extreme<A, EPL, OP>(f, extreme, blockIdx.x, lane, t_hi > 0);
+  fold_flags<A, EPL, OP>(f, extreme, lane, U.live && U.len <= 0);
 }
 
 // the published parts 1.. of long sequences
@@ -487,7 +483,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_tail_kernel(rua_layout L,
   using A = typename elem<T>::acc;
   const int lane = threadIdx.x;
   constexpr int NE = EPL * CPW;
-  const int64_t n_items = (int64_t)W.ctr[0];
+  const int64_t n_items = (int64_t)(W.ctr[0] & 0xffffffffull);
   // the grid is capped (SPLIT_GRID_CAP): every workgroup strides over the published items
   for (int64_t i = blockIdx.x; i < n_items; i += gridDim.x) {
     const int64_t* e = W.items + i * 4;
@@ -499,36 +495,25 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_tail_kernel(rua_layout L,
     fold_rows<T, EPL, OP, NT, COPY, CPW>(U, t_lo, t_hi, data, H, f, CD, copy, lane);
     fold_wave<A, NE, OP>(f, lp_log2);
     store_partial<A, NE>(W.partials, e[3], lane, f);
-    fold_extreme<A, NE, OP>(f, extreme, i, lane, true);
+    fold_flags<A, NE, OP>(f, extreme, lane, false);
   }
 }
 
-// fold the partials of every long unit and finalise.  A 16-wave workgroup per unit: wave w folds the
-// contiguous range of parts [w*per, (w+1)*per) in order (4 partials in flight), then wave 0 folds the 16
-// range results in wave order — a fixed association that depends only on the part count, so the result is
-// bitwise reproducible.
+// fold the partials of every long unit and finalise.  The grid is small (COMBINE_GRID workgroups of 16 waves) and
+// strides over the long units in two passes:
+//   pass A  units with at most COMBINE_SOLO parts — the common case of a batch with many moderately long sequences —
+//           are folded by ONE wave each, in part order (4 partials in flight); no LDS, no barrier;
+//   pass B  units with more parts take the whole workgroup: wave w folds the contiguous range of parts
+//           [w*per, (w+1)*per) in order, then wave 0 folds the 16 range results in wave order.
+// Either association depends only on the part count, so the result is bitwise reproducible.
 constexpr int COMBINE_WAVES_MAX = 16;
+constexpr int64_t RANKS_MIN_WAVES = 4096;   // adjacent-rank waves (RANKS) only when B / ranks-per-wave still fills the chip
+constexpr int COMBINE_SOLO = 32;
+constexpr int64_t COMBINE_GRID = 512;   // 2 workgroups per CU
 
-template <typename T, int EPL, int OP, int CPW>
-__global__ __launch_bounds__(RUA_WAVE * (COMBINE_WAVES_MAX / CPW)) void seg_reduce_combine_kernel(
-    rua_layout L, const int64_t* __restrict__ perm, T* __restrict__ out, int64_t H, int lp_log2, int include_self,
-    T empty_val, rua_layout CD, int copy_mode, SplitWs W) {
-  using A = typename elem<T>::acc;
-  constexpr int NE = EPL * CPW;
-  constexpr int COMBINE_WAVES = COMBINE_WAVES_MAX / CPW;   // LDS: 2 * waves * 64 * NE accumulators
-  __shared__ A s_acc[COMBINE_WAVES][RUA_WAVE * NE];
-  __shared__ A s_aux[COMBINE_WAVES][RUA_WAVE * NE];
-  const int lane = threadIdx.x & (RUA_WAVE - 1), wave = threadIdx.x >> 6;
-  const int64_t n_long = (int64_t)W.ctr[1];
-  for (int64_t j = blockIdx.x; j < n_long; j += gridDim.x) {   // block-uniform loop (capped grid)
-  __syncthreads();                                             // s_acc / s_aux are reused per unit
-  const int64_t* e = W.long_list + j * 4;
-  const int64_t nparts = e[2], pbase = e[3];
-  const int64_t per = (nparts + COMBINE_WAVES - 1) / COMBINE_WAVES;
-  const int64_t p_lo = wave * per, p_hi = (p_lo + per < nparts) ? p_lo + per : nparts;
-  Fold<A, NE> f;
-  fold_init<A, NE, OP>(f);
-  const A* P = reinterpret_cast<const A*>(W.partials);
+template <typename A, int NE, int OP>
+__device__ __forceinline__ void combine_range(Fold<A, NE>& f, const A* __restrict__ P, int64_t pbase, int64_t p_lo,
+                                              int64_t p_hi, int lane) {
   constexpr int PF = 4;
   for (int64_t p = p_lo; p < p_hi; p += PF) {
     A a2[PF][NE], x2[PF][NE];
@@ -543,21 +528,60 @@ __global__ __launch_bounds__(RUA_WAVE * (COMBINE_WAVES_MAX / CPW)) void seg_redu
     for (int u = 0; u < PF; ++u)
       if (p + u < p_hi) fold_merge<A, NE, OP>(f, a2[u], x2[u]);
   }
-#pragma unroll
-  for (int k = 0; k < NE; ++k) { s_acc[wave][lane * NE + k] = f.acc[k]; s_aux[wave][lane * NE + k] = f.aux[k]; }
-  __syncthreads();
-  if (wave == 0) {
-    for (int w = 1; w < COMBINE_WAVES; ++w) {
-      if (w * per >= nparts) break;     // ranges beyond the last part are empty
-      A a2[NE], x2[NE];
-#pragma unroll
-      for (int k = 0; k < NE; ++k) { a2[k] = s_acc[w][lane * NE + k]; x2[k] = s_aux[w][lane * NE + k]; }
-      fold_merge<A, NE, OP>(f, a2, x2);
-    }
+}
+
+template <typename T, int EPL, int OP, int CPW>
+__global__ __launch_bounds__(RUA_WAVE * (COMBINE_WAVES_MAX / CPW)) void seg_reduce_combine_kernel(
+    rua_layout L, const int64_t* __restrict__ perm, T* __restrict__ out, int64_t H, int lp_log2, int include_self,
+    T empty_val, rua_layout CD, int copy_mode, SplitWs W) {
+  using A = typename elem<T>::acc;
+  constexpr int NE = EPL * CPW;
+  constexpr int COMBINE_WAVES = COMBINE_WAVES_MAX / CPW;   // LDS: 2 * waves * 64 * NE accumulators
+  __shared__ A s_acc[COMBINE_WAVES][RUA_WAVE * NE];
+  __shared__ A s_aux[COMBINE_WAVES][RUA_WAVE * NE];
+  const int lane = threadIdx.x & (RUA_WAVE - 1), wave = threadIdx.x >> 6;
+  const int64_t n_long = (int64_t)(W.ctr[0] >> 32);
+  const A* P = reinterpret_cast<const A*>(W.partials);
+
+  // pass A: one wave per unit with few parts
+  for (int64_t j = (int64_t)blockIdx.x * COMBINE_WAVES + wave; j < n_long; j += (int64_t)gridDim.x * COMBINE_WAVES) {
+    const int64_t* e = W.long_list + j * 4;
+    const int64_t nparts = e[2], pbase = e[3];
+    if (nparts > COMBINE_SOLO) continue;
+    Fold<A, NE> f;
+    fold_init<A, NE, OP>(f);
+    combine_range<A, NE, OP>(f, P, pbase, 0, nparts, lane);
     const Unit<T, EPL> U = copy_mode ? make_unit<T, EPL, true, CPW>(L, CD, perm, e[0], e[1], H, lp_log2, lane)
                                      : make_unit<T, EPL, false, CPW>(L, CD, perm, e[0], e[1], H, lp_log2, lane);
     fold_store<T, EPL, OP, CPW>(U, f, out, H, include_self, empty_val);
   }
+
+  // pass B: the whole workgroup per unit with many parts (block-uniform loop and condition)
+  for (int64_t j = blockIdx.x; j < n_long; j += gridDim.x) {
+    const int64_t* e = W.long_list + j * 4;
+    const int64_t nparts = e[2], pbase = e[3];
+    if (nparts <= COMBINE_SOLO) continue;
+    __syncthreads();                                             // s_acc / s_aux are reused per unit
+    const int64_t per = (nparts + COMBINE_WAVES - 1) / COMBINE_WAVES;
+    const int64_t p_lo = wave * per, p_hi = (p_lo + per < nparts) ? p_lo + per : nparts;
+    Fold<A, NE> f;
+    fold_init<A, NE, OP>(f);
+    combine_range<A, NE, OP>(f, P, pbase, p_lo, p_hi, lane);
+#pragma unroll
+    for (int k = 0; k < NE; ++k) { s_acc[wave][lane * NE + k] = f.acc[k]; s_aux[wave][lane * NE + k] = f.aux[k]; }
+    __syncthreads();
+    if (wave == 0) {
+      for (int w = 1; w < COMBINE_WAVES; ++w) {
+        if (w * per >= nparts) break;     // ranges beyond the last part are empty
+        A a2[NE], x2[NE];
+#pragma unroll
+        for (int k = 0; k < NE; ++k) { a2[k] = s_acc[w][lane * NE + k]; x2[k] = s_aux[w][lane * NE + k]; }
+        fold_merge<A, NE, OP>(f, a2, x2);
+      }
+      const Unit<T, EPL> U = copy_mode ? make_unit<T, EPL, true, CPW>(L, CD, perm, e[0], e[1], H, lp_log2, lane)
+                                       : make_unit<T, EPL, false, CPW>(L, CD, perm, e[0], e[1], H, lp_log2, lane);
+      fold_store<T, EPL, OP, CPW>(U, f, out, H, include_self, empty_val);
+    }
   }
 }
 
@@ -762,12 +786,51 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_ranks_kernel(rua_layout
   backward_unit<T, EPL, OP, 0, true>(U, 0, t_hi, data, out, gout, gin, H, 0, lane);
 }
 
-// extreme scratch: [0..63] hashed ordered-bit slots, [64] NaN flag (initialised by rua_reduce.hip)
+// the rare second walk (see fold_flags): global extreme of every row the layout enumerates, into the hashed slots
+template <typename T, int EPL, bool WANT_MAX>
+__global__ __launch_bounds__(RUA_WAVE) void seg_extreme_kernel(rua_layout L, const int64_t* __restrict__ perm,
+                                                               const T* __restrict__ data, int64_t H, int lp_log2,
+                                                               int64_t n_chunks,
+                                                               unsigned long long* __restrict__ extreme) {
+  using A = typename elem<T>::acc;
+  constexpr int OP2 = WANT_MAX ? RUA_MAX : RUA_MIN;
+  const unsigned long long flags = extreme[EXTREME_SLOTS];
+  if ((flags & 2ull) == 0ull || (flags & 1ull) != 0ull) return;   // nothing is empty, or NaN decides everything
+  const int lane = threadIdx.x;
+  Fold<A, EPL> f;
+  fold_init<A, EPL, OP2>(f);
+  bool any = false;
+  for (int64_t wid = blockIdx.x; wid < L.B * n_chunks; wid += gridDim.x) {
+    const int64_t q = wid / n_chunks;
+    const Unit<T, EPL> U = make_unit<T, EPL, false>(L, L, perm, q, wid - q * n_chunks, H, lp_log2, lane);
+    if (U.len <= 0) continue;
+    fold_rows<T, EPL, OP2, false, false>(U, 0, U.len, data, H, f, L, nullptr, lane);
+    any = true;
+  }
+  if (!any) return;
+  A ext = f.acc[0];
+#pragma unroll
+  for (int e = 1; e < EPL; ++e) ext = WANT_MAX ? fmaxx(ext, f.acc[e]) : fminx(ext, f.acc[e]);
+#pragma unroll
+  for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {
+    const A o = __shfl_xor(ext, d, RUA_WAVE);
+    ext = WANT_MAX ? fmaxx(ext, o) : fminx(ext, o);
+  }
+  if (lane == 0) {
+    const int slot = (int)(blockIdx.x & (EXTREME_SLOTS - 1));
+    if (WANT_MAX) atomicMax(&extreme[slot], (unsigned long long)ordered_bits(ext));
+    else atomicMin(&extreme[slot], (unsigned long long)ordered_bits(ext));
+  }
+}
+
+// extreme scratch: [0..63] hashed ordered-bit slots, [64] flags (initialised by rua_reduce.hip)
 template <typename T>
 __global__ __launch_bounds__(RUA_BLOCK) void fill_empty_kernel(rua_layout L, T* __restrict__ out, int64_t H,
                                                                int want_max_of_data,
                                                                const unsigned long long* __restrict__ ext) {
   using A = typename elem<T>::acc;
+  const unsigned long long flags = ext[EXTREME_SLOTS];
+  if (flags == 0ull) return;                       // the common case: no NaN, no empty segment
   // decode the tracked extreme: lane i reads slot i, 6-step butterfly
   const int lane = threadIdx.x & (RUA_WAVE - 1);
   unsigned long long best = ext[lane];
@@ -776,7 +839,7 @@ __global__ __launch_bounds__(RUA_BLOCK) void fill_empty_kernel(rua_layout L, T* 
     const unsigned long long o = __shfl_xor(best, d, RUA_WAVE);
     best = want_max_of_data ? (o > best ? o : best) : (o < best ? o : best);
   }
-  const bool poison = ext[EXTREME_SLOTS] != 0ull;
+  const bool poison = (flags & 1ull) != 0ull;
   A val;
   if (sizeof(A) == 8) val = (A)unordered_f64(best); else val = (A)unordered_f32(best);
   if (poison) val = val - val + (A)__builtin_nanf("");
@@ -835,7 +898,8 @@ static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout&
                        (T*)out, H, lp_log2, n_chunks, include_self, ev, ext, CD, (T*)copy, W);                      \
     hipLaunchKernelGGL((seg_reduce_tail_kernel<T, EPL, OP, NT, COPY, CPW>), dim3(split_grid(max_u)), b, 0, s, L, perm, \
                        (const T*)data, H, lp_log2, ext, CD, (T*)copy, W);                                           \
-    hipLaunchKernelGGL((seg_reduce_combine_kernel<T, EPL, OP, CPW>), dim3(split_grid(max_u)),                     \
+    hipLaunchKernelGGL((seg_reduce_combine_kernel<T, EPL, OP, CPW>),                                                \
+                       dim3((unsigned)(max_u < COMBINE_GRID ? max_u : COMBINE_GRID)),                               \
                        dim3(RUA_WAVE * (COMBINE_WAVES_MAX / CPW)), 0, s, L, perm, (T*)out,                          \
                        H, lp_log2, include_self, ev, CD, COPY ? 1 : 0, W);                                          \
   } else {                                                                                                          \
@@ -856,9 +920,9 @@ static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout&
 }
 
 template <typename T>
-static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,
-                           void* out, int64_t H, int include_self, uint64_t empty_bits, void* extreme,
-                           int64_t split, void* ws, const rua_layout* CD = nullptr, void* copy = nullptr) {
+static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,
+                                void* out, int64_t H, int include_self, uint64_t empty_bits, void* extreme,
+                                int64_t split, void* ws, const rua_layout* CD = nullptr, void* copy = nullptr) {
   constexpr int FULL = 16 / sizeof(T);
   const bool vec_ok = (H % FULL == 0) && (((uintptr_t)data | (uintptr_t)out | (uintptr_t)copy) % 16 == 0);
   const int epl = vec_ok ? FULL : 1;
@@ -876,7 +940,9 @@ static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int
   static const rua_layout none = {};
   const rua_layout& cd = copy ? *CD : none;
   if (copy && !vec_ok) return RUA_EALIGN;   // fused pack + reduce: vector path only (caller falls back to two launches)
-  if (L.kind == RUA_PACK && L.sorted && !copy && !perm && lp_log2 < 6 && !(split > 0 && ws)) {
+  // (only when that still leaves >= 4 waves per SIMD: with fewer sequences one wave per sequence fills the chip better)
+  if (L.kind == RUA_PACK && L.sorted && !copy && !perm && lp_log2 < 6 && !(split > 0 && ws) &&
+      (L.B >> (6 - lp_log2)) >= RANKS_MIN_WAVES) {
     // narrow rows of a PackedSequence: adjacent ranks share a wave instruction
     const int64_t rpw = RUA_WAVE >> lp_log2;
     const int64_t nblk = (L.B + rpw - 1) / rpw;
@@ -917,6 +983,36 @@ static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int
 #undef RUA_GO
 }
 
+
+// the reduce, then (max / min / logsumexp with the reference's `initial`) the conditional second walk for the
+// global extreme: every workgroup of it exits on the flag word unless some segment is empty
+constexpr int64_t EXTREME_GRID = 8192;
+
+template <typename T>
+static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,
+                           void* out, int64_t H, int include_self, uint64_t empty_bits, void* extreme,
+                           int64_t split, void* ws, const rua_layout* CD = nullptr, void* copy = nullptr) {
+  const int r = dispatch_reduce_main<T>(op, s, L, perm, data, out, H, include_self, empty_bits, extreme, split, ws, CD,
+                                        copy);
+  if (r != 0 || !extreme || !(op == RUA_MAX || op == RUA_MIN || op == RUA_LOGSUMEXP)) return r;
+  constexpr int FULL = 16 / sizeof(T);
+  const bool vec_ok = (H % FULL == 0) && ((uintptr_t)data % 16 == 0);
+  const int64_t lpr = (H + (vec_ok ? FULL : 1) - 1) / (vec_ok ? FULL : 1);
+  int lp_log2 = 0;
+  while ((1 << lp_log2) < lpr && lp_log2 < 6) ++lp_log2;
+  const int64_t n_chunks = (lpr + RUA_WAVE - 1) / RUA_WAVE;
+  const int64_t units = L.B * n_chunks;
+  if (units <= 0) return 0;
+  const dim3 g((unsigned)(units < EXTREME_GRID ? units : EXTREME_GRID)), b(RUA_WAVE);
+  unsigned long long* ext = (unsigned long long*)extreme;
+#define RUA_EXT(EPLV, WMAX)                                                                                    \
+  hipLaunchKernelGGL((seg_extreme_kernel<T, EPLV, WMAX>), g, b, 0, s, L, perm, (const T*)data, H, lp_log2,     \
+                     n_chunks, ext)
+  if (op == RUA_MIN) { if (vec_ok) RUA_EXT(FULL, true); else RUA_EXT(1, true); }
+  else { if (vec_ok) RUA_EXT(FULL, false); else RUA_EXT(1, false); }
+#undef RUA_EXT
+  return (int)hipGetLastError();
+}
 
 template <typename T, int EPL>
 static int launch_backward(int op, unsigned grid, hipStream_t s, const rua_layout& L, const int64_t* perm,
@@ -980,7 +1076,8 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
   const int64_t n_chunks = (lpr + RUA_WAVE - 1) / RUA_WAVE;
   const int64_t blocks = L.B * n_chunks;
   if (blocks > 0x7fffffffLL) return RUA_ERANGE;
-  if (L.kind == RUA_PACK && L.sorted && !perm && !ties && lp_log2 < 6 && !(split > 0 && ws) && !extra_count) {
+  if (L.kind == RUA_PACK && L.sorted && !perm && !ties && lp_log2 < 6 && !(split > 0 && ws) && !extra_count &&
+      (L.B >> (6 - lp_log2)) >= RANKS_MIN_WAVES) {
     // narrow rows of a PackedSequence: adjacent ranks share a wave instruction
     const int64_t rpw = RUA_WAVE >> lp_log2;
     const int64_t nblk = (L.B + rpw - 1) / rpw;
