@@ -12,7 +12,9 @@ import torchrua_amd as ta  # noqa: E402
 
 print('threads', torch.get_num_threads(), 'cpus', os.cpu_count())
 g = torch.Generator().manual_seed(5)
-lens = torch.randint(8, 513, (65536,), generator=g)
+B = int(os.environ.get('RUA_PROBE_B', 65536))
+H = int(os.environ.get('RUA_PROBE_H', 512))
+lens = torch.randint(8, 513, (B,), generator=g)
 
 
 def t(fn, n=5):
@@ -38,7 +40,7 @@ for nt in (torch.get_num_threads(), 1):
 torch.set_num_threads(os.cpu_count())
 
 dev = torch.device('cuda:0')
-data = torch.randn(int(lens.sum()), 512, device=dev, dtype=torch.bfloat16)
+data = torch.randn(int(lens.sum()), H, device=dev, dtype=torch.bfloat16)
 
 
 def step():
@@ -47,16 +49,16 @@ def step():
     return ta.reduce_sum(p)
 
 
-for _ in range(3):
+for _ in range(10):
     step()
 torch.cuda.synchronize()
 pr = cProfile.Profile()
 pr.enable()
 t0 = time.perf_counter()
-for _ in range(5):
+for _ in range(50):
     step()
-host_ms = (time.perf_counter() - t0) / 5 * 1e3
+host_ms = (time.perf_counter() - t0) / 50 * 1e3
 torch.cuda.synchronize()
 pr.disable()
 print('host ms per step (enqueue only)', host_ms)
-pstats.Stats(pr).sort_stats('cumulative').print_stats(25)
+pstats.Stats(pr).sort_stats('cumulative').print_stats(45)

@@ -32,14 +32,19 @@ def t(name, fn):
     print(f'{name:34s} {ms:9.3f} ms  {nbytes / ms / 1e9:6.2f} TB/s')
 
 
-for split in (256, 4096, 1 << 60):
-    M.SPLIT_MIN_ROWS = min(split, 1 << 40)
-    M.SPLIT_ROWS = max(split, 4096)
-    tag = f'split {split}' if split < (1 << 40) else 'no split  '
+policy = M.reduce_split_rows
+for split in ('policy', 64, 256, 4096, 0):
+    M.reduce_split_rows = policy if split == 'policy' else (lambda lay, rb=0, s=split: s)
+    tag = f'split {split}' if split else 'no split  '
+    if split == 'policy':
+        tag += f' (= {policy(M.lay_cat(c.token_sizes, lens.numel(), data.size(0)), H * 2)})'
     t(f'segment_sum(C)  {tag}', lambda: ta.segment_sum(c.data, c.token_sizes))
     t(f'reduce_sum(P)   {tag}', lambda: ta.reduce_sum(p))
     t(f'reduce_max(P)   {tag}', lambda: ta.reduce_max(p))
+    x = c.data.detach().requires_grad_(True)
+    out = ta.segment_max(x, c.token_sizes)
+    t(f'segment_max backward  {tag}', lambda: torch.autograd.grad(out, x, torch.ones_like(out), retain_graph=True))
 a = ta.reduce_sum(p)
-M.SPLIT_MIN_ROWS, M.SPLIT_ROWS = 256, 4096
+M.reduce_split_rows = policy
 b = ta.reduce_sum(p)
 print('max |split - nosplit| =', (a.float() - b.float()).abs().max().item())

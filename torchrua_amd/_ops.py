@@ -111,13 +111,13 @@ _EMPTY = {L.SUM: 0.0, L.MEAN: 0.0, L.PROD: 1.0, L.MAX: 0.0, L.MIN: 0.0, L.LOGSUM
 
 
 def _bits(value: float, dtype: torch.dtype) -> int:
-    raw = _fill16(value, dtype)[:torch.empty((), dtype=dtype).element_size()]
+    raw = _fill16(value, dtype)[:dtype.itemsize]
     return int.from_bytes(raw, 'little')
 
 
 def split_workspace(lay: M.Lay, H: int, dtype: torch.dtype, dev) -> Tuple[int, Optional[Tensor]]:
     """(split_rows, workspace) for the reducer's long-sequence splitting (0, None when it is off)."""
-    split = M.reduce_split_rows(lay, H * torch.empty((), dtype=dtype).element_size())
+    split = M.reduce_split_rows(lay, H * dtype.itemsize)
     if not split:
         return 0, None
     nbytes = L.load().rua_reduce_ws_bytes(lay.n_rows, H, L.DTYPES[dtype], split)
