@@ -41,3 +41,22 @@ t('c.ptr()', lambda: c.ptr())
 from torch.nn.utils.rnn import pack_sequence, pad_sequence  # noqa: E402
 t('torch pad_sequence(xs)', lambda: pad_sequence(xs, batch_first=True))
 t('torch pack_sequence(xs)', lambda: pack_sequence(xs, enforce_sorted=False))
+
+
+# the same ops replayed from one HIP graph (fixed lengths, new payload copied into the static input)
+def chain():
+    q = c.pack()
+    return ta.reduce_sum(q), q.roll(1).data, q.last(), c.left().data
+
+
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    chain()
+torch.cuda.current_stream().wait_stream(side)
+torch.cuda.synchronize()
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph):
+    outs = chain()
+t('pack+reduce+roll+last+left eager', chain)
+t('the same five ops, graph.replay()', graph.replay)

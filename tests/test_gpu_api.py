@@ -130,3 +130,37 @@ print("ok")
 ''' % root
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stdout + out.stderr
+
+
+def test_ops_replay_inside_a_hip_graph():
+    """The C ABI never allocates, synchronises or reads back (include/rua.h), so once the derived index vectors of
+    a container are memoised, its ops can be captured in a HIP graph and replayed on new payload: reduce / roll /
+    last / pad / cat over fixed lengths (the launch-bound small-batch case of SURVEY §8d cfg1)."""
+    g = torch.Generator().manual_seed(11)
+    lens = torch.randint(1, 30, (64,), generator=g)
+    n = int(lens.sum())
+    static = torch.randn(n, 32, generator=g).to(DEV)
+    c = ta.with_host_sizes(static, lens)
+
+    def ops(cc):
+        p = cc.pack()
+        return ta.reduce_sum(p), ta.reduce_max(p), p.roll(1).data, p.last(), cc.left(-1.0).data, p.cat().data
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                     # warm-up on a side stream: memoises every index vector
+        for _ in range(2):
+            ops(c)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        outs = ops(c)
+    for seed in (1, 2):
+        fresh = torch.randn(n, 32, generator=torch.Generator().manual_seed(seed)).to(DEV)
+        static.copy_(fresh)
+        graph.replay()
+        torch.cuda.synchronize()
+        want = ops(ta.with_host_sizes(fresh, lens))
+        for got, exp in zip(outs, want):
+            assert torch.equal(got, exp)
