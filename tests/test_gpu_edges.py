@@ -125,6 +125,38 @@ def test_nan_semantics_match_reference():
         np.testing.assert_allclose(out[~np.isnan(ref)], ref[~np.isnan(ref)], rtol=1e-6)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('lens', [[2, 3, 1, 70, 4], [2, 0, 3, 1, 200, 0, 9]])
+def test_infinities_nan_and_empty_segments_like_the_reference(lens, dtype):
+    """max / min / logsumexp with -inf, +inf and NaN elements, all--inf sequences (NaN in the reference's logsumexp),
+    empty segments (the reference's global-extreme `initial`) and NaN poisoning: same NaN pattern, same values."""
+    import warnings
+    g = torch.Generator().manual_seed(sum(lens))
+    lt = torch.tensor(lens)
+    base = torch.randn(int(lt.sum()), 16, generator=g).to(dtype)
+    starts = torch.cumsum(lt, 0) - lt
+    cases = {'clean': base.clone()}
+    x = base.clone(); x[int(starts[0]):int(starts[0]) + lens[0], 3] = float('-inf'); cases['one column of a sequence all -inf'] = x
+    x = base.clone(); x[int(starts[2]) + 1, 5] = float('inf'); cases['+inf element'] = x
+    x = base.clone(); x[int(starts[3]) + 2, :] = float('-inf'); cases['a -inf row'] = x
+    x = base.clone(); x[int(starts[4]), 7] = float('nan'); cases['NaN element'] = x
+    for what, data in cases.items():
+        f = data.float().numpy()
+        for name in ('max', 'min', 'logsumexp'):
+            with warnings.catch_warnings(), np.errstate(all='ignore'):
+                warnings.simplefilter('ignore')
+                ref = getattr(orc, f'segment_{name}')(f, lt.numpy())
+            out = getattr(ta, f'segment_{name}')(data.to(DEV), lt.to(DEV)).float().cpu().numpy()
+            assert np.array_equal(np.isnan(out), np.isnan(ref)), (what, name)
+            ok = ~np.isnan(ref)
+            ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 0.0
+            np.testing.assert_allclose(out[ok], ref[ok], rtol=1e-5 + ulp, atol=1e-6, err_msg=f'{what} {name}')
+            if 0 not in lens:     # the same through a PackedSequence (zero-length sequences do not pack)
+                pk = getattr(ta, f'reduce_{name}')(ta.C(data.to(DEV), lt.to(DEV)).pack()).float().cpu().numpy()
+                assert np.array_equal(np.isnan(pk), np.isnan(ref)), (what, name, 'P')
+                np.testing.assert_allclose(pk[ok], ref[ok], rtol=1e-5 + ulp, atol=1e-6, err_msg=f'{what} {name} P')
+
+
 def test_non_contiguous_and_views():
     data, lt = _mk([4, 2, 5, 1], (8,), torch.float32)
     wide = torch.randn(12, 16, device=DEV)

@@ -232,27 +232,37 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
       }
       if (OP == RUA_LOGSUMEXP) {
         // chunk-wise online logsumexp: the chunk's max first, ONE rescale of the running sum per
-        // chunk, then one exp per element
+        // chunk, then one exp per element.  Rows that are not there are made -inf ONCE per 16-byte load (not
+        // per element: the per-element selects used to cost as many issue slots as the arithmetic): they can
+        // never raise the maximum and add exp(-inf - m) = 0.
+        Pack ninf;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) ninf.v[e] = elem<T>::down(-acc_inf<A>());
+#pragma unroll
+        for (int u = 0; u < UT; ++u)
+#pragma unroll
+          for (int c = 0; c < CPW; ++c)
+            if (!(row[u] >= 0 && (CPW == 1 || col + c * CW < H))) p[u][c] = ninf;
 #pragma unroll
         for (int ce = 0; ce < EPL * CPW; ++ce) {
           const int c = ce / EPL, e = ce % EPL;
-          const bool cok = CPW == 1 || col + c * CW < H;
           A x[UT];
           A cm = -acc_inf<A>();
 #pragma unroll
           for (int u = 0; u < UT; ++u) {
-            const bool ok = row[u] >= 0 && cok;
-            x[u] = ok ? elem<T>::up(p[u][c].v[e]) : -acc_inf<A>();
+            x[u] = elem<T>::up(p[u][c].v[e]);
             cm = nmax(cm, x[u]);
           }
           // NaN-propagating and sticky: once an element is NaN the running max stays NaN (that is how the
           // reference's NaN-poisoned `initial` is detected: fold_flags) and the sum turns NaN
           const A nm = nmax(f.acc[ce], cm);
           if (nm != f.acc[ce]) { f.aux[ce] *= fexp(f.acc[ce] - nm); f.acc[ce] = nm; }
-          const A m = f.acc[ce];
+          // a lane that has seen nothing above -inf yet subtracts 0, not -inf: -inf - -inf would turn the rows that
+          // are not there into NaN.  (A sequence whose elements are ALL -inf is NaN in the reference — exp(-inf - -inf)
+          // — and fold_store restores that from the final maximum.)
+          const A m = (f.acc[ce] == -acc_inf<A>()) ? (A)0 : f.acc[ce];
 #pragma unroll
-          for (int u = 0; u < UT; ++u)
-            if (row[u] >= 0 && cok) f.aux[ce] += fexp(x[u] - m);   // NaN x -> NaN sum; all -inf -> NaN, as the reference
+          for (int u = 0; u < UT; ++u) f.aux[ce] += fexp(x[u] - m);   // NaN x -> NaN sum, as the reference
         }
       } else {
 #pragma unroll
@@ -342,7 +352,8 @@ __device__ __forceinline__ void fold_store(const Unit<T, EPL>& U, Fold<typename 
           f.aux[ce] = f.aux[ce] * fexp(r - m) + fexp(x - m);
           r = m;
         }
-        r = flog(f.aux[ce]) + r;
+        // every element -inf: exp(-inf - -inf) = NaN in the reference (reduce.py:56-61)
+        r = (r == -acc_inf<A>() && cnt > 0) ? (A)__builtin_nanf("") : flog(f.aux[ce]) + r;
       } else if (inc) {
         const A x = elem<T>::up(o[e]);
         if (OP == RUA_SUM || OP == RUA_MEAN) r += x;
@@ -995,6 +1006,7 @@ static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int
   const int r = dispatch_reduce_main<T>(op, s, L, perm, data, out, H, include_self, empty_bits, extreme, split, ws, CD,
                                         copy);
   if (r != 0 || !extreme || !(op == RUA_MAX || op == RUA_MIN || op == RUA_LOGSUMEXP)) return r;
+  if (L.kind == RUA_PACK && !copy) return r;   // every sequence of a PackedSequence holds a token: nothing can be empty
   constexpr int FULL = 16 / sizeof(T);
   const bool vec_ok = (H % FULL == 0) && ((uintptr_t)data % 16 == 0);
   const int64_t lpr = (H + (vec_ok ? FULL : 1) - 1) / (vec_ok ? FULL : 1);
