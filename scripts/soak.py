@@ -23,14 +23,27 @@ t_end = time.time() + budget
 n = 0
 last_report = time.time()
 while time.time() < t_end:
-    B = int(rng.choice([1, 2, 7, 63, 64, 65, 255, 257, 1000, 2049, 3000]))
-    hi = int(rng.choice([1, 2, 5, 17, 63, 64, 65, 130, 300, 700]))
+    family = rng.choice(['mixed', 'long', 'many'], p=[0.7, 0.15, 0.15])
+    if family == 'mixed':
+        B = int(rng.choice([1, 2, 7, 63, 64, 65, 255, 257, 1000, 2049, 3000]))
+        hi = int(rng.choice([1, 2, 5, 17, 63, 64, 65, 130, 300, 700]))
+        H = int(rng.choice([1, 2, 3, 4, 8, 16, 24, 31, 32, 64, 96, 128, 136, 256, 520, 1024]))
+    elif family == 'long':       # few sequences, some far beyond the reducer's part size: split / tail / combine
+        B = int(rng.choice([1, 3, 11, 40]))
+        hi = int(rng.choice([3000, 9000, 30000]))
+        H = int(rng.choice([3, 8, 64, 130, 512]))
+    else:                        # so many short sequences that narrow rows take the adjacent-rank kernels
+        B = int(rng.choice([40000, 140000]))
+        hi = int(rng.choice([1, 2, 4]))
+        H = int(rng.choice([1, 2, 4, 8, 16, 24]))
     lo = int(rng.randint(1, hi + 1))
-    H = int(rng.choice([1, 2, 3, 4, 8, 16, 24, 31, 32, 64, 96, 128, 136, 256, 520, 1024]))
     dtype = [torch.float32, torch.bfloat16, torch.float16, torch.float64, torch.int64][int(rng.randint(0, 5))]
     if B * hi * H > 6e7:
         continue
     lens = torch.from_numpy(rng.randint(lo, hi + 1, size=B).astype(np.int64))
+    if family == 'long':
+        lens[rng.randint(0, B)] = hi          # at least one really long sequence next to random ones
+        lens[rng.randint(0, B)] = 1
     g = torch.Generator().manual_seed(int(rng.randint(0, 2 ** 31)))
     N = int(lens.sum())
     data = torch.randint(-99, 99, (N, H), generator=g) if dtype == torch.int64 else (torch.randn(N, H, generator=g) * 0.5).to(dtype)
@@ -61,6 +74,22 @@ while time.time() < t_end:
                 for o in outs:
                     np.testing.assert_allclose(o.double().cpu().numpy(), ref, rtol=2e-5 + ulp, atol=2e-5 * scale + ulp + 1e-6,
                                                err_msg=name)
+            if dtype in (torch.float32, torch.float64):
+                # fused backward of every layout vs autograd through torch.segment_reduce on the CPU (what the
+                # reference calls, reduce.py:34-53); ties of max/min share the gradient in both
+                name = ['sum', 'mean', 'max', 'min'][int(rng.randint(0, 4))]
+                tied = (torch.randint(0, 3, (N, H), generator=g)).to(dtype)
+                # positive cotangents: torch's segment_reduce backward shares a gradient among tied extrema only when
+                # it is > 0 (its kernel tests `grad_input > 0` to find them; DESIGN.md §5, deviations)
+                cot = (torch.rand(B, H, generator=g) + 0.1).to(dtype)
+                r = tied.clone().requires_grad_(True)
+                torch.segment_reduce(r, name, lengths=lens, unsafe=True).backward(cot)
+                for k in 'CLPR':
+                    x = tied.clone().to(DEV).requires_grad_(True)
+                    z = {'C': lambda c_: c_, 'L': lambda c_: c_.left(), 'P': lambda c_: c_.pack(),
+                         'R': lambda c_: c_.right()}[k](ta.with_host_sizes(x, lens))
+                    getattr(ta, f'reduce_{name}')(z).backward(cot.to(DEV))
+                    torch.testing.assert_close(x.grad.cpu(), r.grad, rtol=1e-5, atol=1e-6, msg=f'backward {name} {k}')
             if dtype == torch.float32 and N * H < 4e6:
                 # scatter_* over shuffled rows (both include_self values) and gradients of a reduce / a cast chain
                 index = torch.repeat_interleave(torch.arange(B), lens)
