@@ -25,23 +25,47 @@ def short(name):
     return name.split('(')[0][:80]
 
 
-rows = list(csv.DictReader(open(glob.glob(os.path.join(G, 'prof_stats', '*', '*_kernel_stats.csv'))[0])))
+def kernel_stats():
+    """Per-kernel stats from `rocprofv3 --kernel-trace --stats`: the CSV when the run wrote one, else the rocpd
+    SQLite database (ROCm 7.2's default output format)."""
+    files = glob.glob(os.path.join(G, 'prof_stats', '*', '*_kernel_stats.csv'))
+    if files:
+        return [(r['Name'], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs'])
+                for r in csv.DictReader(open(files[0]))]
+    import sqlite3
+    con = sqlite3.connect(glob.glob(os.path.join(G, 'prof_stats', '*', '*_results.db'))[0])
+    total = con.execute('select sum(duration) from kernels').fetchone()[0]
+    q = ('select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels '
+         'group by name order by sum(duration) desc')
+    return [(n, c, t, round(a, 1), round(100.0 * t / total, 4), lo, hi) for n, c, t, a, lo, hi in con.execute(q)]
+
+
+def counter_rows(kind):
+    files = glob.glob(os.path.join(G, f'prof_{kind}', '*', '*_counter_collection.csv'))
+    if files:
+        return [(r['Kernel_Name'], r['Counter_Name'], float(r['Counter_Value'])) for r in csv.DictReader(open(files[0]))]
+    dbs = glob.glob(os.path.join(G, f'prof_{kind}', '*', '*_results.db'))
+    if not dbs:
+        return []
+    import sqlite3
+    con = sqlite3.connect(dbs[0])
+    # one row per (dispatch, counter instance): sum the instances of a dispatch
+    q = 'select name, counter_name, sum(counter_value) from pmc_events group by dispatch_id, counter_name'
+    return [(n, c, float(v)) for n, c, v in con.execute(q)]
+
+
 with open(os.path.join(P, f'{tag}_kernel_stats.csv'), 'w', newline='') as f:
     w = csv.writer(f)
     w.writerow(['kernel', 'calls', 'total_ns', 'avg_ns', 'pct', 'min_ns', 'max_ns'])
-    for r in rows:
-        w.writerow([short(r['Name']), r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'],
-                    r['MaxNs']])
+    for name, *rest in kernel_stats():
+        w.writerow([short(name)] + rest)
 
 pmc = {}
 for kind, counter in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
-    files = glob.glob(os.path.join(G, f'prof_{kind}', '*', '*_counter_collection.csv'))
-    if not files:
-        continue
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(files[0])):
-        if r['Counter_Name'] == counter and 'rua::' in r['Kernel_Name']:
-            agg[short(r['Kernel_Name'])].append(float(r['Counter_Value']))
+    for name, cname, value in counter_rows(kind):
+        if cname == counter and 'rua::' in name:
+            agg[short(name)].append(value)
     for k, v in agg.items():
         pmc.setdefault(k, {})[counter] = {'launches': len(v), 'mean': sum(v) / len(v), 'min': min(v), 'max': max(v)}
 
