@@ -403,11 +403,14 @@ struct SplitWs {
   int64_t split;      // rows per part (0 = splitting off)
 };
 
-template <typename A, int EPL>
+template <typename A, int EPL, int OP>
 __device__ __forceinline__ void store_partial(void* partials, int64_t slot, int lane, const Fold<A, EPL>& f) {
   A* p = reinterpret_cast<A*>(partials) + (slot * 2 * RUA_WAVE + lane) * EPL;
 #pragma unroll
-  for (int e = 0; e < EPL; ++e) { p[e] = f.acc[e]; p[RUA_WAVE * EPL + e] = f.aux[e]; }
+  for (int e = 0; e < EPL; ++e) {
+    p[e] = f.acc[e];
+    if (OP == RUA_LOGSUMEXP) p[RUA_WAVE * EPL + e] = f.aux[e];   // only logsumexp carries a second value
+  }
 }
 
 template <typename T, int EPL, int OP, bool NT, bool COPY, bool SPLIT, int CPW>
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
     }
     fold_rows<T, EPL, OP, NT, COPY, CPW>(U, 0, W.split, data, H, f, CD, copy, lane);
     fold_wave<A, NE, OP>(f, lp_log2);
-    store_partial<A, NE>(W.partials, pbase, lane, f);
+    store_partial<A, NE, OP>(W.partials, pbase, lane, f);
   } else {
     fold_rows<T, EPL, OP, NT, COPY, CPW>(U, 0, U.len, data, H, f, CD, copy, lane);
     fold_wave<A, NE, OP>(f, lp_log2);
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_tail_kernel(rua_layout L,
     fold_init<A, NE, OP>(f);
     fold_rows<T, EPL, OP, NT, COPY, CPW>(U, t_lo, t_hi, data, H, f, CD, copy, lane);
     fold_wave<A, NE, OP>(f, lp_log2);
-    store_partial<A, NE>(W.partials, e[3], lane, f);
+    store_partial<A, NE, OP>(W.partials, e[3], lane, f);
     fold_flags<A, NE, OP>(f, extreme, lane, false);
   }
 }
@@ -525,19 +528,25 @@ constexpr int64_t COMBINE_GRID = 512;   // 2 workgroups per CU
 template <typename A, int NE, int OP>
 __device__ __forceinline__ void combine_range(Fold<A, NE>& f, const A* __restrict__ P, int64_t pbase, int64_t p_lo,
                                               int64_t p_hi, int lane) {
-  constexpr int PF = 4;
+  constexpr bool LSE = OP == RUA_LOGSUMEXP;
+  constexpr int PF = LSE ? 4 : 8;               // partials in flight: the walk over one unit's parts is latency-bound
   for (int64_t p = p_lo; p < p_hi; p += PF) {
-    A a2[PF][NE], x2[PF][NE];
+    A a2[PF][NE], x2[LSE ? PF : 1][NE];
+    // unconditional loads (the index is clamped, the merge below is guarded): all PF loads are issued before
+    // the first wait — guarded loads were serialised into PF round trips
 #pragma unroll
-    for (int u = 0; u < PF; ++u)
-      if (p + u < p_hi) {
-        const A* pp = P + ((pbase + p + u) * 2 * RUA_WAVE + lane) * NE;
+    for (int u = 0; u < PF; ++u) {
+      const int64_t pu = (p + u < p_hi) ? p + u : p_hi - 1;
+      const A* pp = P + ((pbase + pu) * 2 * RUA_WAVE + lane) * NE;
 #pragma unroll
-        for (int k = 0; k < NE; ++k) { a2[u][k] = pp[k]; x2[u][k] = pp[RUA_WAVE * NE + k]; }
+      for (int k = 0; k < NE; ++k) {
+        a2[u][k] = pp[k];
+        if (LSE) x2[u][k] = pp[RUA_WAVE * NE + k];
       }
+    }
 #pragma unroll
     for (int u = 0; u < PF; ++u)
-      if (p + u < p_hi) fold_merge<A, NE, OP>(f, a2[u], x2[u]);
+      if (p + u < p_hi) fold_merge<A, NE, OP>(f, a2[u], x2[LSE ? u : 0]);
   }
 }
 
