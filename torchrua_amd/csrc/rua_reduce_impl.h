@@ -367,7 +367,6 @@ __device__ __forceinline__ void fold_store(const Unit<T, EPL>& U, Fold<typename 
   }
 }
 
-// one no-return integer atomic per wave into a hashed slot (the reference's global initial, reduce.py:35,40)
 // The reference's `initial` for max / min / logsumexp is a GLOBAL extreme of the data (reduce.py:35,40: tensor.min()
 // resp. tensor.max()).  It only shows in two rare cases, so the hot loops do not track it; they raise flags
 // (extreme[EXTREME_SLOTS]) instead, after the wave's fold:
