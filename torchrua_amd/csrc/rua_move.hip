@@ -157,6 +157,34 @@ __global__ __launch_bounds__(MOVE_BLOCK) void move_rows_kernel(rua_layout D, rua
 // sub-tiles.  (At >= 1 KiB rows the same tiling changes nothing — a row already fills whole lines — so
 // wide rows keep the generic kernel.)  Phase 1 needs no search: rank r is live at time t iff r < bsz[t].
 constexpr int TR = 16, TT = 16;   // TR * TT == TILE_ROWS
+constexpr int64_t TILE_LDS_MAX_ROW_BYTES = 64;   // at or below: pack_tile_lds_kernel
+
+// phase 1 of both tile kernels (closed form, no search): thread i = (rank << 4) | time of the tile fills the
+// source / destination row of its token, or -1
+template <bool TO_PACK>
+__device__ __forceinline__ void tile_phase1(const rua_layout& Pk, const rua_layout& Ot, int64_t* s_ld, int64_t* s_st) {
+  // which time chunk does this tile belong to?  largest c with tile_start[c] <= blockIdx.x
+  int64_t lo = 0, hi = Pk.n_tchunks;
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (Pk.tile_start[mid] <= (int64_t)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const int64_t t0 = lo * TT;
+  const int64_t r0 = ((int64_t)blockIdx.x - Pk.tile_start[lo]) * TR;
+  const int i = threadIdx.x;
+  const int64_t r = r0 + (i >> 4), t = t0 + (i & 15);
+  int64_t prow = -1, orow = -1;
+  if (t < Pk.T && r < Pk.bsz[t] && r < Pk.B) {
+    int64_t b = Pk.sorted ? Pk.sorted[r] : r;
+    if (b >= 0 && b < Ot.B) {
+      prow = Pk.boff[t] + r;
+      orow = token_to_row(Ot, b, t, seq_len(Ot, b));
+      if (prow >= Pk.n_rows || orow >= Ot.n_rows) { prow = -1; orow = -1; }
+    }
+  }
+  s_ld[i] = TO_PACK ? orow : prow;
+  s_st[i] = TO_PACK ? prow : orow;
+}
 
 template <int VEC, bool TO_PACK>
 __global__ __launch_bounds__(RUA_BLOCK) void pack_tile_kernel(rua_layout Pk, rua_layout Ot, char* __restrict__ dst,
@@ -166,30 +194,7 @@ __global__ __launch_bounds__(RUA_BLOCK) void pack_tile_kernel(rua_layout Pk, rua
   __shared__ int64_t s_ld[TILE_ROWS];
   __shared__ int64_t s_st[TILE_ROWS];
 
-  // which time chunk does this tile belong to?  largest c with tile_start[c] <= blockIdx.x
-  int64_t lo = 0, hi = Pk.n_tchunks;
-  while (hi - lo > 1) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (Pk.tile_start[mid] <= (int64_t)blockIdx.x) lo = mid; else hi = mid;
-  }
-  const int64_t t0 = lo * TT;
-  const int64_t r0 = ((int64_t)blockIdx.x - Pk.tile_start[lo]) * TR;
-
-  {  // ---- phase 1: closed form, no search
-    const int i = threadIdx.x;
-    const int64_t r = r0 + (i >> 4), t = t0 + (i & 15);
-    int64_t prow = -1, orow = -1;
-    if (t < Pk.T && r < Pk.bsz[t] && r < Pk.B) {
-      int64_t b = Pk.sorted ? Pk.sorted[r] : r;
-      if (b >= 0 && b < Ot.B) {
-        prow = Pk.boff[t] + r;
-        orow = token_to_row(Ot, b, t, seq_len(Ot, b));
-        if (prow >= Pk.n_rows || orow >= Ot.n_rows) { prow = -1; orow = -1; }
-      }
-    }
-    s_ld[i] = TO_PACK ? orow : prow;
-    s_st[i] = TO_PACK ? prow : orow;
-  }
+  tile_phase1<TO_PACK>(Pk, Ot, s_ld, s_st);
   __syncthreads();
 
   // ---- phase 2: 4x4 sub-tiles (4 consecutive rows per wave on the time-contiguous side, the 4 waves
@@ -224,6 +229,48 @@ __global__ __launch_bounds__(RUA_BLOCK) void pack_tile_kernel(rua_layout Pk, rua
   }
 }
 
+// Rows of at most 64 B: the same tile, staged through LDS (measured at 32-byte rows: pack 3.5 -> 4.0 TB/s, P.cat
+// 3.9 -> 4.3; at 128-byte rows the 32 KiB of LDS per tile costs more occupancy than the longer runs win: 5.3 -> 4.9,
+// so those keep the sub-tile walk above).
+template <int VEC, bool TO_PACK>
+__global__ __launch_bounds__(RUA_BLOCK) void pack_tile_lds_kernel(rua_layout Pk, rua_layout Ot, char* __restrict__ dst,
+                                                              const char* __restrict__ src, int64_t row_bytes,
+                                                              int64_t lpr) {
+  using V = typename vec_of<VEC>::type;
+  __shared__ int64_t s_ld[TILE_ROWS];
+  __shared__ int64_t s_st[TILE_ROWS];
+
+  tile_phase1<TO_PACK>(Pk, Ot, s_ld, s_st);
+  __syncthreads();
+
+  // ---- phase 2: the tile goes through LDS.  It is read in the SOURCE's contiguous order (consecutive lanes =
+  // consecutive 16-byte pieces of consecutive rows of one run) and written in the DESTINATION's contiguous order,
+  // so both sides see whole 16-row runs (512 B at 32-byte rows) per wave instruction instead of 4-row / 1-row
+  // pieces.  Tile index i = (rank << 4) | time is the C-side order; the P-side order visits (time, rank).
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_stage_raw[];
+  V* stage = reinterpret_cast<V*>(s_stage_raw);
+  const int n_pieces = TILE_ROWS * (int)lpr;
+  // one padding slot per 16 rows: the transposed order strides over 16 * lpr slots, which would otherwise
+  // land every lane of a group on the same LDS banks
+#define RUA_SLOT(i, piece) ((i) * (int)lpr + (piece) + ((i) >> 4))
+#pragma unroll 4
+  for (int idx = threadIdx.x; idx < n_pieces; idx += RUA_BLOCK) {
+    const int pos = idx / (int)lpr, piece = idx - pos * (int)lpr;
+    const int i = TO_PACK ? pos : (((pos & 15) << 4) | (pos >> 4));
+    const int64_t ld = s_ld[i];
+    if (ld >= 0 && s_st[i] >= 0) stage[RUA_SLOT(i, piece)] = ld_row<V, false>(src + ld * row_bytes + (int64_t)piece * VEC);
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int idx = threadIdx.x; idx < n_pieces; idx += RUA_BLOCK) {
+    const int pos = idx / (int)lpr, piece = idx - pos * (int)lpr;
+    const int i = TO_PACK ? (((pos & 15) << 4) | (pos >> 4)) : pos;
+    const int64_t st = s_st[i];
+    if (st >= 0 && s_ld[i] >= 0) st_row<V, false>(dst + st * row_bytes + (int64_t)piece * VEC, stage[RUA_SLOT(i, piece)]);
+  }
+#undef RUA_SLOT
+}
+
 template <bool TO_PACK>
 static int launch_pack_tiles(int vec, hipStream_t s, const rua_layout& Pk, const rua_layout& Ot, char* dst,
                              const char* src, int64_t row_bytes) {
@@ -233,8 +280,12 @@ static int launch_pack_tiles(int vec, hipStream_t s, const rua_layout& Pk, const
   while ((1 << lp_log2) < lpr && lp_log2 < 6) ++lp_log2;
   const int cpr = (int)((lpr + RUA_WAVE - 1) / RUA_WAVE);
   const dim3 g((unsigned)Pk.n_tiles), b(RUA_BLOCK);
-#define RUA_LAUNCH(VEC) \
-  hipLaunchKernelGGL((pack_tile_kernel<VEC, TO_PACK>), g, b, 0, s, Pk, Ot, dst, src, row_bytes, lpr, lp_log2, cpr)
+  const size_t lds = (size_t)(TILE_ROWS * lpr + TILE_ROWS / 16) * vec;   // the staged tile + its padding slots
+#define RUA_LAUNCH(VEC)                                                                                         \
+  if (row_bytes <= TILE_LDS_MAX_ROW_BYTES)                                                                      \
+    hipLaunchKernelGGL((pack_tile_lds_kernel<VEC, TO_PACK>), g, b, lds, s, Pk, Ot, dst, src, row_bytes, lpr);    \
+  else                                                                                                          \
+    hipLaunchKernelGGL((pack_tile_kernel<VEC, TO_PACK>), g, b, 0, s, Pk, Ot, dst, src, row_bytes, lpr, lp_log2, cpr)
   switch (vec) {
     case 16: RUA_LAUNCH(16); break;
     case 8:  RUA_LAUNCH(8); break;
