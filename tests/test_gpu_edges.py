@@ -98,6 +98,22 @@ def test_reduce_packed_many_narrow_sequences(h, dtype):
         torch.testing.assert_close(back.float(), xc.grad.float(), rtol=1e-5 + 4 * ulp, atol=1e-6 + 4 * ulp, msg=name)
 
 
+@pytest.mark.parametrize('h,dtype', [(16, torch.bfloat16), (8, torch.float32), (4, torch.float32)])
+def test_segment_reduce_many_narrow_segments_with_empties(h, dtype):
+    """140 000 segments of 0..5 rows of at most 32 B in a CattedSequence , empty
+    segments included: every op vs the oracle (the reference's global-extreme `initial` for the empty ones)."""
+    g = torch.Generator().manual_seed(h + 100)
+    lt = torch.randint(0, 6, (140_000,), generator=g)
+    data = (torch.randn(int(lt.sum()), h, generator=g) * 0.5).to(dtype)
+    f = data.float().numpy()
+    ulp = {torch.float32: 0.0, torch.bfloat16: 2.0 ** -8}[dtype]
+    for name in ('sum', 'mean', 'max', 'min', 'prod', 'logsumexp'):
+        ref = getattr(orc, f'segment_{name}')(f, lt.numpy())
+        out = getattr(ta, f'segment_{name}')(data.to(DEV), lt.to(DEV))
+        np.testing.assert_allclose(out.double().cpu().numpy(), ref.astype(np.float64), rtol=1e-5 + ulp,
+                                   atol=1e-5 + ulp, err_msg=name)
+
+
 def test_zero_length_segments_and_initial():
     """Empty segments take the reference's `initial`: 0 / 1 / the GLOBAL min (max) resp. max (min)."""
     lens = [0, 3, 0, 0, 2, 5, 0]

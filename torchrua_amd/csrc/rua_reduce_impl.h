@@ -963,6 +963,8 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
   if (L.kind == RUA_PACK && L.sorted && !copy && !perm && lp_log2 < 6 && !(split > 0 && ws) &&
       (L.B >> (6 - lp_log2)) >= RANKS_MIN_WAVES) {
     // narrow rows of a PackedSequence: adjacent ranks share a wave instruction
+    // (tried for a CattedSequence with 32-byte rows too — groups = adjacent sequences: 4.0 -> 2.8 TB/s, unsorted
+    // neighbours differ too much in length — so C keeps one wave per sequence)
     const int64_t rpw = RUA_WAVE >> lp_log2;
     const int64_t nblk = (L.B + rpw - 1) / rpw;
     if (nblk > 0x7fffffffLL) return RUA_ERANGE;
