@@ -62,24 +62,69 @@ template <typename V, bool NT> __device__ __forceinline__ void st_row(char* p, V
 // lp_log2  : log2 of lanes a wave gives one row per instruction (<= 6); rows narrower than
 //            1 KiB share a wave instruction (64 >> lp_log2 rows at a time)
 // cpr      : 64-lane column chunks per row (1 unless row_bytes > 64*VEC)
-template <int VEC, bool SCATTER, bool NT>
+// RPT      : destination rows per lane in phase 1 (1; 4 = the narrow-row variant of roll / rev inside one
+//            PackedSequence, see below)
+template <int VEC, bool SCATTER, bool NT, int RPT = 1>
 __global__ __launch_bounds__(MOVE_BLOCK) void move_rows_kernel(rua_layout D, rua_layout S, int32_t tmap,
                                                               int64_t targ, char* __restrict__ dst,
                                                               const char* __restrict__ src, int64_t row_bytes,
                                                               int64_t lpr, int lp_log2, int cpr, uint4 fillpat,
                                                               int64_t pad_row) {
   using V = typename vec_of<VEC>::type;
-  __shared__ int64_t s_ld[MOVE_TILE];
-  __shared__ int64_t s_st[MOVE_TILE];
+  constexpr int TILE = MOVE_TILE * RPT;
+  __shared__ int64_t s_ld[TILE];
+  __shared__ int64_t s_st[TILE];
 
-  const int64_t tile0 = (int64_t)blockIdx.x * MOVE_TILE;
+  const int64_t tile0 = (int64_t)blockIdx.x * TILE;
   const int64_t left = D.n_rows - tile0;
-  const int nrows = left < MOVE_TILE ? (int)left : MOVE_TILE;
+  const int nrows = left < TILE ? (int)left : TILE;
 
   // ---- phase 1: one lane per destination row
   const bool same_pack = !SCATTER && D.kind == RUA_PACK && S.kind == RUA_PACK && D.bsz && D.boff == S.boff &&
                          D.sorted == S.sorted && D.len_add == 0 && S.len_add == 0 && D.T == S.T;
-  {
+  if (RPT > 1) {
+    // Rows of at most 32 B inside one PackedSequence (the host only picks this variant when `same_pack` holds): a
+    // 256-row tile is 8 KiB, and a workgroup spends its life in the two dependent-load searches of phase 1
+    // (measured 3.1 TB/s at 32-byte rows).  Each lane therefore takes RPT rows and runs their searches in
+    // LOCKSTEP — fixed trip counts, RPT independent loads in flight per step — so the tile is RPT times larger
+    // for the same latency.
+    int64_t j[RPT], lo[RPT], hi[RPT], t[RPT], r[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) { j[k] = tile0 + threadIdx.x + k * MOVE_BLOCK; lo[k] = 0; hi[k] = D.T; }
+    for (int64_t span = D.T; span > 1; span = (span + 1) >> 1) {     // largest t with boff[t] <= j
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const int64_t mid = (lo[k] + hi[k]) >> 1;
+        const bool go = hi[k] - lo[k] > 1;
+        const int64_t v = go ? D.boff[mid] : 0;
+        if (go) { if (v <= j[k]) lo[k] = mid; else hi[k] = mid; }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) { t[k] = lo[k]; r[k] = j[k] - D.boff[t[k]]; lo[k] = 0; hi[k] = D.T; }
+    for (int64_t span = D.T; span > 0; span >>= 1) {                  // len = #{t : bsz[t] > r}
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const bool go = lo[k] < hi[k];
+        const int64_t mid = (lo[k] + hi[k]) >> 1;
+        const int64_t v = go ? D.bsz[mid] : 0;
+        if (go) { if (v > r[k]) lo[k] = mid + 1; else hi[k] = mid; }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const int i = threadIdx.x + k * MOVE_BLOCK;
+      if (i < nrows) {
+        const int64_t len = lo[k];
+        const int64_t ts = apply_tmap(tmap, targ, t[k], len, len);
+        int64_t other = -1;
+        if (ts >= 0 && ts < len) other = S.boff[ts] + r[k];
+        if (other >= S.n_rows) other = -1;
+        s_ld[i] = other;
+        s_st[i] = j[k];
+      }
+    }
+  } else {
     const int i = threadIdx.x;
     if (i < nrows) {
       const int64_t j = tile0 + i;
@@ -318,14 +363,23 @@ static int check_layout(const rua_layout* L, bool is_dst) {
   return RUA_EINVAL;
 }
 
+constexpr int NARROW_RPT = 4;
+
 template <bool SCATTER, bool NT>
 static int launch_move(int vec, unsigned grid, hipStream_t s, const rua_layout& D, const rua_layout& S, int32_t tmap,
-                       int64_t targ, char* dst, const char* src, int64_t row_bytes, uint4 fp, int64_t pad_row) {
+                       int64_t targ, char* dst, const char* src, int64_t row_bytes, uint4 fp, int64_t pad_row,
+                       bool narrow_same_pack = false) {
   const int64_t lpr = (row_bytes + vec - 1) / vec;
   int lp_log2 = 0;
   while ((1 << lp_log2) < lpr && lp_log2 < 6) ++lp_log2;
   const int cpr = (int)((lpr + RUA_WAVE - 1) / RUA_WAVE);
   const dim3 g(grid), b(MOVE_BLOCK);
+  if (narrow_same_pack) {   // vec == 16, gather: see move_rows_kernel<..., RPT>
+    const dim3 gn((grid + NARROW_RPT - 1) / NARROW_RPT);
+    hipLaunchKernelGGL((move_rows_kernel<16, false, NT, NARROW_RPT>), gn, b, 0, s, D, S, tmap, targ, dst, src, row_bytes,
+                       lpr, lp_log2, cpr, fp, pad_row);
+    return (int)hipGetLastError();
+  }
 #define RUA_LAUNCH(VEC) \
   hipLaunchKernelGGL((move_rows_kernel<VEC, SCATTER, NT>), g, b, 0, s, D, S, tmap, targ, dst, src, row_bytes, lpr, lp_log2, cpr, fp, pad_row)
   switch (vec) {
@@ -384,6 +438,10 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
   if (flags & RUA_MOVE_SCATTER)
     return nt ? launch_move<true, true>(vec, g, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row)
               : launch_move<true, false>(vec, g, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row);
-  return nt ? launch_move<false, true>(vec, g, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row)
-            : launch_move<false, false>(vec, g, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row);
+  // roll / rev inside ONE PackedSequence with rows of at most 32 B (3.1 -> 3.9 TB/s; no gain at 64 B): RPT rows per lane (the kernel's `same_pack` test)
+  const bool narrow_same_pack = vec == 16 && row_bytes <= 32 && dst->kind == RUA_PACK && src->kind == RUA_PACK &&
+                                dst->bsz && dst->boff && dst->boff == src->boff && dst->sorted == src->sorted &&
+                                dst->len_add == 0 && src->len_add == 0 && dst->T == src->T && dst->T > 0;
+  return nt ? launch_move<false, true>(vec, g, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, narrow_same_pack)
+            : launch_move<false, false>(vec, g, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, narrow_same_pack);
 }
