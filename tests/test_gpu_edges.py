@@ -28,7 +28,8 @@ def _mk(lens, hidden, dtype, seed=0):
 WIDTHS = [((1,), torch.uint8), ((3,), torch.uint8), ((1,), torch.int16), ((3,), torch.float16), ((1,), torch.float32),
           ((33,), torch.float32), ((6,), torch.float32), ((1,), torch.long), ((2,), torch.long), ((5,), torch.long),
           ((300,), torch.float32), ((1024,), torch.bfloat16), ((1030,), torch.bfloat16), ((4, 3), torch.float32),
-          ((2, 3, 5), torch.float64), ((), torch.float32), ((513,), torch.float16)]
+          ((2, 3, 5), torch.float64), ((), torch.float32), ((513,), torch.float16),
+          ((70001,), torch.float32), ((65536,), torch.bfloat16)]      # 273-KiB odd rows, 128-KiB rows
 
 
 @pytest.mark.parametrize('hidden,dtype', WIDTHS, ids=[f'{h}-{str(d)[6:]}' for h, d in WIDTHS])
@@ -69,6 +70,22 @@ def test_reduce_any_width_dtype_layout(lens, h, dtype, name, kind):
     # fp32 accumulate then ONE rounding to the output dtype: 1e-5 on the accumulation + half an ulp of the dtype
     ulp = {torch.float32: 0.0, torch.float64: 0.0, torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dtype]
     np.testing.assert_allclose(out.double().cpu().numpy(), ref.astype(np.float64), rtol=1e-5 + ulp, atol=1e-5 + ulp)
+
+
+@pytest.mark.parametrize('h,dtype', [(70001, torch.float32), (65536, torch.bfloat16), (4100, torch.float64)])
+def test_reduce_very_wide_rows(h, dtype):
+    """Rows of hundreds of KiB (thousands of column chunks per sequence; odd widths take the scalar path)."""
+    lens = [5, 1, 9, 2, 70]
+    data, lt = _mk(lens, (h,), dtype, seed=h)
+    data = (data * 0.5).to(dtype)
+    f = data.double().numpy() if dtype == torch.float64 else data.float().numpy()
+    ulp = {torch.float32: 0.0, torch.float64: 0.0, torch.bfloat16: 2.0 ** -8}[dtype]
+    c = ta.C(data.to(DEV), lt.to(DEV))
+    for name in ('sum', 'mean', 'max', 'min', 'prod', 'logsumexp'):
+        ref = getattr(orc, f'segment_{name}')(f, lt.numpy()).astype(np.float64)
+        for z in (c, c.pack(), c.left()):
+            out = getattr(ta, f'reduce_{name}')(z)
+            np.testing.assert_allclose(out.double().cpu().numpy(), ref, rtol=2e-5 + ulp, atol=2e-5 + ulp, err_msg=name)
 
 
 @pytest.mark.parametrize('h,dtype', [(16, torch.bfloat16), (24, torch.float32), (3, torch.float32)])
