@@ -100,6 +100,13 @@ int rua_exclusive_scan_i64(const int64_t* in, int64_t* out, int64_t* total, int6
 int rua_pack_meta(const int64_t* lens, const int64_t* sorted, int64_t B, int64_t T,
                   int64_t* unsorted, int64_t* bsz, void* stream);
 
+/* K3 + K1 in one call — everything pack() derives on the device: rua_pack_meta's outputs plus
+ *   boff[t] = sum(bsz[0..t))  (T entries)   and, if off != NULL,   off[b] = sum(lens[0..b))  (B entries).
+ * Moderate sizes (T <= 2 048, B <= 32 768) take ONE launch instead of five; larger ones run the three steps back to
+ * back.  `ws`: rua_scan_ws_elems(max(B, T)) int64 (only touched on the large path).  core/view.py:47-58 + utils.py:16-19. */
+int rua_pack_prepare(const int64_t* lens, const int64_t* sorted, int64_t B, int64_t T, int64_t* unsorted,
+                     int64_t* bsz, int64_t* boff, int64_t* off, int64_t* ws, void* stream);
+
 /* K3b. token_sizes of a PackedSequence in original batch order:
  *   len[b] = #{t : bsz[t] > unsorted[b]}          core/view.py:21-25 (get_mask(P).sum(dim=1)) */
 int rua_lens_from_pack(const int64_t* bsz, int64_t T, const int64_t* unsorted, int64_t B,

@@ -50,6 +50,22 @@ int main(void) {
   CHECK(rua_segment_reduce(&pack, NULL, d_pack, d_out, H, RUA_F32, RUA_SUM, 0, 0, NULL, 0, NULL, s));
   CHECK(hipStreamSynchronize(s));
 
+  /* the one-call form of the three metadata steps above must agree with them */
+  int64_t *d_uns2, *d_bsz2, *d_boff2, *d_off2;
+  CHECK(hipMalloc((void**)&d_uns2, sizeof sorted));
+  CHECK(hipMalloc((void**)&d_bsz2, T * sizeof(int64_t)));
+  CHECK(hipMalloc((void**)&d_boff2, T * sizeof(int64_t)));
+  CHECK(hipMalloc((void**)&d_off2, sizeof lens));
+  CHECK(rua_pack_prepare(d_lens, d_sorted, B, T, d_uns2, d_bsz2, d_boff2, d_off2, d_ws, s));
+  CHECK(hipStreamSynchronize(s));
+  int64_t a[B > T ? B : T], c2[B > T ? B : T];
+  int bad = 0;
+#define SAME(x, y, n)                                                   \
+  CHECK(hipMemcpy(a, x, (n) * sizeof(int64_t), hipMemcpyDeviceToHost)); \
+  CHECK(hipMemcpy(c2, y, (n) * sizeof(int64_t), hipMemcpyDeviceToHost)); \
+  for (int i_ = 0; i_ < (n); ++i_) bad += a[i_] != c2[i_];
+  SAME(d_unsorted, d_uns2, B) SAME(d_bsz, d_bsz2, T) SAME(d_boff, d_boff2, T) SAME(d_off, d_off2, B)
+
   float packed[N * H], out[B * H];
   int64_t bsz[T], unsorted[B];
   CHECK(hipMemcpy(packed, d_pack, sizeof packed, hipMemcpyDeviceToHost));
@@ -60,7 +76,6 @@ int main(void) {
   /* expectations from SURVEY.md §8c(i): rows of C are 0..9; P order = rows [2,7,0,6,3,8,1,4,9,5] */
   const int p_rows[N] = {2, 7, 0, 6, 3, 8, 1, 4, 9, 5};
   const int64_t e_bsz[T] = {4, 3, 2, 1}, e_uns[B] = {2, 0, 3, 1};
-  int bad = 0;
   for (int j = 0; j < N; ++j)
     for (int h = 0; h < H; ++h) bad += packed[j * H + h] != data[p_rows[j] * H + h];
   for (int t = 0; t < T; ++t) bad += bsz[t] != e_bsz[t];

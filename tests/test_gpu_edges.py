@@ -371,6 +371,24 @@ def test_long_sequences_are_split(hidden, dtype):
     assert torch.equal(src.grad, torch.ones_like(src))
 
 
+@pytest.mark.parametrize('B,hi', [(1, 1), (300, 40), (5000, 2048), (32768, 9), (32769, 9), (70000, 3), (50, 2049)])
+def test_pack_prepare_equals_the_separate_steps(B, hi):
+    """rua_pack_prepare (one launch up to T = 2 048 / B = 32 768, three steps beyond) vs torch on the host."""
+    g = torch.Generator().manual_seed(B + hi)
+    lens = torch.randint(1, hi + 1, (B,), generator=g)
+    lens[int(torch.randint(0, B, (1,), generator=g))] = hi
+    c = ta.with_host_sizes(torch.zeros(int(lens.sum()), 1, device=DEV), lens)
+    p = c.pack()
+    srt = torch.sort(lens, descending=True)[1]
+    assert torch.equal(p.sorted_indices.cpu(), srt)
+    assert torch.equal(p.unsorted_indices.cpu(), torch.argsort(srt))
+    bsz = (lens[None, :] > torch.arange(hi)[:, None]).sum(1)
+    assert torch.equal(p.batch_sizes, bsz)
+    from torchrua_amd import _meta as M
+    assert torch.equal(M.pack_boff(p).cpu(), torch.cumsum(bsz, 0) - bsz)
+    assert torch.equal(M.dev_off(c.token_sizes).cpu(), torch.cumsum(lens, 0) - lens)
+
+
 def test_bucketing_is_a_stable_sort():
     """rua_index_buckets == a stable sort of the rows by destination (checked against torch.sort(stable=True)),
     for few / many destinations, 1-3 radix passes, out-of-range indices ignored."""

@@ -46,6 +46,8 @@ SYMBOLS = {
     'rua_scan_ws_elems': (c_int64, [c_int64]),
     'rua_exclusive_scan_i64': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'rua_pack_meta': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    'rua_pack_prepare': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p]),
     'rua_lens_from_pack': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     'rua_enum_rows': (c_int, [POINTER(RuaLayout), c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rua_mask': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int32, c_uint64, c_uint64, c_void_p]),

@@ -9,6 +9,7 @@ touches payload bytes.
 import ctypes
 from typing import List, Optional, Tuple
 
+import numpy as np
 import torch
 from torch import Tensor
 
@@ -100,8 +101,7 @@ def max_len(token_sizes: Tensor) -> int:
     hit = _memo_get(token_sizes, 'max')
     if hit is not None:
         return hit
-    with host_serial():
-        return _memo_put(token_sizes, 'max', int(h.max()) if h.numel() else 0)
+    return _memo_put(token_sizes, 'max', int(h.detach().numpy().max()) if h.numel() else 0)
 
 
 def total_len(token_sizes: Tensor) -> int:
@@ -109,8 +109,7 @@ def total_len(token_sizes: Tensor) -> int:
     if hit is not None:
         return hit
     h = host_lens(token_sizes)
-    with host_serial():
-        return _memo_put(token_sizes, 'sum', int(h.sum()))
+    return _memo_put(token_sizes, 'sum', int(h.detach().numpy().sum()))
 
 
 def dev_off(token_sizes: Tensor) -> Tensor:
@@ -248,13 +247,14 @@ class PackTiling:
     __slots__ = ('bsz', 'tile_start', 'n_tchunks', 'n_tiles')
 
     def __init__(self, batch_sizes: Tensor, bsz_dev: Tensor, dev: torch.device):
-        with host_serial():
-            counts = (batch_sizes[::TILE_T] + (TILE_R - 1)) // TILE_R
-            start = torch.zeros(counts.numel() + 1, dtype=torch.long)
-            torch.cumsum(counts, 0, out=start[1:])
-        self.n_tchunks = int(counts.numel())
+        # numpy on the (CPU, by PackedSequence's contract) batch_sizes: a handful of torch CPU ops on a few dozen
+        # elements cost ~30 us EACH on the GPU box's 128-thread host build
+        counts = (batch_sizes.numpy()[::TILE_T] + (TILE_R - 1)) // TILE_R
+        start = np.zeros(counts.size + 1, dtype=np.int64)
+        np.cumsum(counts, out=start[1:])
+        self.n_tchunks = int(counts.size)
         self.n_tiles = int(start[-1])
-        self.tile_start = to_device_async(start, dev)
+        self.tile_start = to_device_async(torch.from_numpy(start), dev)
         self.bsz = bsz_dev
 
 
@@ -302,6 +302,7 @@ class _StagingRing:
         self.bufs = [None] * self.SLOTS
         self.events = [None] * self.SLOTS
         self.i = 0
+        self.side = None      # the upload stream of this device
 
     def upload(self, host: Tensor, dev: torch.device) -> Tensor:
         i = self.i
@@ -315,10 +316,27 @@ class _StagingRing:
             self.bufs[i] = buf
         staged = buf[:nbytes].view(host.dtype).view(host.shape)
         staged.copy_(host)
-        out = torch.empty(host.shape, dtype=host.dtype, device=dev)
-        out.copy_(staged, non_blocking=True)
+        cur = torch.cuda.current_stream(dev)
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))
+        if torch.cuda.is_current_stream_capturing():
+            out = torch.empty(host.shape, dtype=host.dtype, device=dev)
+            out.copy_(staged, non_blocking=True)
+            ev.record(cur)
+        else:
+            # The copy runs on its OWN stream: it depends on nothing the compute stream holds (the source is host
+            # memory written just above), so the copy engine works while the previous step's kernels still run and
+            # the consumer finds its input ready, instead of a copy -> kernel hand-off sitting in the middle of the
+            # compute queue.  The destination comes from the side stream's pool (a block freed on the compute stream
+            # may still be read by a pending kernel) and is handed to the compute stream with record_stream.
+            side = self.side
+            if side is None:
+                side = self.side = torch.cuda.Stream(dev)
+            with torch.cuda.stream(side):
+                out = torch.empty(host.shape, dtype=host.dtype, device=dev)
+                out.copy_(staged, non_blocking=True)
+                ev.record(side)
+            cur.wait_event(ev)
+            out.record_stream(cur)
         self.events[i] = ev
         return out
 
@@ -327,7 +345,8 @@ _rings = {}
 
 
 def to_device_async(host: Tensor, dev: torch.device) -> Tensor:
-    """Enqueue the H2D of a small contiguous host vector on the current stream without blocking the host."""
+    """Enqueue the H2D of a small contiguous host vector (on the device's upload stream; the current stream waits
+    for it) without blocking the host."""
     if dev.type != 'cuda' or host.numel() == 0 or not host.is_contiguous():
         return host.to(dev)
     ring = _rings.get(dev)

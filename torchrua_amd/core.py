@@ -85,11 +85,17 @@ def _pack_meta(token_sizes: Tensor, dev: torch.device):
     T = M.max_len(token_sizes)
     sorted_indices = M.to_device_async(index, dev)
     batch_sizes = M.batch_sizes_from_host_lens(host, T)
+    # one call for everything derived on the device; the internal vectors share one allocation:
+    # batch_sizes [T] | their offsets [T] | offsets of the lengths [B] | scan scratch
+    need_off = M._memo_get(token_sizes, 'off') is None and lens is token_sizes
     unsorted = torch.empty(B, dtype=torch.long, device=dev)
-    bsz_dev = torch.empty(T, dtype=torch.long, device=dev)
-    K.check(lib.rua_pack_meta(K.ptr(lens), K.ptr(sorted_indices), B, T, K.ptr(unsorted), K.ptr(bsz_dev),
-                              K.stream_ptr(dev)), 'rua_pack_meta')
-    boff = M.exclusive_scan(bsz_dev)
+    buf = torch.empty(2 * T + B + lib.rua_scan_ws_elems(max(B, T)), dtype=torch.long, device=dev)
+    bsz_dev, boff, off = buf[:T], buf[T:2 * T], buf[2 * T:2 * T + B]
+    K.check(lib.rua_pack_prepare(K.ptr(lens), K.ptr(sorted_indices), B, T, K.ptr(unsorted), K.ptr(bsz_dev),
+                                 K.ptr(boff), K.ptr(off) if need_off else None, K.ptr(buf[2 * T + B:]),
+                                 K.stream_ptr(dev)), 'rua_pack_prepare')
+    if need_off:
+        M._memo_put(token_sizes, 'off', off)      # the CattedSequence side of the cast needs them next
     meta = (lens, sorted_indices, unsorted, batch_sizes, bsz_dev, boff)
     M._memo_put(token_sizes, key, (meta, tuple(t._version for t in meta)))
     return meta

@@ -120,6 +120,86 @@ __global__ __launch_bounds__(RUA_BLOCK) void pack_meta_kernel(const int64_t* __r
   }
 }
 
+// Everything pack() needs in ONE launch when T and B are moderate (mid-size batches spend as long in the launch
+// gaps of five tiny kernels as in their payload): block 0 computes batch_sizes AND their exclusive offsets (T <=
+// one scan tile), block 1 the exclusive offsets of the lengths (a looping single-block scan, B <= 16 tiles),
+// the other blocks invert the permutation.
+constexpr int64_t PREP_T_MAX = SCAN_TILE;
+constexpr int64_t PREP_B_MAX = 16 * SCAN_TILE;
+
+__global__ __launch_bounds__(RUA_BLOCK) void pack_prepare_kernel(const int64_t* __restrict__ lens,
+                                                                 const int64_t* __restrict__ sorted, int64_t B,
+                                                                 int64_t T, int64_t* __restrict__ unsorted,
+                                                                 int64_t* __restrict__ bsz,
+                                                                 int64_t* __restrict__ boff,
+                                                                 int64_t* __restrict__ off) {
+  if (blockIdx.x == 0) {
+    // batch_sizes: lens[sorted[r]] is non-increasing in r, bsz[t] = #{r : lens[sorted[r]] > t}.  A lane takes the
+    // time steps tid, tid + 256, ... and runs their searches in LOCKSTEP (fixed trip count, SCAN_ITEMS independent
+    // load pairs in flight per step): the chain is as long as one search, not SCAN_ITEMS of them.
+    __shared__ int64_t s_bsz[SCAN_TILE];
+    int64_t lo[SCAN_ITEMS], hi[SCAN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) { lo[k] = 0; hi[k] = ((int64_t)threadIdx.x + k * RUA_BLOCK < T) ? B : 0; }
+    for (int64_t span = B; span > 0; span >>= 1) {
+#pragma unroll
+      for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const bool go = lo[k] < hi[k];
+        const int64_t mid = (lo[k] + hi[k]) >> 1;
+        int64_t b = go ? sorted[mid] : 0;
+        if (b < 0 || b >= B) b = 0;                       // a corrupt order must not index out of range
+        const int64_t v = go ? lens[b] : 0;
+        if (go) { if (v > (int64_t)threadIdx.x + k * RUA_BLOCK) lo[k] = mid + 1; else hi[k] = mid; }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+      const int64_t t = (int64_t)threadIdx.x + k * RUA_BLOCK;
+      s_bsz[t] = lo[k];
+      if (t < T) bsz[t] = lo[k];
+    }
+    __syncthreads();
+    // their exclusive offsets: thread k owns SCAN_ITEMS consecutive time steps, so the per-thread order is the
+    // global order
+    const int64_t base = (int64_t)threadIdx.x * SCAN_ITEMS;
+    int64_t v[SCAN_ITEMS];
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) { v[k] = s_bsz[base + k]; s += v[k]; }
+    int64_t tot;
+    int64_t run = block_exclusive_scan(s, &tot);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+      if (base + k < T) boff[base + k] = run;
+      run += v[k];
+    }
+  } else if (blockIdx.x == 1) {
+    if (!off) return;
+    int64_t carry = 0;
+    for (int64_t tile = 0; tile < B; tile += SCAN_TILE) {      // block-uniform loop
+      const int64_t base = tile + (int64_t)threadIdx.x * SCAN_ITEMS;
+      int64_t v[SCAN_ITEMS];
+      int64_t s = 0;
+#pragma unroll
+      for (int k = 0; k < SCAN_ITEMS; ++k) { v[k] = (base + k < B) ? lens[base + k] : 0; s += v[k]; }
+      int64_t tot;
+      int64_t run = carry + block_exclusive_scan(s, &tot);
+#pragma unroll
+      for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < B) off[base + k] = run;
+        run += v[k];
+      }
+      carry += tot;
+    }
+  } else {
+    const int64_t i = (int64_t)(blockIdx.x - 2) * RUA_BLOCK + threadIdx.x;
+    if (i < B) {
+      const int64_t b = sorted[i];
+      if (b >= 0 && b < B) unsorted[b] = i;
+    }
+  }
+}
+
 __global__ __launch_bounds__(RUA_BLOCK) void lens_from_pack_kernel(const int64_t* __restrict__ bsz, int64_t T,
                                                                    const int64_t* __restrict__ unsorted,
                                                                    int64_t B, int64_t* __restrict__ lens) {
@@ -207,6 +287,23 @@ int rua_pack_meta(const int64_t* lens, const int64_t* sorted, int64_t B, int64_t
   hipLaunchKernelGGL(pack_meta_kernel, dim3(grid_for(n)), dim3(RUA_BLOCK), 0, (hipStream_t)stream, lens, sorted, B,
                      T, unsorted, bsz);
   return (int)hipGetLastError();
+}
+
+int rua_pack_prepare(const int64_t* lens, const int64_t* sorted, int64_t B, int64_t T, int64_t* unsorted,
+                     int64_t* bsz, int64_t* boff, int64_t* off, int64_t* ws, void* stream) {
+  if (B < 0 || T < 0) return RUA_EINVAL;
+  if (B == 0) return 0;
+  if (!lens || !sorted || !unsorted || (T > 0 && (!bsz || !boff))) return RUA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (T <= PREP_T_MAX && B <= PREP_B_MAX) {
+    hipLaunchKernelGGL(pack_prepare_kernel, dim3(2 + grid_for(B)), dim3(RUA_BLOCK), 0, s, lens, sorted, B, T, unsorted,
+                       bsz, boff, off);
+    return (int)hipGetLastError();
+  }
+  int r = rua_pack_meta(lens, sorted, B, T, unsorted, bsz, stream);
+  if (r == 0 && T > 0) r = rua_exclusive_scan_i64(bsz, boff, nullptr, T, ws, stream);
+  if (r == 0 && off) r = rua_exclusive_scan_i64(lens, off, nullptr, B, ws, stream);
+  return r;
 }
 
 int rua_lens_from_pack(const int64_t* bsz, int64_t T, const int64_t* unsorted, int64_t B, int64_t* lens,
