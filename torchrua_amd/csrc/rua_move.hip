@@ -208,11 +208,20 @@ constexpr int64_t TILE_LDS_MAX_ROW_BYTES = 64;   // at or below: pack_tile_lds_k
 // source / destination row of its token, or -1
 template <bool TO_PACK>
 __device__ __forceinline__ void tile_phase1(const rua_layout& Pk, const rua_layout& Ot, int64_t* s_ld, int64_t* s_st) {
-  // which time chunk does this tile belong to?  largest c with tile_start[c] <= blockIdx.x
+  // which time chunk does this tile belong to?  largest c with tile_start[c] <= blockIdx.x.  Up to 64 chunks
+  // (T <= 1 024) every lane loads one entry and a ballot counts them: ONE load instead of a six-step chain of
+  // dependent ones — an 8-KiB tile lives for ~8 us, most of it waiting on such chains.
   int64_t lo = 0, hi = Pk.n_tchunks;
-  while (hi - lo > 1) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (Pk.tile_start[mid] <= (int64_t)blockIdx.x) lo = mid; else hi = mid;
+  if (Pk.n_tchunks <= RUA_WAVE) {
+    const int lane = threadIdx.x & (RUA_WAVE - 1);
+    const int64_t v = lane < Pk.n_tchunks ? Pk.tile_start[lane] : 0x7fffffffffffffffLL;
+    lo = (int64_t)__popcll(__ballot(v <= (int64_t)blockIdx.x)) - 1;
+    if (lo < 0) lo = 0;
+  } else {
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (Pk.tile_start[mid] <= (int64_t)blockIdx.x) lo = mid; else hi = mid;
+    }
   }
   const int64_t t0 = lo * TT;
   const int64_t r0 = ((int64_t)blockIdx.x - Pk.tile_start[lo]) * TR;
