@@ -164,3 +164,36 @@ def test_ops_replay_inside_a_hip_graph():
         want = ops(ta.with_host_sizes(fresh, lens))
         for got, exp in zip(outs, want):
             assert torch.equal(got, exp)
+
+
+def test_ops_follow_the_current_stream():
+    """Everything is enqueued on torch's CURRENT stream (metadata uploads ride their own upload stream and the current
+    one waits for them): a whole chain under a non-default stream, consumed on the default stream after the usual
+    wait_stream, and many back-to-back steps that recycle the pinned staging ring."""
+    g = torch.Generator().manual_seed(3)
+    lens = torch.randint(1, 50, (300,), generator=g)
+    data = torch.randn(int(lens.sum()), 24, generator=g)
+    exp_sum = torch.stack([x.sum(0) for x in torch.split(data, lens.tolist())])
+    s1 = torch.cuda.Stream()
+    dd = data.to(DEV)
+    s1.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s1):
+        c = ta.with_host_sizes(dd, lens)
+        p = c.pack()
+        out = ta.reduce_sum(p)
+        back = p.roll(2).roll(-2).cat().data
+    torch.cuda.current_stream().wait_stream(s1)
+    torch.testing.assert_close(out.cpu(), exp_sum, rtol=1e-5, atol=1e-5)
+    assert torch.equal(back, dd)
+    for p_ in (p.data, out, back):
+        p_.record_stream(torch.cuda.current_stream())
+    # 100 steps with fresh lengths each (3 uploads per step through a 32-slot ring), no sync in between
+    outs = []
+    for i in range(100):
+        li = torch.roll(lens, i)
+        ci = ta.with_host_sizes(dd, li)
+        outs.append((li, ta.reduce_sum(ci.pack())))
+    torch.cuda.synchronize()
+    for li, o in outs[::7]:
+        ref = torch.stack([x.sum(0) for x in torch.split(data, li.tolist())])
+        torch.testing.assert_close(o.cpu(), ref, rtol=1e-5, atol=1e-5)
