@@ -182,7 +182,7 @@ int rua_pack_reduce(const rua_layout* src, const rua_layout* pack, const void* d
  *   MAX/MIN g/ties where x == out, else 0.
  * grad_in has the storage of `data`; rows of padded layouts that hold no token are NOT written.
  * With `perm` it is the gradient w.r.t. the SOURCE rows of scatter_* (reduce.py:6-31); include_self != 0 then
- * counts the old destination row in MEAN's divisor (MAX/MIN ties with the old row are the caller's business).
+ * counts the old destination row in MEAN's divisor (MAX/MIN: seed `ties` with the old row's tie, below).
  * split_rows / ws as in rua_segment_reduce.
  * ties (MAX/MIN; may be NULL): [B, H] accumulators (f32, f64 for RUA_F64) that the caller pre-sets to the ties
  * the rows of `data` do not see (0, or 1 where the old destination row of a scatter_max/min with include_self
