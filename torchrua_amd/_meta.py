@@ -168,7 +168,15 @@ def adopt_pack(p, lens: Tensor, boff: Tensor, bsz_dev: Tensor) -> None:
     dev = p.data.device
     _memo_put(p.batch_sizes, f'boff:{dev}', boff)
     _memo_put(p.batch_sizes, f'dev:{dev}', bsz_dev)
-    _memo_put(p.batch_sizes, 'lens', (p.unsorted_indices, lens))
+    # The lengths are kept as an ALIAS (same storage and version counter, another tensor object) that inherits the
+    # plain-data memos: `lens` itself memoises this very batch_sizes (core._pack_meta), and batch_sizes pointing
+    # back at it would close a reference cycle per pack() — cyclic garbage that forces full GC passes.
+    alias = lens.detach()
+    for key in ('host', 'max', 'sum', 'off'):
+        hit = _memo_get(lens, key)
+        if hit is not None:
+            _memo_put(alias, key, hit)
+    _memo_put(p.batch_sizes, 'lens', (p.unsorted_indices, alias))
 
 
 def batch_sizes_from_host_lens(h: Tensor, T: int) -> Tensor:
@@ -331,10 +339,15 @@ class _StagingRing:
             side = self.side
             if side is None:
                 side = self.side = torch.cuda.Stream(dev)
-            with torch.cuda.stream(side):
+            # (set_stream twice instead of the `torch.cuda.stream` context manager: a third of its cost, and this
+            # runs twice per pack())
+            torch.cuda.set_stream(side)
+            try:
                 out = torch.empty(host.shape, dtype=host.dtype, device=dev)
                 out.copy_(staged, non_blocking=True)
                 ev.record(side)
+            finally:
+                torch.cuda.set_stream(cur)
             cur.wait_event(ev)
             out.record_stream(cur)
         self.events[i] = ev

@@ -22,12 +22,22 @@ def set_kernel_hook(fn) -> None:
     _kernel_hook = fn
 
 
+_fill_cache = {}
+
+
 def _fill16(value, dtype: torch.dtype) -> bytes:
-    """The fill element replicated to 16 bytes (as the kernel's uint4 pattern)."""
+    """The fill element replicated to 16 bytes (as the kernel's uint4 pattern); memoised per (value, dtype)."""
+    key = (value, dtype) if isinstance(value, (int, float, bool, bytes)) else None
+    hit = _fill_cache.get(key) if key is not None else None
+    if hit is not None:
+        return hit
     raw = value if isinstance(value, bytes) else torch.tensor([value], dtype=dtype).view(torch.uint8).numpy().tobytes()
     if len(raw) > 16:
         raise L.RuaError(f'fill element wider than 16 bytes ({dtype})')
-    return (raw * (16 // len(raw)))[:16]
+    out = (raw * (16 // len(raw)))[:16]
+    if key is not None and len(_fill_cache) < 256:
+        _fill_cache[key] = out
+    return out
 
 
 class MovePlan:

@@ -79,7 +79,7 @@ def _pack_meta(token_sizes: Tensor, dev: torch.device):
     key = f'pack_meta:{dev}'
     hit = M._memo_get(token_sizes, key)
     if hit is not None and all(t._version == v for t, v in zip(hit[0], hit[1])):
-        return hit[0]
+        return (lens,) + hit[0]
     host, index = _sorted_indices(token_sizes)
     B = lens.numel()
     T = M.max_len(token_sizes)
@@ -96,9 +96,11 @@ def _pack_meta(token_sizes: Tensor, dev: torch.device):
                                  K.stream_ptr(dev)), 'rua_pack_prepare')
     if need_off:
         M._memo_put(token_sizes, 'off', off)      # the CattedSequence side of the cast needs them next
-    meta = (lens, sorted_indices, unsorted, batch_sizes, bsz_dev, boff)
+    # (`lens` itself stays out of the memo: a tensor whose memo holds the tensor is a reference cycle, and cyclic
+    # garbage made at every step drives Python into full collections — 38 ms each with torch's heap to scan)
+    meta = (sorted_indices, unsorted, batch_sizes, bsz_dev, boff)
     M._memo_put(token_sizes, key, (meta, tuple(t._version for t in meta)))
-    return meta
+    return (lens,) + meta
 
 
 def _pack_view(self: Union[C, L, R], **kwargs) -> P:
