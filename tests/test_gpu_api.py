@@ -197,3 +197,37 @@ def test_ops_follow_the_current_stream():
     for li, o in outs[::7]:
         ref = torch.stack([x.sum(0) for x in torch.split(data, li.tolist())])
         torch.testing.assert_close(o.cpu(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_no_cyclic_garbage_per_step():
+    """The memos and plans an op leaves behind must be freed by reference counting alone: cyclic garbage created at
+    every step pushes CPython into full collections (tens of ms with torch's heap to scan)."""
+    import gc
+    g = torch.Generator().manual_seed(5)
+    lens = torch.randint(1, 40, (200,), generator=g)
+    data = torch.randn(int(lens.sum()), 16, generator=g).to(DEV)
+    idx = torch.randint(0, 200, (data.size(0),), generator=g).to(DEV)
+
+    def step():
+        c = ta.with_host_sizes(data, lens)
+        p = c.pack()
+        out = ta.reduce_sum(p) + ta.reduce_max(c.left()) + ta.segment_logsumexp(c.data, c.token_sizes)
+        q = p.roll(1).rev().cat().right().pack()
+        x = data.clone().requires_grad_(True)
+        z = ta.C(x, c.token_sizes).pack()
+        (ta.reduce_max(z).sum() + z.roll(2).left().data.sum()).backward()
+        s = ta.scatter_sum(torch.zeros(200, 16, device=DEV), idx, data)
+        xs = c.split()
+        return out, q, x.grad, s, ta.C.new(xs).last(), p.head(1), c.trunc((0, 0)), c.bmask()
+
+    for _ in range(3):
+        step()
+    gc.collect()
+    gc.disable()
+    try:
+        for _ in range(3):
+            keep = step()
+        del keep
+        assert gc.collect() == 0
+    finally:
+        gc.enable()
