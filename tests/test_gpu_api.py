@@ -231,3 +231,30 @@ def test_no_cyclic_garbage_per_step():
         assert gc.collect() == 0
     finally:
         gc.enable()
+
+
+def test_chains_with_a_host_mirror_never_sync():
+    """Lengths that came from the host (C.new / with_host_sizes) are mirrored, and the mirror travels through
+    pack / cat / pad / roll / trunc: no op of such a chain may read anything back from the device (the reference pays a
+    blocking .item() or .cpu() in every size() and pack_view, layout/cat.py:61-66, core/view.py:48)."""
+    g = torch.Generator().manual_seed(9)
+    lens = torch.randint(2, 30, (500,), generator=g)
+    data = torch.randn(int(lens.sum()), 8, generator=g).to(DEV)
+    c = ta.with_host_sizes(data, lens)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        p = c.pack()
+        c2 = p.cat()
+        p2 = c2.pack()                      # the mirror came along through the PackedSequence
+        l = c2.left(0.5)
+        p3 = l.pack()
+        r = p3.roll(3).rev().right()
+        outs = (ta.reduce_sum(p2), ta.reduce_max(l), ta.reduce_logsumexp(r), p3.last(), c2.head(2).data, c2.trunc((1, 0)).data)
+        size = (c2.size(), l.size(), p2.size())
+        with pytest.raises(RuntimeError):   # the detector itself works: a device-only length vector must be read back
+            ta.C(data, lens.to(DEV, non_blocking=True)).pack()
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    assert torch.equal(c2.data, data) and torch.equal(p2.data, p.data) and size[0][:2] == (500, int(lens.max()))
+    assert all(bool(torch.isfinite(o).all()) for o in outs)
