@@ -138,6 +138,7 @@ int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32_t tmap, in
 
 /* ---- reductions ------------------------------------------------------------ */
 enum rua_dtype { RUA_F32 = 0, RUA_BF16 = 1, RUA_F16 = 2, RUA_F64 = 3 };
+#define RUA_TIES_FINAL 2   /* rua_segment_reduce_backward's include_self: see there */
 enum rua_op {
   RUA_SUM = 0, RUA_MEAN = 1, RUA_MAX = 2, RUA_MIN = 3, RUA_PROD = 4, RUA_LOGSUMEXP = 5
 };
@@ -160,11 +161,15 @@ enum rua_op {
  *               2 rows of empty sequences are left untouched (torch.index_reduce semantics).
  * split_rows > 0 (with `ws` of rua_reduce_ws_bytes(lay->n_rows, H, dtype, split_rows) bytes) cuts sequences
  * longer than split_rows into parts handled by separate waves (published through a device-side work list,
- * fp32 partials folded in part order: deterministic); 0 = one wave streams each sequence. */
+ * fp32 partials folded in part order: deterministic); 0 = one wave streams each sequence.
+ * ties_out (MAX/MIN with include_self == 0 and no perm; may be NULL): [B, H] f32 (f64 for RUA_F64) that receives, per
+ * output element, how many elements of the sequence equal it — what the backward needs, for free in the pass that
+ * reads the payload anyway (rua_segment_reduce_backward with include_self = RUA_TIES_FINAL then takes ONE walk). */
 int64_t rua_reduce_ws_bytes(int64_t n_rows, int64_t H, int32_t dtype, int64_t split_rows);
 int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* data, void* out,
                        int64_t H, int32_t dtype, int32_t op, int32_t include_self,
-                       uint64_t empty_bits, void* extreme, int64_t split_rows, void* ws, void* stream);
+                       uint64_t empty_bits, void* extreme, int64_t split_rows, void* ws, void* ties_out,
+                       void* stream);
 
 /* Fused pack + reduce (an EXTENSION: the reference has no one-call equivalent; it is exactly
  * core/cast.py:41-49 followed by the reduction of reduce.py:34-61 over the packed rows).  One pass over
@@ -188,7 +193,8 @@ int rua_pack_reduce(const rua_layout* src, const rua_layout* pack, const void* d
  * the rows of `data` do not see (0, or 1 where the old destination row of a scatter_max/min with include_self
  * equals `out`).  The kernel adds every sequence's own ties (integer-valued float atomics: exact), then divides
  * the gradient by the total — which lets long sequences be split, and leaves the totals for the caller.
- * With ties == NULL each sequence is counted and applied by one wave (no splitting for MAX/MIN). */
+ * With ties == NULL each sequence is counted and applied by one wave (no splitting for MAX/MIN).
+ * include_self == RUA_TIES_FINAL: `ties` already holds the complete counts (the forward's ties_out): no counting walk. */
 int rua_segment_reduce_backward(const rua_layout* lay, const int64_t* perm, const void* data, const void* out,
                                 const void* grad_out, void* grad_in, int64_t H, int32_t dtype, int32_t op,
                                 int32_t include_self, int64_t split_rows, void* ws, void* ties, void* stream);

@@ -47,7 +47,7 @@ int main(void) {
   pack.kind = RUA_PACK; pack.n_rows = N; pack.B = B; pack.lens = d_lens; pack.boff = d_boff; pack.T = T;
   pack.sorted = d_sorted; pack.unsorted = d_unsorted;
   CHECK(rua_move_rows(&pack, &cat, RUA_T_SHIFT, 0, d_pack, d_data, H * sizeof(float), NULL, -1, 0, s));
-  CHECK(rua_segment_reduce(&pack, NULL, d_pack, d_out, H, RUA_F32, RUA_SUM, 0, 0, NULL, 0, NULL, s));
+  CHECK(rua_segment_reduce(&pack, NULL, d_pack, d_out, H, RUA_F32, RUA_SUM, 0, 0, NULL, 0, NULL, NULL, s));
   CHECK(hipStreamSynchronize(s));
 
   /* the one-call form of the three metadata steps above must agree with them */

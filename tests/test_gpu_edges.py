@@ -190,6 +190,38 @@ def test_infinities_nan_and_empty_segments_like_the_reference(lens, dtype):
                 np.testing.assert_allclose(pk[ok], ref[ok], rtol=1e-5 + ulp, atol=1e-6, err_msg=f'{what} {name} P')
 
 
+def test_max_min_backward_counts_come_from_the_forward():
+    """The differentiable forward of max/min also counts the elements equal to the extreme (so the backward is one
+    walk): ties inside one chunk, across chunks and row groups, every layout, split sequences — against autograd through torch.segment_reduce on the CPU (positive cotangents: DESIGN §5)."""
+    g = torch.Generator().manual_seed(21)
+    lens = [1, 300, 7, 64, 65, 5000, 2, 129]
+    lt = torch.tensor(lens)
+    for h, dtype in ((8, torch.float32), (24, torch.float32), (512, torch.float32), (130, torch.float64)):
+        x = torch.randint(0, 3, (sum(lens), h), generator=g).to(dtype)
+        cot = (torch.rand(len(lens), h, generator=g) + 0.1).to(dtype)
+        for name in ('max', 'min'):
+            r = x.clone().requires_grad_(True)
+            ref = torch.segment_reduce(r, name, lengths=lt, unsafe=True)
+            ref.backward(cot)
+            for kind in 'CLPR':
+                xs = x.clone().to(DEV).requires_grad_(True)
+                c = ta.with_host_sizes(xs, lt)
+                z = {'C': lambda: c, 'L': c.left, 'P': c.pack, 'R': c.right}[kind]()
+                out = getattr(ta, f'reduce_{name}')(z)
+                out.backward(cot.to(DEV))
+                torch.testing.assert_close(out.detach().cpu(), ref.detach())
+                torch.testing.assert_close(xs.grad.cpu(), r.grad, rtol=1e-6, atol=1e-7, msg=f'{name} {kind} h={h}')
+    # a NaN result: its NaN elements are the hits and share the gradient (column 0; every sequence holds one there, so
+    # the reference's NaN-poisoned `initial` changes nothing in that column)
+    x = torch.tensor([[float('nan'), 1.0], [1.0, 2.0], [float('nan'), 3.0], [float('nan'), 4.0], [5.0, 0.0]])
+    lt2 = torch.tensor([3, 2])
+    r = x.clone().requires_grad_(True)
+    torch.segment_reduce(r, 'max', lengths=lt2, unsafe=True).backward(torch.ones(2, 2))
+    xs = x.clone().to(DEV).requires_grad_(True)
+    ta.segment_max(xs, lt2.to(DEV)).backward(torch.ones(2, 2, device=DEV))
+    assert xs.grad[:, 0].tolist() == r.grad[:, 0].tolist() == [0.5, 0.0, 0.5, 1.0, 0.0]
+
+
 def test_non_contiguous_and_views():
     data, lt = _mk([4, 2, 5, 1], (8,), torch.float32)
     wide = torch.randn(12, 16, device=DEV)

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get('RUA_LIB_PATH') or os.path.join(_HERE, 'librua_hip.so'
 CAT, LEFT, PACK, RIGHT, LIST = 0, 1, 2, 3, 4
 # enum rua_tmap
 T_SHIFT, T_ROLL, T_REV_S, T_REV_D, T_ZERO = 0, 1, 2, 3, 4
+TIES_FINAL = 2      # rua_segment_reduce_backward include_self: `ties` came complete from the forward
 MOVE_SCATTER = 1
 # enum rua_dtype / rua_op
 F32, BF16, F16, F64 = 0, 1, 2, 3
@@ -55,7 +56,7 @@ SYMBOLS = {
                               c_int64, c_void_p, c_int64, c_int32, c_void_p]),
     'rua_reduce_ws_bytes': (c_int64, [c_int64, c_int64, c_int32, c_int64]),
     'rua_segment_reduce': (c_int, [POINTER(RuaLayout), c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
-                                   c_int32, c_uint64, c_void_p, c_int64, c_void_p, c_void_p]),
+                                   c_int32, c_uint64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     'rua_pack_reduce': (c_int, [POINTER(RuaLayout), POINTER(RuaLayout), c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                 c_int32, c_uint64, c_void_p, c_int64, c_void_p, c_void_p]),
     'rua_segment_reduce_backward': (c_int, [POINTER(RuaLayout), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -136,7 +136,7 @@ def split_workspace(lay: M.Lay, H: int, dtype: torch.dtype, dev) -> Tuple[int, O
 
 def launch_reduce(lay: M.Lay, data: Tensor, op: int, out: Optional[Tensor] = None, include_self: int = 0,
                   perm: Optional[Tensor] = None, hidden: Tuple[int, ...] = (), reference_initial: bool = True,
-                  name: str = 'reduce') -> Tensor:
+                  name: str = 'reduce', ties_out: Optional[Tensor] = None) -> Tensor:
     """rua_segment_reduce (+ rua_fill_empty for the reference's global-extreme `initial`)."""
     dev = L.require_device(data)
     lib = L.load()
@@ -156,7 +156,7 @@ def launch_reduce(lay: M.Lay, data: Tensor, op: int, out: Optional[Tensor] = Non
         _kernel_hook(name, True)
     L.check(lib.rua_segment_reduce(lay.ref(), L.ptr(perm), L.ptr(data), L.ptr(out), H, L.DTYPES[data.dtype], op,
                                    include_self, _bits(_EMPTY[op], data.dtype), L.ptr(extreme), split, L.ptr(ws),
-                                   L.stream_ptr(dev)), 'rua_segment_reduce')
+                                   L.ptr(ties_out), L.stream_ptr(dev)), 'rua_segment_reduce')
     if _kernel_hook:
         _kernel_hook(name, False)
     if extreme is not None:
@@ -168,16 +168,22 @@ def launch_reduce(lay: M.Lay, data: Tensor, op: int, out: Optional[Tensor] = Non
 class _Reduce(torch.autograd.Function):
     @staticmethod
     def forward(ctx, data: Tensor, lay: M.Lay, op: int, hidden, lens: Optional[Tensor]):
-        out = launch_reduce(lay, data, op, hidden=hidden)
-        ctx.lay, ctx.op, ctx.lens = lay, op, lens
+        ties = None
+        if op in (L.MAX, L.MIN):
+            # the forward counts, per output element, the elements equal to it (free in the pass that reads the payload
+            # anyway): the backward is then ONE walk instead of a counting walk plus an applying walk
+            acc = torch.float64 if data.dtype == torch.float64 else torch.float32
+            ties = torch.empty((lay.B,) + tuple(hidden), dtype=acc, device=data.device)
+        out = launch_reduce(lay, data, op, hidden=hidden, ties_out=ties)
+        ctx.lay, ctx.op, ctx.lens, ctx.ties = lay, op, lens, ties
         ctx.save_for_backward(data.contiguous(), out)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad: Tensor):
-        """One fused kernel (rua_segment_reduce_backward): reads the payload once (twice for max/min: the tie
-        count), writes the gradient once — no [N, H] temporaries."""
+        """One fused kernel (rua_segment_reduce_backward): reads the payload once (max/min: the forward already
+        counted the ties), writes the gradient once — no [N, H] temporaries."""
         data, out = ctx.saved_tensors
         lay, op = ctx.lay, ctx.op
         dev = L.require_device(data)
@@ -189,13 +195,11 @@ class _Reduce(torch.autograd.Function):
         for d in out.shape[1:]:
             H *= d
         split, ws = split_workspace(lay, H, data.dtype, dev)
-        ties = None
-        if split and op in (L.MAX, L.MIN):     # long sequences: count ties across parts first, then apply
-            ties = torch.zeros(out.shape, dtype=torch.float64 if data.dtype == torch.float64 else torch.float32,
-                               device=dev)
+        ties = ctx.ties                        # max/min: counted by the forward -> apply only (TIES_FINAL)
         L.check(lib.rua_segment_reduce_backward(lay.ref(), None, L.ptr(data), L.ptr(out), L.ptr(grad), L.ptr(g), H,
-                                                L.DTYPES[data.dtype], op, 0, split, L.ptr(ws), L.ptr(ties),
-                                                L.stream_ptr(dev)), 'rua_segment_reduce_backward')
+                                                L.DTYPES[data.dtype], op, L.TIES_FINAL if ties is not None else 0,
+                                                split, L.ptr(ws), L.ptr(ties), L.stream_ptr(dev)),
+                'rua_segment_reduce_backward')
         return g, None, None, None, None
 
 

@@ -14,10 +14,10 @@ __global__ void extreme_init_entry_kernel(unsigned long long* ext, int want_max_
 #define RUA_DECL(NAME)                                                                                              \
   int reduce_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data, void* out,  \
                     int64_t H, int include_self, uint64_t empty_bits, void* extreme, int64_t split, void* ws,     \
-                    const rua_layout* CD, void* copy);                                                             \
+                    const rua_layout* CD, void* copy, void* ties);                                                 \
   int backward_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,           \
                       const void* out, const void* gout, void* gin, int64_t H, int extra_count, int64_t split,    \
-                      void* ws, void* ties);                                                                       \
+                      void* ws, void* ties, bool ties_final);                                                      \
   int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, const void* ext);
 RUA_DECL(f32) RUA_DECL(bf16) RUA_DECL(f16) RUA_DECL(f64)
 #undef RUA_DECL
@@ -39,11 +39,12 @@ int rua_segment_reduce_backward(const rua_layout* lay, const int64_t* perm, cons
   if (lay->B == 0 || H == 0 || lay->n_rows == 0) return 0;
   if (!data || !out || !grad_out || !grad_in) return RUA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  const bool final = include_self == RUA_TIES_FINAL && ties != nullptr;   // the forward counted them (ties_out)
   switch (dtype) {
-    case RUA_F32: return backward_f32(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self ? 1 : 0, split_rows, ws, ties);
-    case RUA_BF16: return backward_bf16(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self ? 1 : 0, split_rows, ws, ties);
-    case RUA_F16: return backward_f16(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self ? 1 : 0, split_rows, ws, ties);
-    case RUA_F64: return backward_f64(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self ? 1 : 0, split_rows, ws, ties);
+    case RUA_F32: return backward_f32(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final);
+    case RUA_BF16: return backward_bf16(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final);
+    case RUA_F16: return backward_f16(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final);
+    case RUA_F64: return backward_f64(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final);
   }
   return RUA_EINVAL;
 }
@@ -60,7 +61,7 @@ int64_t rua_reduce_ws_bytes(int64_t n_rows, int64_t H, int32_t dtype, int64_t sp
 
 int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* data, void* out, int64_t H,
                        int32_t dtype, int32_t op, int32_t include_self, uint64_t empty_bits, void* extreme,
-                       int64_t split_rows, void* ws, void* stream) {
+                       int64_t split_rows, void* ws, void* ties, void* stream) {
   if (!lay || H < 0 || lay->B < 0) return RUA_EINVAL;
   if (lay->kind != RUA_CAT && lay->kind != RUA_PACK && lay->kind != RUA_LEFT && lay->kind != RUA_RIGHT)
     return RUA_EINVAL;
@@ -69,16 +70,17 @@ int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* d
   if (perm && lay->kind != RUA_CAT) return RUA_EINVAL;
   if (lay->B == 0 || H == 0) return 0;
   if (!out || (lay->n_rows > 0 && !data)) return RUA_EINVAL;
+  if (ties && (include_self != 0 || perm || (op != RUA_MAX && op != RUA_MIN))) return RUA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (extreme && (op == RUA_MAX || op == RUA_MIN || op == RUA_LOGSUMEXP)) {
     hipLaunchKernelGGL(extreme_init_entry_kernel, dim3(1), dim3(128), 0, s, (unsigned long long*)extreme,
                        op == RUA_MIN ? 1 : 0);
   }
   switch (dtype) {
-    case RUA_F32: return reduce_f32(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr);
-    case RUA_BF16: return reduce_bf16(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr);
-    case RUA_F16: return reduce_f16(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr);
-    case RUA_F64: return reduce_f64(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr);
+    case RUA_F32: return reduce_f32(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr, ties);
+    case RUA_BF16: return reduce_bf16(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr, ties);
+    case RUA_F16: return reduce_f16(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr, ties);
+    case RUA_F64: return reduce_f64(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr, ties);
   }
   return RUA_EINVAL;
 }
@@ -97,10 +99,10 @@ int rua_pack_reduce(const rua_layout* src, const rua_layout* pack, const void* d
     hipLaunchKernelGGL(extreme_init_entry_kernel, dim3(1), dim3(128), 0, s, (unsigned long long*)extreme,
                        op == RUA_MIN ? 1 : 0);
   switch (dtype) {
-    case RUA_F32: return reduce_f32(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data);
-    case RUA_BF16: return reduce_bf16(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data);
-    case RUA_F16: return reduce_f16(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data);
-    case RUA_F64: return reduce_f64(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data);
+    case RUA_F32: return reduce_f32(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data, nullptr);
+    case RUA_BF16: return reduce_bf16(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data, nullptr);
+    case RUA_F16: return reduce_f16(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data, nullptr);
+    case RUA_F64: return reduce_f64(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data, nullptr);
   }
   return RUA_EINVAL;
 }

@@ -146,6 +146,26 @@ __device__ __forceinline__ Unit<T, EPL> make_unit(const rua_layout& L, const rua
   return u;
 }
 
+// Internal ops: max / min that ALSO count how many elements equal the extreme (in `aux`).  The forward of a
+// differentiable reduce_max/min uses them and stores the counts, so the backward is ONE walk (read x, write
+// g / ties where x == out) instead of a counting walk plus an applying walk — two passes over the payload, not three.
+constexpr int RUA_MAX_T = 6, RUA_MIN_T = 7;
+constexpr bool op_is_max(int op) { return op == RUA_MAX || op == RUA_MAX_T; }
+constexpr bool op_is_min(int op) { return op == RUA_MIN || op == RUA_MIN_T; }
+constexpr bool op_counts(int op) { return op == RUA_MAX_T || op == RUA_MIN_T; }
+constexpr bool op_uses_aux(int op) { return op == RUA_LOGSUMEXP || op_counts(op); }
+
+// (extreme, count) <- merge with (x, c).  NaN is the extreme of extremes (torch: max/min propagate NaN, and the
+// backward treats NaN elements as the hits of a NaN result), -inf/+inf start values carry count 0.
+template <typename A, bool IS_MAX>
+__device__ __forceinline__ void tie_update(A& acc, A& cnt, A x, A c) {
+  const bool xn = x != x, an = acc != acc;
+  const bool better = xn ? !an : (!an && (IS_MAX ? x > acc : x < acc));
+  const bool equal = xn ? an : (x == acc);
+  cnt = better ? c : (equal ? cnt + c : cnt);
+  acc = better ? x : acc;
+}
+
 // running state of one lane
 template <typename A, int EPL>
 struct Fold {
@@ -156,8 +176,8 @@ template <typename A, int EPL, int OP>
 __device__ __forceinline__ void fold_init(Fold<A, EPL>& f) {
 #pragma unroll
   for (int e = 0; e < EPL; ++e) {
-    f.acc[e] = (OP == RUA_PROD) ? (A)1 : (OP == RUA_MAX || OP == RUA_LOGSUMEXP) ? -acc_inf<A>()
-             : (OP == RUA_MIN) ? acc_inf<A>() : (A)0;
+    f.acc[e] = (OP == RUA_PROD) ? (A)1 : (op_is_max(OP) || OP == RUA_LOGSUMEXP) ? -acc_inf<A>()
+             : op_is_min(OP) ? acc_inf<A>() : (A)0;
     f.aux[e] = (A)0;
   }
 }
@@ -264,6 +284,63 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
 #pragma unroll
           for (int u = 0; u < UT; ++u) f.aux[ce] += fexp(x[u] - m);   // NaN x -> NaN sum, as the reference
         }
+      } else if (op_counts(OP)) {
+        // max / min that also count the elements equal to the extreme, chunk-wise like logsumexp so that it stays
+        // near the memory rate (~5 issue slots per element; a per-element (extreme, count) update is ~15 and made
+        // the forward three times slower): (A) the chunk's extreme per column, (B) ONE reset of the count per
+        // column if the extreme moved, (C) count += (x == extreme) per element.
+        constexpr bool MX = OP == RUA_MAX_T;
+        A m[EPL * CPW];
+#pragma unroll
+        for (int ce = 0; ce < EPL * CPW; ++ce) m[ce] = f.acc[ce];
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+          if (row[u] < 0) continue;
+#pragma unroll
+          for (int ce = 0; ce < EPL * CPW; ++ce) {
+            const int c = ce / EPL, e = ce % EPL;
+            if (CPW > 1 && col + c * CW >= H) continue;
+            const A x = elem<T>::up(p[u][c].v[e]);
+            m[ce] = MX ? nmax(m[ce], x) : nmin(m[ce], x);
+          }
+        }
+        bool any_nan = false;
+#pragma unroll
+        for (int ce = 0; ce < EPL * CPW; ++ce) {
+          const bool mn = m[ce] != m[ce];
+          const bool same = (m[ce] == f.acc[ce]) || (mn && f.acc[ce] != f.acc[ce]);
+          f.aux[ce] = same ? f.aux[ce] : (A)0;                      // the extreme moved (or turned NaN): start over
+          any_nan |= mn;
+        }
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+          if (row[u] < 0) continue;
+#pragma unroll
+          for (int ce = 0; ce < EPL * CPW; ++ce) {
+            const int c = ce / EPL, e = ce % EPL;
+            if (CPW > 1 && col + c * CW >= H) continue;
+            const A x = elem<T>::up(p[u][c].v[e]);
+            f.aux[ce] += (x == m[ce]) ? (A)1 : (A)0;
+          }
+        }
+        if (any_nan) {
+          // rare: a NaN extreme counts its NaN elements (torch's backward treats them as the hits of a NaN result)
+#pragma unroll
+          for (int ce = 0; ce < EPL * CPW; ++ce) {
+            if (m[ce] == m[ce]) continue;
+            const int c = ce / EPL, e = ce % EPL;
+            A k = f.aux[ce];                                         // NaNs counted in earlier chunks (or 0)
+#pragma unroll
+            for (int u = 0; u < UT; ++u) {
+              if (row[u] < 0 || (CPW > 1 && col + c * CW >= H)) continue;
+              const A x = elem<T>::up(p[u][c].v[e]);
+              k += (x != x) ? (A)1 : (A)0;
+            }
+            f.aux[ce] = k;
+          }
+        }
+#pragma unroll
+        for (int ce = 0; ce < EPL * CPW; ++ce) f.acc[ce] = m[ce];
       } else {
 #pragma unroll
         for (int u = 0; u < UT; ++u) {
@@ -298,6 +375,7 @@ __device__ __forceinline__ void fold_wave(Fold<A, EPL>& f, int lp_log2) {
       else if (OP == RUA_PROD) f.acc[e] *= o;
       else if (OP == RUA_MAX) f.acc[e] = nmax(f.acc[e], o);
       else if (OP == RUA_MIN) f.acc[e] = nmin(f.acc[e], o);
+      else if (op_counts(OP)) tie_update<A, OP == RUA_MAX_T>(f.acc[e], f.aux[e], o, __shfl_xor(f.aux[e], d, RUA_WAVE));
       else {
         const A os = __shfl_xor(f.aux[e], d, RUA_WAVE);
         const A m = nmax(f.acc[e], o);
@@ -319,6 +397,7 @@ __device__ __forceinline__ void fold_merge(Fold<A, EPL>& f, const A* acc2, const
     else if (OP == RUA_PROD) f.acc[e] *= o;
     else if (OP == RUA_MAX) f.acc[e] = nmax(f.acc[e], o);
     else if (OP == RUA_MIN) f.acc[e] = nmin(f.acc[e], o);
+    else if (op_counts(OP)) tie_update<A, OP == RUA_MAX_T>(f.acc[e], f.aux[e], o, aux2[e]);
     else {
       const A m = nmax(f.acc[e], o);
       if (m == -acc_inf<A>()) { f.aux[e] = f.aux[e] + aux2[e]; }
@@ -332,7 +411,8 @@ __device__ __forceinline__ void fold_merge(Fold<A, EPL>& f, const A* acc2, const
 //               2 = leave out[b] untouched when the sequence is empty (index_reduce semantics)
 template <typename T, int EPL, int OP, int CPW = 1, bool RANKS = false>
 __device__ __forceinline__ void fold_store(const Unit<T, EPL>& U, Fold<typename elem<T>::acc, EPL * CPW>& f,
-                                           T* __restrict__ out, int64_t H, int include_self, T empty_val) {
+                                           T* __restrict__ out, int64_t H, int include_self, T empty_val,
+                                           typename elem<T>::acc* __restrict__ ties = nullptr) {
   using A = typename elem<T>::acc;
   constexpr int CW = RUA_WAVE * EPL;
   const bool keep = include_self == 2 && U.len <= 0;
@@ -363,6 +443,7 @@ __device__ __forceinline__ void fold_store(const Unit<T, EPL>& U, Fold<typename 
       }
       if (OP == RUA_MEAN && cnt > 0) r = r / (A)cnt;
       o[e] = (cnt == 0) ? empty_val : elem<T>::down(r);
+      if (op_counts(OP) && ties) ties[U.b * H + U.col + c * CW + e] = f.aux[ce];   // elements equal to the extreme
     }
   }
 }
@@ -379,7 +460,7 @@ __device__ __forceinline__ void fold_store(const Unit<T, EPL>& U, Fold<typename 
 template <typename A, int EPL, int OP>
 __device__ __forceinline__ void fold_flags(const Fold<A, EPL>& f, unsigned long long* __restrict__ extreme,
                                            int lane, bool empty_unit) {
-  if (!(OP == RUA_MAX || OP == RUA_MIN || OP == RUA_LOGSUMEXP) || !extreme) return;
+  if (!(op_is_max(OP) || op_is_min(OP) || OP == RUA_LOGSUMEXP) || !extreme) return;
   bool nan = false;
 #pragma unroll
   for (int e = 0; e < EPL; ++e) nan |= (f.acc[e] != f.acc[e]);
@@ -400,6 +481,7 @@ struct SplitWs {
   void* partials;
   int64_t max_u;      // bound on extra items and on long units
   int64_t split;      // rows per part (0 = splitting off)
+  void* ties;         // [B, H] accumulators of the tie-counting max/min (RUA_MAX_T / RUA_MIN_T), else NULL
 };
 
 template <typename A, int EPL, int OP>
@@ -408,7 +490,7 @@ __device__ __forceinline__ void store_partial(void* partials, int64_t slot, int 
 #pragma unroll
   for (int e = 0; e < EPL; ++e) {
     p[e] = f.acc[e];
-    if (OP == RUA_LOGSUMEXP) p[RUA_WAVE * EPL + e] = f.aux[e];   // only logsumexp carries a second value
+    if (op_uses_aux(OP)) p[RUA_WAVE * EPL + e] = f.aux[e];   // logsumexp's sum / the tie count; nothing else has one
   }
 }
 
@@ -458,7 +540,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
   } else {
     fold_rows<T, EPL, OP, NT, COPY, CPW>(U, 0, U.len, data, H, f, CD, copy, lane);
     fold_wave<A, NE, OP>(f, lp_log2);
-    fold_store<T, EPL, OP, CPW>(U, f, out, H, include_self, empty_val);
+    fold_store<T, EPL, OP, CPW>(U, f, out, H, include_self, empty_val, (A*)W.ties);
   }
   fold_flags<A, NE, OP>(f, extreme, lane, U.len <= 0);
 }
@@ -468,7 +550,8 @@ template <typename T, int EPL, int OP, bool NT>
 __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_ranks_kernel(rua_layout L, const T* __restrict__ data,
                                                                     T* __restrict__ out, int64_t H, int lp_log2,
                                                                     int include_self, T empty_val,
-                                                                    unsigned long long* __restrict__ extreme) {
+                                                                    unsigned long long* __restrict__ extreme,
+                                                                    typename elem<T>::acc* __restrict__ ties) {
   using A = typename elem<T>::acc;
   const int lane = threadIdx.x;
   const Unit<T, EPL> U = make_unit<T, EPL, false, 1, true>(L, L, nullptr, blockIdx.x, 0, H, lp_log2, lane);
@@ -482,7 +565,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_ranks_kernel(rua_layout L
   fold_init<A, EPL, OP>(f);
   fold_rows<T, EPL, OP, NT, false, 1, true>(U, 0, t_hi, data, H, f, L, nullptr, lane);
   fold_wave<A, EPL, OP, true>(f, lp_log2);
-  fold_store<T, EPL, OP, 1, true>(U, f, out, H, include_self, empty_val);
+  fold_store<T, EPL, OP, 1, true>(U, f, out, H, include_self, empty_val, ties);
   fold_flags<A, EPL, OP>(f, extreme, lane, U.live && U.len <= 0);
 }
 
@@ -527,7 +610,7 @@ constexpr int64_t COMBINE_GRID = 512;   // 2 workgroups per CU
 template <typename A, int NE, int OP>
 __device__ __forceinline__ void combine_range(Fold<A, NE>& f, const A* __restrict__ P, int64_t pbase, int64_t p_lo,
                                               int64_t p_hi, int lane) {
-  constexpr bool LSE = OP == RUA_LOGSUMEXP;
+  constexpr bool LSE = op_uses_aux(OP);          // a second value travels with the partial
   constexpr int PF = LSE ? 4 : 8;               // partials in flight: the walk over one unit's parts is latency-bound
   for (int64_t p = p_lo; p < p_hi; p += PF) {
     A a2[PF][NE], x2[LSE ? PF : 1][NE];
@@ -572,7 +655,7 @@ __global__ __launch_bounds__(RUA_WAVE * (COMBINE_WAVES_MAX / CPW)) void seg_redu
     combine_range<A, NE, OP>(f, P, pbase, 0, nparts, lane);
     const Unit<T, EPL> U = copy_mode ? make_unit<T, EPL, true, CPW>(L, CD, perm, e[0], e[1], H, lp_log2, lane)
                                      : make_unit<T, EPL, false, CPW>(L, CD, perm, e[0], e[1], H, lp_log2, lane);
-    fold_store<T, EPL, OP, CPW>(U, f, out, H, include_self, empty_val);
+    fold_store<T, EPL, OP, CPW>(U, f, out, H, include_self, empty_val, (A*)W.ties);
   }
 
   // pass B: the whole workgroup per unit with many parts (block-uniform loop and condition)
@@ -599,7 +682,7 @@ __global__ __launch_bounds__(RUA_WAVE * (COMBINE_WAVES_MAX / CPW)) void seg_redu
       }
       const Unit<T, EPL> U = copy_mode ? make_unit<T, EPL, true, CPW>(L, CD, perm, e[0], e[1], H, lp_log2, lane)
                                        : make_unit<T, EPL, false, CPW>(L, CD, perm, e[0], e[1], H, lp_log2, lane);
-      fold_store<T, EPL, OP, CPW>(U, f, out, H, include_self, empty_val);
+      fold_store<T, EPL, OP, CPW>(U, f, out, H, include_self, empty_val, (A*)W.ties);
     }
   }
 }
@@ -788,11 +871,12 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_tail_kernel(rua_layout 
 }
 
 // backward over a PackedSequence with narrow rows: adjacent ranks side by side (see seg_reduce_ranks_kernel)
-template <typename T, int EPL, int OP>
+template <typename T, int EPL, int OP, int TIES>
 __global__ __launch_bounds__(RUA_WAVE) void seg_backward_ranks_kernel(rua_layout L, const T* __restrict__ data,
                                                                       const T* __restrict__ out,
                                                                       const T* __restrict__ gout,
-                                                                      T* __restrict__ gin, int64_t H, int lp_log2) {
+                                                                      T* __restrict__ gin, int64_t H, int lp_log2,
+                                                                      typename elem<T>::acc* __restrict__ ties) {
   const int lane = threadIdx.x;
   const Unit<T, EPL> U = make_unit<T, EPL, false, 1, true>(L, L, nullptr, blockIdx.x, 0, H, lp_log2, lane);
   int64_t t_hi = U.len;                       // the wave walks to its longest sequence
@@ -802,7 +886,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_ranks_kernel(rua_layout
     t_hi = o > t_hi ? o : t_hi;
   }
   if (t_hi <= 0) return;
-  backward_unit<T, EPL, OP, 0, true>(U, 0, t_hi, data, out, gout, gin, H, 0, lane);
+  backward_unit<T, EPL, OP, TIES, true>(U, 0, t_hi, data, out, gout, gin, H, 0, lane, ties);
 }
 
 // the rare second walk (see fold_flags): global extreme of every row the layout enumerates, into the hashed slots
@@ -896,7 +980,7 @@ template <typename T, int EPL, bool NT, bool COPY, int CPW>
 static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout& L, const int64_t* perm,
                          const void* data, void* out, int64_t H, int lp_log2, int64_t n_chunks, int include_self,
                          uint64_t empty_bits, void* extreme, const rua_layout& CD, void* copy, int64_t split,
-                         void* ws) {
+                         void* ws, void* ties) {
   using A = typename elem<T>::acc;
   T ev;
   __builtin_memcpy(&ev, &empty_bits, sizeof(T));
@@ -910,6 +994,7 @@ static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout&
     hipError_t e = hipMemsetAsync(W.ctr, 0, 4 * sizeof(unsigned long long), s);
     if (e != hipSuccess) return (int)e;
   }
+  W.ties = ties;
   unsigned long long* ext = (unsigned long long*)extreme;
 #define RUA_LAUNCH(OP)                                                                                              \
   if (do_split) {                                                                                                   \
@@ -928,8 +1013,12 @@ static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout&
   switch (op) {
     case RUA_SUM: RUA_LAUNCH(RUA_SUM); break;
     case RUA_MEAN: RUA_LAUNCH(RUA_MEAN); break;
-    case RUA_MAX: RUA_LAUNCH(RUA_MAX); break;
-    case RUA_MIN: RUA_LAUNCH(RUA_MIN); break;
+    case RUA_MAX:
+      if constexpr (!COPY) { if (ties) { RUA_LAUNCH(RUA_MAX_T); break; } }   // also count the ties (for the backward)
+      RUA_LAUNCH(RUA_MAX); break;
+    case RUA_MIN:
+      if constexpr (!COPY) { if (ties) { RUA_LAUNCH(RUA_MIN_T); break; } }
+      RUA_LAUNCH(RUA_MIN); break;
     case RUA_PROD: RUA_LAUNCH(RUA_PROD); break;
     case RUA_LOGSUMEXP: RUA_LAUNCH(RUA_LOGSUMEXP); break;
     default: return RUA_EINVAL;
@@ -941,9 +1030,10 @@ static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout&
 template <typename T>
 static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,
                                 void* out, int64_t H, int include_self, uint64_t empty_bits, void* extreme,
-                                int64_t split, void* ws, const rua_layout* CD = nullptr, void* copy = nullptr) {
+                                int64_t split, void* ws, const rua_layout* CD = nullptr, void* copy = nullptr,
+                                void* ties = nullptr) {
   constexpr int FULL = 16 / sizeof(T);
-  const bool vec_ok = (H % FULL == 0) && (((uintptr_t)data | (uintptr_t)out | (uintptr_t)copy) % 16 == 0);
+  const bool vec_ok = (H % FULL == 0) && (((uintptr_t)data | (uintptr_t)out | (uintptr_t)copy | (uintptr_t)ties) % 16 == 0);
   const int epl = vec_ok ? FULL : 1;
   const int64_t lpr = (H + epl - 1) / epl;  // lanes per row
   int lp_log2 = 0;
@@ -974,13 +1064,13 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
     unsigned long long* ext = (unsigned long long*)extreme;
 #define RUA_RANKS(EPLV, NTV, OPV)                                                                                  \
   hipLaunchKernelGGL((seg_reduce_ranks_kernel<T, EPLV, OPV, NTV>), gg, bb, 0, s, L, (const T*)data, (T*)out, H,    \
-                     lp_log2, include_self, ev, ext)
+                     lp_log2, include_self, ev, ext, (typename elem<T>::acc*)ties)
 #define RUA_RANKS_OP(EPLV, NTV)                                  \
   switch (op) {                                                  \
     case RUA_SUM: RUA_RANKS(EPLV, NTV, RUA_SUM); break;          \
     case RUA_MEAN: RUA_RANKS(EPLV, NTV, RUA_MEAN); break;        \
-    case RUA_MAX: RUA_RANKS(EPLV, NTV, RUA_MAX); break;          \
-    case RUA_MIN: RUA_RANKS(EPLV, NTV, RUA_MIN); break;          \
+    case RUA_MAX: if (ties) RUA_RANKS(EPLV, NTV, RUA_MAX_T); else RUA_RANKS(EPLV, NTV, RUA_MAX); break; \
+    case RUA_MIN: if (ties) RUA_RANKS(EPLV, NTV, RUA_MIN_T); else RUA_RANKS(EPLV, NTV, RUA_MIN); break; \
     case RUA_PROD: RUA_RANKS(EPLV, NTV, RUA_PROD); break;        \
     case RUA_LOGSUMEXP: RUA_RANKS(EPLV, NTV, RUA_LOGSUMEXP); break; \
     default: return RUA_EINVAL;                                  \
@@ -993,7 +1083,7 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
   }
 #define RUA_GO(EPLV, NTV, COPYV, CPWV)                                                                             \
   return launch_reduce<T, EPLV, NTV, COPYV, CPWV>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self, \
-                                                  empty_bits, extreme, cd, copy, split, ws)
+                                                  empty_bits, extreme, cd, copy, split, ws, ties)
   if (copy) {
     if (wide) { if (nt) RUA_GO(FULL, true, true, 4); else RUA_GO(FULL, false, true, 4); }
     if (nt) RUA_GO(FULL, true, true, 1); else RUA_GO(FULL, false, true, 1);
@@ -1012,9 +1102,10 @@ constexpr int64_t EXTREME_GRID = 8192;
 template <typename T>
 static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,
                            void* out, int64_t H, int include_self, uint64_t empty_bits, void* extreme,
-                           int64_t split, void* ws, const rua_layout* CD = nullptr, void* copy = nullptr) {
+                           int64_t split, void* ws, const rua_layout* CD = nullptr, void* copy = nullptr,
+                           void* ties = nullptr) {
   const int r = dispatch_reduce_main<T>(op, s, L, perm, data, out, H, include_self, empty_bits, extreme, split, ws, CD,
-                                        copy);
+                                        copy, ties);
   if (r != 0 || !extreme || !(op == RUA_MAX || op == RUA_MIN || op == RUA_LOGSUMEXP)) return r;
   if (L.kind == RUA_PACK && !copy) return r;   // every sequence of a PackedSequence holds a token: nothing can be empty
   constexpr int FULL = 16 / sizeof(T);
@@ -1039,11 +1130,13 @@ static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int
 template <typename T, int EPL>
 static int launch_backward(int op, unsigned grid, hipStream_t s, const rua_layout& L, const int64_t* perm,
                            const void* data, const void* out, const void* gout, void* gin, int64_t H, int lp_log2,
-                           int64_t n_chunks, int extra_count, int64_t split, void* ws, void* ties) {
+                           int64_t n_chunks, int extra_count, int64_t split, void* ws, void* ties,
+                           bool ties_final) {
   using A = typename elem<T>::acc;
   const dim3 g(grid), b(RUA_WAVE);
   const bool extreme_op = op == RUA_MAX || op == RUA_MIN;
   const bool phased = extreme_op && ties != nullptr;        // count phase, then apply phase
+  // ties_final: the forward already counted them (RUA_MAX_T / RUA_MIN_T) -> the apply phase alone, ONE walk
   const int64_t max_u = split_max_extra(L.n_rows, split) * n_chunks;
   // PROD keeps whole sequences: its zero-factor special case needs the zero count and the product of the other
   // factors of the whole sequence, and a product combined by atomics would not be reproducible
@@ -1069,7 +1162,8 @@ static int launch_backward(int op, unsigned grid, hipStream_t s, const rua_layou
     }                                                                                                              \
   }
 #define RUA_EXTREME(OP)                                       \
-  if (phased) { RUA_PHASE(OP, 1) RUA_PHASE(OP, 2) } else RUA_PHASE(OP, 0)
+  if (phased && ties_final) RUA_PHASE(OP, 2)                  \
+  else if (phased) { RUA_PHASE(OP, 1) RUA_PHASE(OP, 2) } else RUA_PHASE(OP, 0)
   switch (op) {
     case RUA_SUM: RUA_PHASE(RUA_SUM, 0); break;
     case RUA_MEAN: RUA_PHASE(RUA_MEAN, 0); break;
@@ -1087,7 +1181,7 @@ static int launch_backward(int op, unsigned grid, hipStream_t s, const rua_layou
 template <typename T>
 static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,
                              const void* out, const void* gout, void* gin, int64_t H, int extra_count,
-                             int64_t split, void* ws, void* ties) {
+                             int64_t split, void* ws, void* ties, bool ties_final) {
   constexpr int FULL = 16 / sizeof(T);
   const uintptr_t ptrs = (uintptr_t)data | (uintptr_t)out | (uintptr_t)gout | (uintptr_t)gin | (uintptr_t)ties;
   const bool vec_ok = (H % FULL == 0) && (ptrs % 16 == 0);
@@ -1098,24 +1192,24 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
   const int64_t n_chunks = (lpr + RUA_WAVE - 1) / RUA_WAVE;
   const int64_t blocks = L.B * n_chunks;
   if (blocks > 0x7fffffffLL) return RUA_ERANGE;
-  if (L.kind == RUA_PACK && L.sorted && !perm && !ties && lp_log2 < 6 && !(split > 0 && ws) && !extra_count &&
-      (L.B >> (6 - lp_log2)) >= RANKS_MIN_WAVES) {
+  if (L.kind == RUA_PACK && L.sorted && !perm && (!ties || ties_final) && lp_log2 < 6 && !(split > 0 && ws) &&
+      !extra_count && (L.B >> (6 - lp_log2)) >= RANKS_MIN_WAVES) {
     // narrow rows of a PackedSequence: adjacent ranks share a wave instruction
     const int64_t rpw = RUA_WAVE >> lp_log2;
     const int64_t nblk = (L.B + rpw - 1) / rpw;
     if (nblk > 0x7fffffffLL) return RUA_ERANGE;
     const dim3 gg((unsigned)nblk), bb(RUA_WAVE);
-#define RUA_BRANKS(EPLV, OPV)                                                                                     \
-  hipLaunchKernelGGL((seg_backward_ranks_kernel<T, EPLV, OPV>), gg, bb, 0, s, L, (const T*)data, (const T*)out,   \
-                     (const T*)gout, (T*)gin, H, lp_log2)
+#define RUA_BRANKS(EPLV, OPV, TV)                                                                                   \
+  hipLaunchKernelGGL((seg_backward_ranks_kernel<T, EPLV, OPV, TV>), gg, bb, 0, s, L, (const T*)data,              \
+                     (const T*)out, (const T*)gout, (T*)gin, H, lp_log2, (typename elem<T>::acc*)ties)
 #define RUA_BRANKS_OP(EPLV)                                     \
   switch (op) {                                                 \
-    case RUA_SUM: RUA_BRANKS(EPLV, RUA_SUM); break;             \
-    case RUA_MEAN: RUA_BRANKS(EPLV, RUA_MEAN); break;           \
-    case RUA_MAX: RUA_BRANKS(EPLV, RUA_MAX); break;             \
-    case RUA_MIN: RUA_BRANKS(EPLV, RUA_MIN); break;             \
-    case RUA_PROD: RUA_BRANKS(EPLV, RUA_PROD); break;           \
-    case RUA_LOGSUMEXP: RUA_BRANKS(EPLV, RUA_LOGSUMEXP); break; \
+    case RUA_SUM: RUA_BRANKS(EPLV, RUA_SUM, 0); break;          \
+    case RUA_MEAN: RUA_BRANKS(EPLV, RUA_MEAN, 0); break;        \
+    case RUA_MAX: if (ties) RUA_BRANKS(EPLV, RUA_MAX, 2); else RUA_BRANKS(EPLV, RUA_MAX, 0); break; \
+    case RUA_MIN: if (ties) RUA_BRANKS(EPLV, RUA_MIN, 2); else RUA_BRANKS(EPLV, RUA_MIN, 0); break; \
+    case RUA_PROD: RUA_BRANKS(EPLV, RUA_PROD, 0); break;        \
+    case RUA_LOGSUMEXP: RUA_BRANKS(EPLV, RUA_LOGSUMEXP, 0); break; \
     default: return RUA_EINVAL;                                 \
   }
     if (vec_ok) { RUA_BRANKS_OP(FULL) } else { RUA_BRANKS_OP(1) }
@@ -1125,9 +1219,9 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
   }
   if (vec_ok)
     return launch_backward<T, FULL>(op, (unsigned)blocks, s, L, perm, data, out, gout, gin, H, lp_log2, n_chunks,
-                                    extra_count, split, ws, ties);
+                                    extra_count, split, ws, ties, ties_final);
   return launch_backward<T, 1>(op, (unsigned)blocks, s, L, perm, data, out, gout, gin, H, lp_log2, n_chunks, extra_count,
-                               split, ws, ties);
+                               split, ws, ties, ties_final);
 }
 
 // ---- per-dtype entry points: each element type is compiled in its own translation unit
@@ -1135,10 +1229,10 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
 #define RUA_DECLARE_REDUCE_DTYPE(NAME)                                                                              \
   int reduce_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data, void* out,  \
                     int64_t H, int include_self, uint64_t empty_bits, void* extreme, int64_t split, void* ws,     \
-                    const rua_layout* CD, void* copy);                                                             \
+                    const rua_layout* CD, void* copy, void* ties);                                                 \
   int backward_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,           \
                       const void* out, const void* gout, void* gin, int64_t H, int extra_count, int64_t split,    \
-                      void* ws, void* ties);                                                                       \
+                      void* ws, void* ties, bool ties_final);                                                      \
   int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, const void* ext);
 RUA_DECLARE_REDUCE_DTYPE(f32)
 RUA_DECLARE_REDUCE_DTYPE(bf16)
@@ -1149,14 +1243,14 @@ RUA_DECLARE_REDUCE_DTYPE(f64)
   namespace rua {                                                                                                   \
   int reduce_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data, void* out,  \
                     int64_t H, int include_self, uint64_t empty_bits, void* extreme, int64_t split, void* ws,     \
-                    const rua_layout* CD, void* copy) {                                                            \
+                    const rua_layout* CD, void* copy, void* ties) {                                                \
     return dispatch_reduce<T>(op, s, L, perm, data, out, H, include_self, empty_bits, extreme, split, ws, CD,      \
-                              copy);                                                                               \
+                              copy, ties);                                                                         \
   }                                                                                                                 \
   int backward_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,           \
                       const void* out, const void* gout, void* gin, int64_t H, int extra_count, int64_t split,    \
-                      void* ws, void* ties) {                                                                      \
-    return dispatch_backward<T>(op, s, L, perm, data, out, gout, gin, H, extra_count, split, ws, ties);            \
+                      void* ws, void* ties, bool ties_final) {                                                     \
+    return dispatch_backward<T>(op, s, L, perm, data, out, gout, gin, H, extra_count, split, ws, ties, ties_final); \
   }                                                                                                                 \
   int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, const void* ext) { \
     hipLaunchKernelGGL(fill_empty_kernel<T>, dim3(grid_for(L.B)), dim3(RUA_BLOCK), 0, s, L, (T*)out, H, want_max,  \
