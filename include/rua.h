@@ -162,8 +162,9 @@ enum rua_op {
  * split_rows > 0 (with `ws` of rua_reduce_ws_bytes(lay->n_rows, H, dtype, split_rows) bytes) cuts sequences
  * longer than split_rows into parts handled by separate waves (published through a device-side work list,
  * fp32 partials folded in part order: deterministic); 0 = one wave streams each sequence.
- * ties_out (MAX/MIN with include_self == 0 and no perm; may be NULL): [B, H] f32 (f64 for RUA_F64) that receives, per
- * output element, how many elements of the sequence equal it — what the backward needs, for free in the pass that
+ * ties_out (MAX/MIN; may be NULL): [B, H] f32 (f64 for RUA_F64) that receives, per output element, how many elements
+ * of the sequence equal it (with include_self == 1 the old row is folded into the result but not counted; rows that
+ * include_self == 2 leaves untouched are not written: pre-zero the buffer) — what the backward needs, for free in the pass that
  * reads the payload anyway (rua_segment_reduce_backward with include_self = RUA_TIES_FINAL then takes ONE walk). */
 int64_t rua_reduce_ws_bytes(int64_t n_rows, int64_t H, int32_t dtype, int64_t split_rows);
 int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* data, void* out,

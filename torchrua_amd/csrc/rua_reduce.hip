@@ -70,7 +70,7 @@ int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* d
   if (perm && lay->kind != RUA_CAT) return RUA_EINVAL;
   if (lay->B == 0 || H == 0) return 0;
   if (!out || (lay->n_rows > 0 && !data)) return RUA_EINVAL;
-  if (ties && (include_self != 0 || perm || (op != RUA_MAX && op != RUA_MIN))) return RUA_EINVAL;
+  if (ties && op != RUA_MAX && op != RUA_MIN) return RUA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (extreme && (op == RUA_MAX || op == RUA_MIN || op == RUA_LOGSUMEXP)) {
     hipLaunchKernelGGL(extreme_init_entry_kernel, dim3(1), dim3(128), 0, s, (unsigned long long*)extreme,

@@ -440,6 +440,7 @@ __device__ __forceinline__ void fold_store(const Unit<T, EPL>& U, Fold<typename 
         else if (OP == RUA_PROD) r *= x;
         else if (OP == RUA_MAX) r = nmax(r, x);
         else if (OP == RUA_MIN) r = nmin(r, x);
+        else if (op_counts(OP)) tie_update<A, OP == RUA_MAX_T>(r, f.aux[ce], x, (A)0);   // the old row's own tie: the caller's
       }
       if (OP == RUA_MEAN && cnt > 0) r = r / (A)cnt;
       o[e] = (cnt == 0) ? empty_val : elem<T>::down(r);

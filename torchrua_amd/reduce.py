@@ -136,9 +136,14 @@ class _Scatter(torch.autograd.Function):
             mode = 1 if include_self else 2
         if op == K.LOGSUMEXP and not include_self:
             out, mode = torch.empty_like(tensor), 0            # untouched rows -> log(0) = -inf (reduce.py:26-31)
+        ties = None
+        if op in (K.MAX, K.MIN) and (ctx.needs_input_grad[0] or ctx.needs_input_grad[2]):
+            # source rows equal to the result, counted by the forward (the backward is then one walk)
+            ties = torch.zeros(out.shape, dtype=torch.float64 if source.dtype == torch.float64 else torch.float32,
+                               device=source.device)
         O.launch_reduce(lay, source.detach(), op, out=out, include_self=mode, perm=perm, hidden=hidden,
-                        reference_initial=False, name='scatter')
-        ctx.op, ctx.include_self, ctx.lay, ctx.perm = op, include_self, lay, perm
+                        reference_initial=False, name='scatter', ties_out=ties)
+        ctx.op, ctx.include_self, ctx.lay, ctx.perm, ctx.ties = op, include_self, lay, perm, ties
         ctx.save_for_backward(tensor, index, source, out, counts)
         return out
 
@@ -159,20 +164,23 @@ class _Scatter(torch.autograd.Function):
         H = 1
         for d in out.shape[1:]:
             H *= d
-        ties = None
+        ties, final = None, 0
         if op in (K.MAX, K.MIN):
             # ties the source rows do not see: the old destination row where it equals the result.  torch's
             # index_reduce backward counts it even when include_self=False (FunctionsManual index_reduce_backward:
             # N = self_is_result.index_add(source_is_result)) and the reference inherits that (reduce.py:6-11),
             # so it is reproduced here.
             acc = torch.float64 if source.dtype == torch.float64 else torch.float32
-            ties = (tensor == out).to(acc)
-            hit_t = ties.clone() if inc else None
+            hit_t = (tensor == out).to(acc)
+            if ctx.ties is not None:          # the forward counted the source rows: totals are complete, one walk
+                ties, final = hit_t + ctx.ties, K.TIES_FINAL
+            else:
+                ties = hit_t.clone()
         g_src = torch.empty_like(source)       # every source row belongs to exactly one bucket
         split, ws = O.split_workspace(ctx.lay, H, source.dtype, dev)
         K.check(K.load().rua_segment_reduce_backward(ctx.lay.ref(), K.ptr(ctx.perm), K.ptr(source.contiguous()),
                                                      K.ptr(out), K.ptr(grad), K.ptr(g_src), H, K.DTYPES[source.dtype],
-                                                     op, 1 if inc else 0, split, K.ptr(ws), K.ptr(ties),
+                                                     op, final if final else (1 if inc else 0), split, K.ptr(ws), K.ptr(ties),
                                                      K.stream_ptr(dev)), 'rua_segment_reduce_backward')
         if op == K.SUM:
             g_ten = grad if inc else None
