@@ -99,7 +99,9 @@ while time.time() < t_end:
                     for inc in (False, True):
                         ref = getattr(orc, f'scatter_{name}')(ten.numpy(), index[perm].numpy(), f[perm.numpy()], include_self=inc)
                         got = getattr(ta, f'scatter_{name}')(ten.to(DEV), index[perm].to(DEV), data[perm].to(DEV), include_self=inc)
-                        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * max(1.0, scale), err_msg=f'scatter {name}')
+                        # fp32 sums of up to `max len` terms in different orders: the error scales with the length
+                        sscale = float(np.abs(f).max()) * (int(lens.max()) if name == 'sum' else 1)
+                        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=2e-5 * sscale + 1e-4, err_msg=f'scatter {name}')
                 x = data.clone().to(DEV).requires_grad_(True)
                 c = ta.C(x, lens.to(DEV))
                 out = ta.reduce_logsumexp(c.pack().roll(1).left().pack())
