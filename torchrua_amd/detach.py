@@ -1,5 +1,8 @@
-"""split / tolist — mirror of torchrua.detach (reference detach.py:9-51): host-side list
-materialisation (inherently synchronous)."""
+"""split / tolist (the API of torchrua.detach, reference detach.py:9-51): hand the sequences back as a Python
+list.  Inherently host-side and synchronous; the only device work is the P -> C move.
+
+C/P: one torch.split by the (host-mirrored, if available) lengths.  L/R: a sequence is a slice of its own padded
+row, so the list is B views `data[b, lo:hi]` — no flattening of the padded storage, no sections for the padding."""
 from typing import List
 
 import torch
@@ -7,35 +10,30 @@ import torch
 from torchrua_amd import _meta as M
 from torchrua_amd.layout import C, L, P, R, T, Z
 
-
 __all__ = []  # methods are attached to the layout classes
 
 
-def _cat_pack_split(self) -> List[T]:
-    """detach.py:9-13."""
-    data, token_sizes = self.cat()
-    return torch.split(data, M.host_lens(token_sizes).tolist(), dim=0)
+def _split_dense(self) -> List[T]:
+    dense = self.cat()
+    return list(torch.split(dense.data, M.host_lens(dense.token_sizes).tolist()))
 
 
-def _padded_split(right: bool):
-    def split(self) -> List[T]:
-        """detach.py:20-27 / 33-40."""
-        t = self.size()[1]
-        lens = M.host_lens(self.token_sizes)
-        pair = [t - lens, lens] if right else [lens, t - lens]
-        sections = torch.stack(pair, dim=-1).view(-1).tolist()
-        return torch.split(self.data.flatten(start_dim=0, end_dim=1), sections, dim=0)[(1 if right else 0)::2]
-    return split
+def _split_left(self: L) -> List[T]:
+    return [self.data[b, :n] for b, n in enumerate(M.host_lens(self.token_sizes).tolist())]
+
+
+def _split_right(self: R) -> List[T]:
+    n_steps = self.size()[1]                     # right alignment is against the longest sequence
+    return [self.data[b, n_steps - n:n_steps] for b, n in enumerate(M.host_lens(self.token_sizes).tolist())]
 
 
 def _tolist(self: Z):
-    """detach.py:44-45 (the reference's P.tolist is broken: PackedSequence has no detach(); ours works)."""
-    return [tensor.detach().cpu().tolist() for tensor in self.split()]
+    """(the reference's P.tolist fails — PackedSequence has no detach(); this one works for all four)"""
+    return [piece.detach().cpu().tolist() for piece in self.split()]
 
 
-C.split = _cat_pack_split
-P.split = _cat_pack_split
-L.split = _padded_split(False)
-R.split = _padded_split(True)
+C.split = P.split = _split_dense
+L.split = _split_left
+R.split = _split_right
 for _cls in (C, L, P, R):
     _cls.tolist = _tolist

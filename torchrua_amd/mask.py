@@ -1,31 +1,35 @@
-"""mask / bmask / fmask — mirror of torchrua.mask (reference mask.py:6-38): one kernel writes the whole
-[b, t] grid (`t < len[b] ? one : zero`) instead of new_full + an N-element index_put."""
+"""mask / bmask / fmask (the API of torchrua.mask, reference mask.py:6-38).  The reference fills a [b, t] grid
+and scatters `one` through an N-element index; here ONE kernel writes every cell (`t < len[b] ? one : zero`,
+rua_mask) — an attention-mask producer usually sits right behind a pad, on grids of B x T cells."""
 import torch
 
 from torchrua_amd.core import _mask_grid
 from torchrua_amd.layout import C, L, P, R, T, Z, lens_of
 
-
 __all__ = []  # methods are attached to the layout classes
 
 
 def _mask(self: Z, zero, one, dtype: torch.dtype = None) -> T:
-    """mask.py:6-14."""
-    b, t = self.size()[:2]
-    return _mask_grid(lens_of(self), b, t, zero, one, self.data.dtype if dtype is None else dtype)
+    n_seq, n_steps = self.size()[:2]
+    return _mask_grid(lens_of(self), n_seq, n_steps, zero, one, self.data.dtype if dtype is None else dtype)
 
 
-def _bmask(self: Z) -> T:
-    """mask.py:22-23."""
-    return self.mask(zero=False, one=True, dtype=torch.bool)
+# the two fixed flavours: which (zero, one, dtype) a container asks `mask` for
+_FLAVOURS = {
+    'bmask': lambda z: (False, True, torch.bool),                                    # True on tokens
+    'fmask': lambda z: (torch.finfo(z.data.dtype).min, 0, z.data.dtype),             # additive: 0 on tokens, -max off
+}
 
 
-def _fmask(self: Z) -> T:
-    """mask.py:31-32."""
-    return self.mask(zero=torch.finfo(self.data.dtype).min, one=0, dtype=self.data.dtype)
+def _flavoured(name: str):
+    def method(self: Z) -> T:
+        zero, one, dtype = _FLAVOURS[name](self)
+        return self.mask(zero=zero, one=one, dtype=dtype)
+    method.__name__ = name
+    return method
 
 
 for _cls in (C, L, P, R):
     _cls.mask = _mask
-    _cls.bmask = _bmask
-    _cls.fmask = _fmask
+    for _name in _FLAVOURS:
+        setattr(_cls, _name, _flavoured(_name))
