@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RUA_ABI_VERSION 1
+#define RUA_ABI_VERSION 2
 
 /* argument errors (negative so they cannot collide with hipError_t) */
 #define RUA_EINVAL   (-1)  /* bad enum / null pointer / negative size      */
@@ -195,10 +195,28 @@ int rua_pack_reduce(const rua_layout* src, const rua_layout* pack, const void* d
  * equals `out`).  The kernel adds every sequence's own ties (integer-valued float atomics: exact), then divides
  * the gradient by the total — which lets long sequences be split, and leaves the totals for the caller.
  * With ties == NULL each sequence is counted and applied by one wave (no splitting for MAX/MIN).
- * include_self == RUA_TIES_FINAL: `ties` already holds the complete counts (the forward's ties_out): no counting walk. */
+ * include_self == RUA_TIES_FINAL: `ties` already holds the complete counts (the forward's ties_out): no counting walk.
+ * self_in (perm != NULL only; may be NULL): the old destination rows [B, H] of a scatter_* — the `tensor` argument of
+ * reduce.py:6-31.  MAX/MIN with RUA_TIES_FINAL: the kernel itself adds the tie of the old row where it equals `out`
+ * (torch's index_reduce backward counts it with and without include_self), so `ties` is the forward's ties_out
+ * unchanged.  PROD with include_self == 1: the old row is one more factor of every source row's gradient
+ * (g * tensor * prod(other sources), zero factors handled like torch). */
 int rua_segment_reduce_backward(const rua_layout* lay, const int64_t* perm, const void* data, const void* out,
                                 const void* grad_out, void* grad_in, int64_t H, int32_t dtype, int32_t op,
-                                int32_t include_self, int64_t split_rows, void* ws, void* ties, void* stream);
+                                int32_t include_self, int64_t split_rows, void* ws, void* ties,
+                                const void* self_in, void* stream);
+
+/* Gradient of scatter_* w.r.t. the destination `tensor` (reduce.py:6-31; torch's index_add / index_reduce backward),
+ * one elementwise launch over [S, H]:
+ *   include_self != 0:  SUM g | MEAN g/(counts+1) | MAX/MIN (tensor == out) ? g/(aux+1) : 0 | PROD g*aux |
+ *                       LOGSUMEXP g*exp(tensor - out)
+ *   include_self == 0:  g in rows no index names (counts == 0: they keep `tensor`), 0 elsewhere.
+ * counts[S]: bucket sizes (rua_index_buckets).  aux [S, H]: MAX/MIN — the source rows' tie counts (f32; f64 for
+ * RUA_F64; rua_segment_reduce's ties_out; NULL = none); PROD — the product of each bucket's source rows in the
+ * payload dtype (rua_segment_reduce into ones with include_self = 2).  self_in/out may be NULL where unused. */
+int rua_scatter_self_grad(const int64_t* counts, int64_t S, int64_t H, const void* self_in, const void* out,
+                          const void* grad_out, const void* aux, void* grad_self, int32_t dtype, int32_t op,
+                          int32_t include_self, void* stream);
 
 /* After rua_segment_reduce / rua_pack_reduce with `extreme` (MAX/MIN/LOGSUMEXP): write the global extreme into the
  * rows of empty sequences, or NaN into every row when the NaN flag is up (the reference's initial=NaN behaviour). */

@@ -67,16 +67,44 @@ def test_z_keys_and_tensor_patch():
         assert torch.equal(buf, p.data)
         assert plain[2].item() == 2                 # ordinary indexing untouched
     finally:
-        from torchrua_amd import core
-        torch.Tensor.__getitem__ = core._tensor_getitem
-        torch.Tensor.__setitem__ = core._tensor_setitem
+        ta.unpatch_tensor_indexing()
+    with pytest.raises((TypeError, IndexError, RuntimeError)):
+        plain[idx]
 
 
 def test_alias_module():
+    """`install_as_torchrua()` = what `import torchrua` gives with the reference: the names AND the import-time
+    patch of Tensor.__getitem__/__setitem__ (core/get.py:11-18, core/set.py:10-18)."""
     ta.install_as_torchrua()
-    import torchrua
-    assert torchrua is sys.modules['torchrua_amd'] and torchrua.C is ta.C
-    assert torchrua.segment_sum is ta.segment_sum
+    try:
+        import torchrua
+        assert torchrua is sys.modules['torchrua_amd'] and torchrua.C is ta.C
+        assert torchrua.segment_sum is ta.segment_sum
+        xs = _xs([3, 1, 4, 2])
+        c = torchrua.C.new(xs)
+        for z in (c, c.pack(), c.left(), c.right()):
+            i = z.idx()                                         # rows of z.raw() in z's own order
+            got = z.raw()[i]                                    # tensor[Z]: select/roll.py:21 spells roll this way
+            assert type(got) is type(i) and torch.equal(got.data, z.raw()[i.data])
+            if isinstance(z, (torchrua.C, torchrua.P)):
+                assert torch.equal(got.data, z.data)
+            buf = torch.zeros_like(z.raw())
+            buf[i] = got.data                                   # tensor[Z] = value (core/set.py:10-18)
+            ref = torch.zeros_like(z.raw())
+            ref.index_put_((i.data,), got.data)
+            assert torch.equal(buf, ref)
+        # the reference's own spelling of roll for a padded layout goes through tensor[Z]
+        l = c.left()
+        rolled = l.raw()[l.idx().cat().roll(1).left()]          # select/roll.py:19-20 via the patched Tensor
+        assert isinstance(rolled, torchrua.L) and torch.equal(rolled.data, l.roll(1).data)
+        # gradients flow through tensor[Z]
+        x = torch.randn(10, 5, device=DEV, requires_grad=True)
+        k = c.idx().roll(1)
+        x[k].data.sum().backward()
+        assert torch.equal(x.grad, torch.ones_like(x))
+        assert torch.arange(5, device=DEV)[2].item() == 2       # ordinary indexing untouched
+    finally:
+        ta.unpatch_tensor_indexing()
 
 
 def test_packed_sequences_built_by_torch():

@@ -1,0 +1,169 @@
+"""Regressions for defects found by review: zero-length sequences through pack() at row
+widths on both sides of the 128-byte kernel switch, scatter_* argument validation (what torch.index_add /
+index_reduce reject), the hot path under torch.inference_mode(), scatter_prod's gradient where `tensor` is 0,
+and the privacy of the host length mirror."""
+import numpy as np
+import pytest
+import torch
+
+import torchrua_amd as ta
+from gpu_util import DEV, assert_same_seq, host_sort
+from helpers import orc, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------ zero-length sequences in pack()
+@pytest.mark.parametrize('lens', [[0, 3, 0, 2], [2, 0, 0, 5, 1, 0], [0, 0, 4], [3, 0]], ids=str)
+@pytest.mark.parametrize('hidden,dtype', [((4,), torch.float32), ((16,), torch.float32), ((32,), torch.float32),
+                                          ((40,), torch.float32), ((256,), torch.bfloat16), ((3,), torch.uint8)],
+                         ids=['16B', '64B', '128B', '160B', '512B', '3B'])
+def test_pack_with_empty_sequences(lens, hidden, dtype):
+    """core/cast.py:41-49 handles empty sequences (they sort last and never show in batch_sizes): every valid
+    sequence must arrive, whatever the row width (the generic mover and the (rank x time) tile kernel)."""
+    g = torch.Generator().manual_seed(len(lens))
+    n = sum(lens)
+    data = (torch.randn((n,) + hidden, generator=g) * 4).to(dtype)
+    lt = torch.tensor(lens, dtype=torch.long)
+    srt = host_sort(lens)
+    oc = orc.C(to_np(data), lt.numpy())
+    op = orc.to_pack(oc, srt)
+    c = ta.C(data.to(DEV), lt.to(DEV))
+    for src, osrc in ((c, oc), (c.left(), orc.to_left(oc)), (c.right(), orc.to_right(oc))):
+        p = src.pack()
+        assert_same_seq(p, op, f'pack of {type(src).__name__}')
+        # and back again: the oracle's P -> C is not defined with empty sequences in the reference (IndexError,
+        # SURVEY §8a), here the round trip returns the original
+        back = p.cat()
+        assert torch.equal(back.data, c.data) and torch.equal(back.token_sizes.cpu(), lt)
+        assert torch.equal(p.left().data, c.left().data)
+        assert torch.equal(p.right().data, c.right().data)
+        assert torch.equal(p.roll(1).cat().data, c.roll(1).data)
+    if dtype in (torch.float32, torch.bfloat16):
+        p = c.pack()
+        f = data.float().numpy()
+        for name in ('sum', 'mean', 'prod'):
+            ref = getattr(orc, f'segment_{name}')(f, lt.numpy())
+            out = getattr(ta, f'reduce_{name}')(p).float().cpu().numpy()
+            np.testing.assert_allclose(out, ref, rtol=1e-2 if dtype == torch.bfloat16 else 1e-5, atol=1e-5)
+        # max over an empty sequence: the reference's `initial` = the global minimum (reduce.py:35)
+        ref = orc.segment_max(f, lt.numpy())
+        out = ta.reduce_max(p).float().cpu().numpy()
+        np.testing.assert_array_equal(out, ref)
+        assert torch.equal(ta.reduce_max(p), ta.reduce_max(c))
+        assert torch.equal(ta.reduce_logsumexp(p), ta.reduce_logsumexp(c))
+        pf, of = ta.pack_reduce(c, 'sum')
+        assert torch.equal(pf.data, p.data) and torch.equal(of, ta.reduce_sum(p))
+
+
+def test_pack_with_empty_sequences_metadata():
+    lens = [0, 3, 0, 2]
+    c = ta.C(torch.arange(5, dtype=torch.float32, device=DEV)[:, None].repeat(1, 64), torch.tensor(lens, device=DEV))
+    p = c.pack()
+    assert p.batch_sizes.tolist() == [2, 2, 1]
+    assert sorted(p.sorted_indices.tolist()) == [0, 1, 2, 3] and p.sorted_indices.tolist()[:2] == [1, 3]
+    assert p.size()[:2] == (2, 3)                         # the reference's P.size(): batch_sizes.max()
+    assert ta.get_mask(p).tolist() == [[0, 0, 0], [1, 1, 1], [0, 0, 0], [1, 1, 0]]
+    assert p.cat().token_sizes.tolist() == lens
+
+
+# ------------------------------------------------------------------ scatter_* validation
+def test_scatter_rejects_what_torch_rejects():
+    t = torch.zeros(4, 8, device=DEV)
+    idx = torch.tensor([0, 1, 1, 3], device=DEV)
+    src = torch.ones(4, 8, device=DEV)
+    ta.scatter_sum(t, idx, src)
+    with pytest.raises(ta.RuaError):
+        ta.scatter_sum(t.half(), idx, src)                          # dtype mismatch (would overflow the half buffer)
+    with pytest.raises(ta.RuaError):
+        ta.scatter_sum(t, idx, torch.ones(4, 9, device=DEV))        # row shape mismatch
+    with pytest.raises(ta.RuaError):
+        ta.scatter_sum(t, idx[:3], src)                             # index shorter than source
+    with pytest.raises(ta.RuaError):
+        ta.scatter_sum(t, torch.cat([idx, idx]), src)               # index longer than source
+    with pytest.raises(ta.RuaError):
+        ta.scatter_sum(t, idx.view(2, 2), src)                      # index not 1-D
+    with pytest.raises(ta.RuaError):
+        ta.scatter_max(t, idx.float(), src)                         # index not integral
+
+
+@pytest.mark.parametrize('name', ['sum', 'mean', 'max', 'min', 'prod', 'logsumexp'])
+@pytest.mark.parametrize('include_self', [False, True])
+def test_scatter_into_non_contiguous_tensor(name, include_self):
+    """A dense but transposed `tensor`: the result is row-major data of the same values torch computes."""
+    g = torch.Generator().manual_seed(3)
+    t = torch.randn(6, 5, generator=g).t().to(DEV)            # [5, 6] view with strides (1, 5)
+    assert not t.is_contiguous()
+    idx = torch.tensor([4, 0, 0, 2, 4, 4, 1], device=DEV)
+    src = torch.randn(7, 6, generator=g).to(DEV)
+    out = getattr(ta, f'scatter_{name}')(t, idx, src, include_self=include_self)
+    ref = getattr(orc, f'scatter_{name}')(t.cpu().contiguous().numpy(), idx.cpu().numpy(), src.cpu().numpy(), include_self)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
+    assert out.is_contiguous()
+
+
+def test_scatter_int32_index():
+    t = torch.zeros(3, 4, device=DEV)
+    src = torch.arange(20, dtype=torch.float32, device=DEV).view(5, 4)
+    idx = torch.tensor([2, 0, 2, 1, 0], device=DEV)
+    assert torch.equal(ta.scatter_sum(t, idx.int(), src), ta.scatter_sum(t, idx, src))
+
+
+# ------------------------------------------------------------------ inference mode
+def test_hot_path_under_inference_mode():
+    lens = [5, 2, 9, 1, 4]
+    with torch.inference_mode():
+        xs = [torch.randn(n, 32, device=DEV) for n in lens]
+        c = ta.C.new(xs)
+        p = c.pack()
+        assert p.data.shape == (sum(lens), 32) and p.batch_sizes.tolist()[0] == 5
+        assert c.size()[:2] == (5, 9)
+        l = c.left()
+        assert torch.equal(l.cat().data, c.data)
+        s = ta.reduce_sum(p)
+        ref = torch.stack([x.sum(0) for x in xs])
+        torch.testing.assert_close(s, ref, rtol=1e-5, atol=1e-5)
+        c2 = ta.with_host_sizes(c.data, torch.tensor(lens))
+        assert torch.equal(c2.pack().data, p.data)
+        c3 = ta.C(c.data, torch.tensor(lens, device=DEV))            # device-only lengths: D2H + memo
+        assert torch.equal(c3.pack().data, p.data) and torch.equal(c3.roll(2).data, c.roll(2).data)
+        assert torch.equal(ta.segment_max(c.data, c.token_sizes), torch.stack([x.max(0).values for x in xs]))
+
+
+# ------------------------------------------------------------------ scatter_prod gradient where tensor == 0
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_scatter_prod_include_self_gradient_with_zeros_in_tensor(dtype):
+    g = torch.Generator().manual_seed(11)
+    t = (torch.rand(5, 6, generator=g, dtype=dtype) + 0.5)
+    t[1, 2] = 0.0
+    t[3] = 0.0
+    t[4, 0] = 0.0                       # row 4 is named by no index: d out / d tensor = 1 there
+    idx = torch.tensor([0, 1, 1, 3, 3, 3, 0])
+    src = torch.rand(7, 6, generator=g, dtype=dtype) + 0.5
+    src[4, 1] = 0.0
+    w = torch.randn(5, 6, generator=g, dtype=dtype)
+
+    def run(fn, dev):
+        tt, ss = t.to(dev).detach().clone().requires_grad_(), src.to(dev).detach().clone().requires_grad_()
+        out = fn(tt, idx.to(dev), ss)
+        (out * w.to(dev)).sum().backward()
+        return out.detach().cpu(), tt.grad.cpu(), ss.grad.cpu()
+
+    ref = run(lambda a, i, s: torch.index_reduce(a, 0, i, s, 'prod', include_self=True), 'cpu')
+    got = run(lambda a, i, s: ta.scatter_prod(a, i, s, include_self=True), DEV)
+    for r, o, what in zip(ref, got, ('out', 'grad tensor', 'grad source')):
+        assert not torch.isnan(o).any(), what
+        torch.testing.assert_close(o, r, rtol=1e-5, atol=1e-6, msg=lambda m: f'{what}: {m}')
+
+
+# ------------------------------------------------------------------ the host mirror is private
+def test_with_host_sizes_keeps_its_own_copy():
+    lens = torch.tensor([3, 1, 4, 2])
+    data = torch.randn(10, 16, device=DEV)
+    c = ta.with_host_sizes(data, lens)
+    expect = ta.C(data, torch.tensor([3, 1, 4, 2], device=DEV)).pack()
+    lens[:] = torch.tensor([1, 1, 1, 1])            # a loader recycling its buffer
+    p = c.pack()
+    assert p.batch_sizes.tolist() == [4, 3, 2, 1]
+    assert torch.equal(p.data, expect.data) and torch.equal(p.sorted_indices, expect.sorted_indices)
+    assert c.size()[:2] == (4, 4)

@@ -9,7 +9,7 @@ librua_hip.so must have been built (`make -C torchrua_amd/csrc`).
 from torchrua_amd.layout import *  # noqa: F401,F403
 from torchrua_amd.utils import *  # noqa: F401,F403
 from torchrua_amd.core import *  # noqa: F401,F403
-from torchrua_amd.core import patch_tensor_indexing, with_host_sizes  # noqa: F401
+from torchrua_amd.core import patch_tensor_indexing, unpatch_tensor_indexing, with_host_sizes  # noqa: F401
 from torchrua_amd.select import *  # noqa: F401,F403
 from torchrua_amd.reduce import *  # noqa: F401,F403
 from torchrua_amd.segment import *  # noqa: F401,F403
@@ -28,6 +28,12 @@ __version__ = '0.1.0'
 
 
 def install_as_torchrua() -> None:
-    """Make `import torchrua` resolve to this package (drop-in under code written for the reference)."""
+    """Make `import torchrua` resolve to this package (drop-in under code written for the reference).
+
+    Like importing the reference, this also teaches `tensor[Z]` / `tensor[Z] = value` to take a container of row
+    indices (the reference patches Tensor.__getitem__/__setitem__ at import time: core/get.py:11-18,
+    core/set.py:10-18).  A plain `import torchrua_amd` leaves torch.Tensor untouched; call
+    `patch_tensor_indexing()` yourself to opt in without the alias."""
     import sys
     sys.modules.setdefault('torchrua', sys.modules[__name__])
+    patch_tensor_indexing()

@@ -13,6 +13,7 @@ import torch  # noqa: F401  (must be imported first: maps the HIP runtime our li
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RUA_LIB_PATH') or os.path.join(_HERE, 'librua_hip.so')   # env: developer A/B of builds
 
+ABI_VERSION = 2
 # enum rua_kind
 CAT, LEFT, PACK, RIGHT, LIST = 0, 1, 2, 3, 4
 # enum rua_tmap
@@ -60,7 +61,10 @@ SYMBOLS = {
     'rua_pack_reduce': (c_int, [POINTER(RuaLayout), POINTER(RuaLayout), c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                 c_int32, c_uint64, c_void_p, c_int64, c_void_p, c_void_p]),
     'rua_segment_reduce_backward': (c_int, [POINTER(RuaLayout), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                            c_int64, c_int32, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p]),
+                                            c_int64, c_int32, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p,
+                                            c_void_p]),
+    'rua_scatter_self_grad': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_int32, c_int32, c_int32, c_void_p]),
     'rua_fill_empty': (c_int, [POINTER(RuaLayout), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     'rua_bucket_ws_elems': (c_int64, [c_int64, c_int64]),
     'rua_index_buckets': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -85,8 +89,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the ABI and this table disagree
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.rua_abi_version() != 1:
-        raise RuaError(f'ABI mismatch: library reports {lib.rua_abi_version()}, binding expects 1')
+    if lib.rua_abi_version() != ABI_VERSION:
+        raise RuaError(f'ABI mismatch: library reports {lib.rua_abi_version()}, binding expects {ABI_VERSION}')
     _lib = lib
     return lib
 

@@ -35,12 +35,18 @@ class host_serial:
 
 
 # ------------------------------------------------------------------ per-tensor memo
+def _version(t: Tensor) -> int:
+    """The tensor's version counter; inference tensors keep none (and cannot be written in place outside
+    inference mode), so they memoise under a constant."""
+    return 0 if t.is_inference() else t._version
+
+
 def _memo_get(t: Tensor, key: str):
     memo = t.__dict__.get('_rua_memo')
     if memo is None:
         return None
     hit = memo.get(key)
-    if hit is None or hit[0] != t._version:
+    if hit is None or hit[0] != _version(t):
         return None
     return hit[1]
 
@@ -50,7 +56,7 @@ def _memo_put(t: Tensor, key: str, value):
     if memo is None:
         memo = {}
         t.__dict__['_rua_memo'] = memo
-    memo[key] = (t._version, value)
+    memo[key] = (_version(t), value)
     return value
 
 
@@ -122,7 +128,19 @@ def dev_off(token_sizes: Tensor) -> Tensor:
 
 # ------------------------------------------------------------------ PackedSequence metadata
 def pack_B(p) -> int:
+    """The reference's P.size()[0] = batch_sizes.max() (layout/pack.py:12-17): the number of NON-EMPTY sequences."""
     return int(p.batch_sizes[0]) if p.batch_sizes.numel() else 0
+
+
+def pack_nseq(p) -> int:
+    """Sequences in the batch, zero-length ones included: what sorted/unsorted_indices and the lengths are sized
+    by.  `batch_sizes[0]` only bounds the RANK of a stored row; using it as the batch size would turn every
+    sequence whose index is >= the non-empty count into padding (C.pack() of lens such as [0,3,0,2])."""
+    if p.unsorted_indices is not None:
+        return int(p.unsorted_indices.numel())
+    if p.sorted_indices is not None:
+        return int(p.sorted_indices.numel())
+    return pack_B(p)
 
 
 def pack_boff(p) -> Tensor:
@@ -151,7 +169,7 @@ def pack_lens(p) -> Tensor:
         return hit[1]
     dev = L.require_device(p.data)
     lib = L.load()
-    B, T = pack_B(p), p.batch_sizes.numel()
+    B, T = pack_nseq(p), p.batch_sizes.numel()
     bsz = pack_bsz_dev(p)
     lens = torch.empty(B, dtype=torch.long, device=dev)
     L.check(lib.rua_lens_from_pack(L.ptr(bsz), T, L.ptr(p.unsorted_indices), B, L.ptr(lens), L.stream_ptr(dev)),
@@ -291,7 +309,7 @@ def lay_pack(p, lens: Optional[Tensor] = None, len_add: int = 0, boff: Optional[
         t = pack_tiling(p)       # narrow rows: hand the (rank x time) tile table to the mover
         keep += [t.bsz, t.tile_start]
         extra.update(bsz=L.ptr(t.bsz), tile_start=L.ptr(t.tile_start), n_tchunks=t.n_tchunks, n_tiles=t.n_tiles)
-    return Lay(keep, max_len=T, kind=L.PACK, n_rows=n_rows, B=pack_B(p),
+    return Lay(keep, max_len=T, kind=L.PACK, n_rows=n_rows, B=pack_nseq(p),
                lens=L.ptr(lens), len_add=len_add, boff=L.ptr(boff), T=T, sorted=L.ptr(p.sorted_indices),
                unsorted=L.ptr(p.unsorted_indices), **extra)
 

@@ -148,6 +148,8 @@ def launch_reduce(lay: M.Lay, data: Tensor, op: int, out: Optional[Tensor] = Non
         H *= d
     if out is None:
         out = torch.empty((lay.B,) + tuple(hidden), dtype=data.dtype, device=dev)
+    elif not out.is_contiguous() or out.dtype != data.dtype or out.numel() != lay.B * H:
+        raise L.RuaError('reduce target must be a contiguous [B, *hidden] tensor of the payload dtype')
     extreme = None
     if reference_initial and op in (L.MAX, L.MIN, L.LOGSUMEXP) and include_self == 0:
         extreme = torch.empty(65, dtype=torch.long, device=dev)  # initialised by the library
@@ -198,7 +200,7 @@ class _Reduce(torch.autograd.Function):
         ties = ctx.ties                        # max/min: counted by the forward -> apply only (TIES_FINAL)
         L.check(lib.rua_segment_reduce_backward(lay.ref(), None, L.ptr(data), L.ptr(out), L.ptr(grad), L.ptr(g), H,
                                                 L.DTYPES[data.dtype], op, L.TIES_FINAL if ties is not None else 0,
-                                                split, L.ptr(ws), L.ptr(ties), L.stream_ptr(dev)),
+                                                split, L.ptr(ws), L.ptr(ties), None, L.stream_ptr(dev)),
                 'rua_segment_reduce_backward')
         return g, None, None, None, None
 

@@ -29,8 +29,9 @@ def _to_self(self: Any, *_, **__) -> Any:
 # ------------------------------------------------------------------ core/view.py
 def get_mask(self: Z) -> Tensor:
     """core/view.py:11-18: [b, t] int64 grid of 0/1 — one kernel, no (batch_ptr, token_ptr) scatter."""
-    b, t = self.size()[:2]
-    return _mask_grid(lens_of(self), b, t, 0, 1, torch.long)
+    lens = lens_of(self)
+    # (rows = every sequence of the batch: P.size() counts only the non-empty ones, layout/pack.py:12-17)
+    return _mask_grid(lens, lens.numel(), self.size()[1], 0, 1, torch.long)
 
 
 def _mask_grid(lens: Tensor, b: int, t: int, zero, one, dtype: torch.dtype) -> Tensor:
@@ -78,7 +79,7 @@ def _pack_meta(token_sizes: Tensor, dev: torch.device):
     # sort, no upload — unless somebody wrote into the tensors handed out last time
     key = f'pack_meta:{dev}'
     hit = M._memo_get(token_sizes, key)
-    if hit is not None and all(t._version == v for t, v in zip(hit[0], hit[1])):
+    if hit is not None and all(M._version(t) == v for t, v in zip(hit[0], hit[1])):
         return (lens,) + hit[0]
     host, index = _sorted_indices(token_sizes)
     B = lens.numel()
@@ -99,7 +100,7 @@ def _pack_meta(token_sizes: Tensor, dev: torch.device):
     # (`lens` itself stays out of the memo: a tensor whose memo holds the tensor is a reference cycle, and cyclic
     # garbage made at every step drives Python into full collections — 38 ms each with torch's heap to scan)
     meta = (sorted_indices, unsorted, batch_sizes, bsz_dev, boff)
-    M._memo_put(token_sizes, key, (meta, tuple(t._version for t in meta)))
+    M._memo_put(token_sizes, key, (meta, tuple(M._version(t) for t in meta)))
     return (lens,) + meta
 
 
@@ -152,7 +153,7 @@ def _to_padded(cls, kind):
     def cast(self, fill_value: Number = 0):
         """core/cast.py:19-38 (left) / 52-71 (right): fill and payload in one pass."""
         lens = lens_of(self)
-        b, t = self.size()[:2]
+        b, t = lens.numel(), self.size()[1]
         dst = M.lay_padded(kind, lens, b, t, t)
         plan = O.MovePlan(dst, describe(self), (b, t) + _hidden(self), fill=fill_value,
                           name='to_left' if kind == K.LEFT else 'to_right')
@@ -285,21 +286,33 @@ _tensor_setitem = Tensor.__setitem__
 
 
 def patch_tensor_indexing() -> None:
-    """Opt-in twin of the reference's import-time patch of Tensor.__getitem__/__setitem__
-    (core/get.py:11-18, core/set.py:10-18): lets `tensor[Z]` re-wrap a container of row indices.
-    Not applied on import so that ordinary tensor indexing in the process is left untouched."""
+    """Twin of the reference's import-time patch of Tensor.__getitem__/__setitem__ (core/get.py:11-18,
+    core/set.py:10-18): lets `tensor[Z]` re-wrap a container of row indices and `tensor[Z] = value` scatter through
+    one.  `install_as_torchrua()` applies it (importing the reference does); a plain `import torchrua_amd` does not,
+    so that ordinary tensor indexing in the process is left untouched.  Payload on a HIP device goes through the
+    row mover, like container[Z]."""
     def tensor_getitem(self: T, key):
         if isinstance(key, (C, L, P, R)):
+            if self.is_cuda and self.dim() >= 1:
+                return key._replace(data=_gather_flat(self, key.data))
             return key._replace(data=_tensor_getitem(self, key.data))
         return _tensor_getitem(self, key)
 
     def tensor_setitem(self: T, key, value) -> None:
         if isinstance(key, (C, L, P, R)):
+            if self.is_cuda and self.dim() >= 1:
+                return _scatter_flat(self, key.data, value)
             return _tensor_setitem(self, key.data, value)
         return _tensor_setitem(self, key, value)
 
     Tensor.__getitem__ = tensor_getitem
     Tensor.__setitem__ = tensor_setitem
+
+
+def unpatch_tensor_indexing() -> None:
+    """Put torch's own Tensor.__getitem__/__setitem__ back."""
+    Tensor.__getitem__ = _tensor_getitem
+    Tensor.__setitem__ = _tensor_setitem
 
 
 # ------------------------------------------------------------------ core/__init__.py constructors
@@ -321,7 +334,9 @@ R.new = staticmethod(lambda tensors, fill_value=0: _new_cat(tensors).right(fill_
 
 def with_host_sizes(data: Tensor, token_sizes_host: Tensor) -> C:
     """C(data, token_sizes) from lengths that live on the host (what C.new does for a list)."""
-    host = token_sizes_host.to(dtype=torch.long, device='cpu')
+    # a private copy (B * 8 bytes): the mirror outlives this call, and a loader that reuses its length buffer must
+    # not be able to change what later pack()/size() calls sort and size from
+    host = token_sizes_host.to(dtype=torch.long, device='cpu', copy=True)
     dev_sizes = M.to_device_async(host, data.device)
     M.attach_host(dev_sizes, host)
     return C(data=data, token_sizes=dev_sizes)

@@ -17,8 +17,10 @@ __global__ void extreme_init_entry_kernel(unsigned long long* ext, int want_max_
                     const rua_layout* CD, void* copy, void* ties);                                                 \
   int backward_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,           \
                       const void* out, const void* gout, void* gin, int64_t H, int extra_count, int64_t split,    \
-                      void* ws, void* ties, bool ties_final);                                                      \
-  int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, const void* ext);
+                      void* ws, void* ties, bool ties_final, const void* self_in);                                 \
+  int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, const void* ext);  \
+  int self_grad_##NAME(hipStream_t s, const int64_t* counts, int64_t S, int64_t H, const void* self_in,            \
+                       const void* out, const void* gout, const void* aux, void* gself, int op, int inc);
 RUA_DECL(f32) RUA_DECL(bf16) RUA_DECL(f16) RUA_DECL(f64)
 #undef RUA_DECL
 }  // namespace rua
@@ -29,22 +31,44 @@ extern "C" {
 
 int rua_segment_reduce_backward(const rua_layout* lay, const int64_t* perm, const void* data, const void* out,
                                 const void* grad_out, void* grad_in, int64_t H, int32_t dtype, int32_t op,
-                                int32_t include_self, int64_t split_rows, void* ws, void* ties, void* stream) {
+                                int32_t include_self, int64_t split_rows, void* ws, void* ties,
+                                const void* self_in, void* stream) {
   if (!lay || H < 0 || lay->B < 0) return RUA_EINVAL;
   if (lay->kind != RUA_CAT && lay->kind != RUA_PACK && lay->kind != RUA_LEFT && lay->kind != RUA_RIGHT)
     return RUA_EINVAL;
   if (lay->kind == RUA_CAT && lay->lens && !lay->off) return RUA_EINVAL;
   if (lay->kind == RUA_PACK && lay->T > 0 && !lay->boff) return RUA_EINVAL;
   if (perm && lay->kind != RUA_CAT) return RUA_EINVAL;
+  if (self_in && !perm) return RUA_EINVAL;       // the old destination row only exists for scatter_*
   if (lay->B == 0 || H == 0 || lay->n_rows == 0) return 0;
   if (!data || !out || !grad_out || !grad_in) return RUA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const bool final = include_self == RUA_TIES_FINAL && ties != nullptr;   // the forward counted them (ties_out)
   switch (dtype) {
-    case RUA_F32: return backward_f32(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final);
-    case RUA_BF16: return backward_bf16(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final);
-    case RUA_F16: return backward_f16(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final);
-    case RUA_F64: return backward_f64(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final);
+    case RUA_F32: return backward_f32(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final, self_in);
+    case RUA_BF16: return backward_bf16(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final, self_in);
+    case RUA_F16: return backward_f16(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final, self_in);
+    case RUA_F64: return backward_f64(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final, self_in);
+  }
+  return RUA_EINVAL;
+}
+
+int rua_scatter_self_grad(const int64_t* counts, int64_t S, int64_t H, const void* self_in, const void* out,
+                          const void* grad_out, const void* aux, void* grad_self, int32_t dtype, int32_t op,
+                          int32_t include_self, void* stream) {
+  if (S < 0 || H < 0 || op < RUA_SUM || op > RUA_LOGSUMEXP) return RUA_EINVAL;
+  if (S == 0 || H == 0) return 0;
+  if (!counts || !grad_out || !grad_self) return RUA_EINVAL;
+  const bool reads_self = include_self && (op == RUA_MAX || op == RUA_MIN || op == RUA_LOGSUMEXP);
+  if (reads_self && (!self_in || !out)) return RUA_EINVAL;
+  if (include_self && op == RUA_PROD && !aux) return RUA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int inc = include_self ? 1 : 0;
+  switch (dtype) {
+    case RUA_F32: return self_grad_f32(s, counts, S, H, self_in, out, grad_out, aux, grad_self, op, inc);
+    case RUA_BF16: return self_grad_bf16(s, counts, S, H, self_in, out, grad_out, aux, grad_self, op, inc);
+    case RUA_F16: return self_grad_f16(s, counts, S, H, self_in, out, grad_out, aux, grad_self, op, inc);
+    case RUA_F64: return self_grad_f64(s, counts, S, H, self_in, out, grad_out, aux, grad_self, op, inc);
   }
   return RUA_EINVAL;
 }

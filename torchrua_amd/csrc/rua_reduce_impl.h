@@ -710,7 +710,8 @@ __device__ __forceinline__ void backward_unit(const Unit<T, EPL>& U, int64_t t_l
                                               const T* __restrict__ data, const T* __restrict__ out,
                                               const T* __restrict__ gout, T* __restrict__ gin, int64_t H,
                                               int extra_count, int lane,
-                                              typename elem<T>::acc* __restrict__ ties = nullptr) {
+                                              typename elem<T>::acc* __restrict__ ties = nullptr,
+                                              const T* __restrict__ self_in = nullptr) {
   using A = typename elem<T>::acc;
   struct alignas(sizeof(T) * EPL) Pack { T v[EPL]; };
   const int64_t b = U.b, col = U.col, len = U.len, base = U.base, tb = U.tb;
@@ -740,10 +741,23 @@ __device__ __forceinline__ void backward_unit(const Unit<T, EPL>& U, int64_t t_l
   for (int e = 0; e < EPL; ++e) zeros[e] = (A)0;
   const bool whole = RANKS || (t_lo == 0 && t_hi >= len);
   const bool two_pass = ((OP == RUA_MAX || OP == RUA_MIN) && TIES != 2) || (OP == RUA_PROD && whole);
+  // scatter_* (perm) with the old destination row `self_in`: for MAX/MIN that row is one more candidate tie — torch
+  // counts it even with include_self=False (index_reduce_backward: N = self_is_result + index_add(source_is_result));
+  // for PROD with include_self it is one more factor of the product
+  A sv[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) sv[e] = (A)1;
+  const bool has_self = self_in != nullptr && colok;
+  if (has_self) {
+    const Pack ps = *reinterpret_cast<const Pack*>(self_in + b * H + col);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) sv[e] = elem<T>::up(ps.v[e]);
+  }
   if (TIES == 2 && colok) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
-      const A c = ties[b * H + col + e];
+      A c = ties[b * H + col + e];
+      if (has_self && ((sv[e] == o[e]) || (sv[e] != sv[e] && o[e] != o[e]))) c += (A)1;
       g[e] = g[e] / (c > (A)0 ? c : (A)1);
     }
   }
@@ -812,7 +826,10 @@ __device__ __forceinline__ void backward_unit(const Unit<T, EPL>& U, int64_t t_l
       }
 #pragma unroll
       for (int e = 0; e < EPL; ++e) {
-        if (OP == RUA_PROD) zeros[e] = cnt[e];
+        if (OP == RUA_PROD) {
+          zeros[e] = cnt[e];
+          if (has_self && extra_count) { if (sv[e] == (A)0) zeros[e] += (A)1; else nz[e] *= sv[e]; }
+        }
         else if (TIES == 1) { if (colok && rsub == 0 && cnt[e] > (A)0) atomicAdd(&ties[b * H + col + e], cnt[e]); }
         else g[e] = g[e] / (cnt[e] > (A)0 ? cnt[e] : (A)1);   // MAX/MIN: ties share the gradient equally
       }
@@ -830,7 +847,8 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_kernel(rua_layout L, co
                                                                 const T* __restrict__ gout, T* __restrict__ gin,
                                                                 int64_t H, int lp_log2, int64_t n_chunks,
                                                                 int extra_count, SplitWs W,
-                                                                typename elem<T>::acc* __restrict__ ties) {
+                                                                typename elem<T>::acc* __restrict__ ties,
+                                                                const T* __restrict__ self_in) {
   const int lane = threadIdx.x;
   const int64_t wid = blockIdx.x;
   const int64_t q = wid / n_chunks;
@@ -849,7 +867,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_kernel(rua_layout L, co
     }
     t_hi = W.split;
   }
-  backward_unit<T, EPL, OP, TIES>(U, 0, t_hi, data, out, gout, gin, H, extra_count, lane, ties);
+  backward_unit<T, EPL, OP, TIES>(U, 0, t_hi, data, out, gout, gin, H, extra_count, lane, ties, self_in);
 }
 
 template <typename T, int EPL, int OP, int TIES>
@@ -859,7 +877,8 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_tail_kernel(rua_layout 
                                                                      const T* __restrict__ gout,
                                                                      T* __restrict__ gin, int64_t H, int lp_log2,
                                                                      int extra_count, SplitWs W,
-                                                                     typename elem<T>::acc* __restrict__ ties) {
+                                                                     typename elem<T>::acc* __restrict__ ties,
+                                                                     const T* __restrict__ self_in) {
   const int lane = threadIdx.x;
   const int64_t n_items = (int64_t)W.ctr[0];
   for (int64_t i = blockIdx.x; i < n_items; i += gridDim.x) {
@@ -867,7 +886,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_tail_kernel(rua_layout 
     const Unit<T, EPL> U = make_unit<T, EPL, false>(L, L, perm, e[0], e[1], H, lp_log2, lane);
     const int64_t t_lo = e[2] * W.split;
     const int64_t t_hi = (t_lo + W.split < U.len) ? t_lo + W.split : U.len;
-    backward_unit<T, EPL, OP, TIES>(U, t_lo, t_hi, data, out, gout, gin, H, extra_count, lane, ties);
+    backward_unit<T, EPL, OP, TIES>(U, t_lo, t_hi, data, out, gout, gin, H, extra_count, lane, ties, self_in);
   }
 }
 
@@ -949,15 +968,63 @@ __global__ __launch_bounds__(RUA_BLOCK) void fill_empty_kernel(rua_layout L, T* 
   if (poison) val = val - val + (A)__builtin_nanf("");
   const T tv = elem<T>::down(val);
 
-  // one thread per sequence; only empty sequences (or everything, when a NaN poisoned `initial`) are written
-  const int64_t b = (int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x;
-  if (b >= L.B) return;
-  if (!poison && seq_len(L, b) > 0) return;
-  T* o = out + b * H;
-  for (int64_t h = 0; h < H; ++h) o[h] = tv;
+  // only empty sequences (or everything, when a NaN poisoned `initial`) are written.  A lane inspects one sequence,
+  // then the wave writes the marked rows together, lanes side by side along H (coalesced stores; the poisoned case
+  // rewrites the whole [B, H] output and used to do it one scalar store per thread)
+  const int64_t b0 = ((int64_t)blockIdx.x * RUA_WAVES_PER_BLOCK + (threadIdx.x >> 6)) * RUA_WAVE;
+  const int64_t b = b0 + lane;
+  const bool mine = b < L.B && (poison || seq_len(L, b) <= 0);
+  unsigned long long todo = __ballot(mine);
+  while (todo) {
+    const int k = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    T* o = out + (b0 + k) * H;
+    for (int64_t h = lane; h < H; h += RUA_WAVE) o[h] = tv;
+  }
 }
 
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + RUA_BLOCK - 1) / RUA_BLOCK); }
+
+// Gradient of scatter_* w.r.t. the destination `tensor` ([S, H], reduce.py:6-31 through torch's index_reduce /
+// index_add backward): elementwise in (tensor, out, grad) plus the per-destination facts the other kernels already
+// produced — the bucket size, MAX/MIN: the source rows' tie counts (the forward's ties_out), PROD: the product of
+// the bucket's source rows.  One thread per element.
+//   include_self:  SUM g | MEAN g/(n+1) | MAX/MIN (tensor == out) ? g/ties : 0 | PROD g*prod(sources) |
+//                  LOGSUMEXP g*exp(tensor - out)
+//   otherwise:     rows no index names keep `tensor` (index_reduce semantics): g there, 0 elsewhere
+template <typename T>
+__global__ __launch_bounds__(RUA_BLOCK) void scatter_self_grad_kernel(const int64_t* __restrict__ counts, int64_t S,
+                                                                      int64_t H, const T* __restrict__ self_in,
+                                                                      const T* __restrict__ out,
+                                                                      const T* __restrict__ gout,
+                                                                      const void* __restrict__ aux,
+                                                                      T* __restrict__ gself, int op, int inc) {
+  using A = typename elem<T>::acc;
+  const int64_t i = (int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x;
+  if (i >= S * H) return;
+  const int64_t n = counts[i / H];
+  const A g = elem<T>::up(gout[i]);
+  A r;
+  if (!inc) {
+    r = n == 0 ? g : (A)0;
+  } else if (op == RUA_SUM) {
+    r = g;
+  } else if (op == RUA_MEAN) {
+    r = g / (A)(n + 1);
+  } else if (op == RUA_PROD) {
+    r = g * elem<T>::up(reinterpret_cast<const T*>(aux)[i]);
+  } else {
+    const A x = elem<T>::up(self_in[i]), o = elem<T>::up(out[i]);
+    if (op == RUA_LOGSUMEXP) {
+      r = g * fexp(x - o);
+    } else {
+      const bool hit = (x == o) || (x != x && o != o);
+      const A c = (aux ? reinterpret_cast<const A*>(aux)[i] : (A)0) + (A)1;
+      r = hit ? g / c : (A)0;
+    }
+  }
+  gself[i] = elem<T>::down(r);
+}
 
 // workspace carving for the long-sequence split (see SplitWs)
 static inline int64_t split_max_extra(int64_t n_rows, int64_t split) { return split > 0 ? n_rows / split : 0; }
@@ -1108,7 +1175,8 @@ static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int
   const int r = dispatch_reduce_main<T>(op, s, L, perm, data, out, H, include_self, empty_bits, extreme, split, ws, CD,
                                         copy, ties);
   if (r != 0 || !extreme || !(op == RUA_MAX || op == RUA_MIN || op == RUA_LOGSUMEXP)) return r;
-  if (L.kind == RUA_PACK && !copy) return r;   // every sequence of a PackedSequence holds a token: nothing can be empty
+  // (a PackedSequence may carry zero-length sequences too — C.pack() of lens such as [0,3,0,2] — so PACK takes the
+  // same lazy second walk: every workgroup leaves on the flag word unless a sequence was empty or a NaN showed)
   constexpr int FULL = 16 / sizeof(T);
   const bool vec_ok = (H % FULL == 0) && ((uintptr_t)data % 16 == 0);
   const int64_t lpr = (H + (vec_ok ? FULL : 1) - 1) / (vec_ok ? FULL : 1);
@@ -1132,9 +1200,10 @@ template <typename T, int EPL>
 static int launch_backward(int op, unsigned grid, hipStream_t s, const rua_layout& L, const int64_t* perm,
                            const void* data, const void* out, const void* gout, void* gin, int64_t H, int lp_log2,
                            int64_t n_chunks, int extra_count, int64_t split, void* ws, void* ties,
-                           bool ties_final) {
+                           bool ties_final, const void* self_in) {
   using A = typename elem<T>::acc;
   const dim3 g(grid), b(RUA_WAVE);
+  const T* sp = (const T*)self_in;
   const bool extreme_op = op == RUA_MAX || op == RUA_MIN;
   const bool phased = extreme_op && ties != nullptr;        // count phase, then apply phase
   // ties_final: the forward already counted them (RUA_MAX_T / RUA_MIN_T) -> the apply phase alone, ONE walk
@@ -1154,12 +1223,12 @@ static int launch_backward(int op, unsigned grid, hipStream_t s, const rua_layou
       hipError_t e_ = hipMemsetAsync(W.ctr, 0, 4 * sizeof(unsigned long long), s);                                 \
       if (e_ != hipSuccess) return (int)e_;                                                                        \
       hipLaunchKernelGGL((seg_backward_kernel<T, EPL, OP, true, TIESV>), g, b, 0, s, L, perm, (const T*)data,      \
-                         (const T*)out, (const T*)gout, (T*)gin, H, lp_log2, n_chunks, extra_count, W, tp);        \
+                         (const T*)out, (const T*)gout, (T*)gin, H, lp_log2, n_chunks, extra_count, W, tp, sp);    \
       hipLaunchKernelGGL((seg_backward_tail_kernel<T, EPL, OP, TIESV>), dim3(split_grid(max_u)), b, 0, s, L, perm, \
-                         (const T*)data, (const T*)out, (const T*)gout, (T*)gin, H, lp_log2, extra_count, W, tp);  \
+                         (const T*)data, (const T*)out, (const T*)gout, (T*)gin, H, lp_log2, extra_count, W, tp, sp); \
     } else {                                                                                                       \
       hipLaunchKernelGGL((seg_backward_kernel<T, EPL, OP, false, TIESV>), g, b, 0, s, L, perm, (const T*)data,     \
-                         (const T*)out, (const T*)gout, (T*)gin, H, lp_log2, n_chunks, extra_count, W, tp);        \
+                         (const T*)out, (const T*)gout, (T*)gin, H, lp_log2, n_chunks, extra_count, W, tp, sp);    \
     }                                                                                                              \
   }
 #define RUA_EXTREME(OP)                                       \
@@ -1182,9 +1251,10 @@ static int launch_backward(int op, unsigned grid, hipStream_t s, const rua_layou
 template <typename T>
 static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,
                              const void* out, const void* gout, void* gin, int64_t H, int extra_count,
-                             int64_t split, void* ws, void* ties, bool ties_final) {
+                             int64_t split, void* ws, void* ties, bool ties_final, const void* self_in) {
   constexpr int FULL = 16 / sizeof(T);
-  const uintptr_t ptrs = (uintptr_t)data | (uintptr_t)out | (uintptr_t)gout | (uintptr_t)gin | (uintptr_t)ties;
+  const uintptr_t ptrs = (uintptr_t)data | (uintptr_t)out | (uintptr_t)gout | (uintptr_t)gin | (uintptr_t)ties |
+                         (uintptr_t)self_in;
   const bool vec_ok = (H % FULL == 0) && (ptrs % 16 == 0);
   const int epl = vec_ok ? FULL : 1;
   const int64_t lpr = (H + epl - 1) / epl;
@@ -1194,7 +1264,7 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
   const int64_t blocks = L.B * n_chunks;
   if (blocks > 0x7fffffffLL) return RUA_ERANGE;
   if (L.kind == RUA_PACK && L.sorted && !perm && (!ties || ties_final) && lp_log2 < 6 && !(split > 0 && ws) &&
-      !extra_count && (L.B >> (6 - lp_log2)) >= RANKS_MIN_WAVES) {
+      !extra_count && !self_in && (L.B >> (6 - lp_log2)) >= RANKS_MIN_WAVES) {
     // narrow rows of a PackedSequence: adjacent ranks share a wave instruction
     const int64_t rpw = RUA_WAVE >> lp_log2;
     const int64_t nblk = (L.B + rpw - 1) / rpw;
@@ -1220,9 +1290,9 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
   }
   if (vec_ok)
     return launch_backward<T, FULL>(op, (unsigned)blocks, s, L, perm, data, out, gout, gin, H, lp_log2, n_chunks,
-                                    extra_count, split, ws, ties, ties_final);
+                                    extra_count, split, ws, ties, ties_final, self_in);
   return launch_backward<T, 1>(op, (unsigned)blocks, s, L, perm, data, out, gout, gin, H, lp_log2, n_chunks, extra_count,
-                               split, ws, ties, ties_final);
+                               split, ws, ties, ties_final, self_in);
 }
 
 // ---- per-dtype entry points: each element type is compiled in its own translation unit
@@ -1233,8 +1303,10 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
                     const rua_layout* CD, void* copy, void* ties);                                                 \
   int backward_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,           \
                       const void* out, const void* gout, void* gin, int64_t H, int extra_count, int64_t split,    \
-                      void* ws, void* ties, bool ties_final);                                                      \
-  int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, const void* ext);
+                      void* ws, void* ties, bool ties_final, const void* self_in);                                 \
+  int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, const void* ext); \
+  int self_grad_##NAME(hipStream_t s, const int64_t* counts, int64_t S, int64_t H, const void* self_in,            \
+                       const void* out, const void* gout, const void* aux, void* gself, int op, int inc);
 RUA_DECLARE_REDUCE_DTYPE(f32)
 RUA_DECLARE_REDUCE_DTYPE(bf16)
 RUA_DECLARE_REDUCE_DTYPE(f16)
@@ -1250,12 +1322,20 @@ RUA_DECLARE_REDUCE_DTYPE(f64)
   }                                                                                                                 \
   int backward_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,           \
                       const void* out, const void* gout, void* gin, int64_t H, int extra_count, int64_t split,    \
-                      void* ws, void* ties, bool ties_final) {                                                     \
-    return dispatch_backward<T>(op, s, L, perm, data, out, gout, gin, H, extra_count, split, ws, ties, ties_final); \
+                      void* ws, void* ties, bool ties_final, const void* self_in) {                                \
+    return dispatch_backward<T>(op, s, L, perm, data, out, gout, gin, H, extra_count, split, ws, ties, ties_final, \
+                                self_in);                                                                          \
   }                                                                                                                 \
   int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, const void* ext) { \
     hipLaunchKernelGGL(fill_empty_kernel<T>, dim3(grid_for(L.B)), dim3(RUA_BLOCK), 0, s, L, (T*)out, H, want_max,  \
                        (const unsigned long long*)ext);                                                            \
+    return (int)hipGetLastError();                                                                                  \
+  }                                                                                                                 \
+  int self_grad_##NAME(hipStream_t s, const int64_t* counts, int64_t S, int64_t H, const void* self_in,            \
+                       const void* out, const void* gout, const void* aux, void* gself, int op, int inc) {         \
+    if (S * H > 0x7fffffffLL * RUA_BLOCK) return RUA_ERANGE;                                                        \
+    hipLaunchKernelGGL(scatter_self_grad_kernel<T>, dim3(grid_for(S * H)), dim3(RUA_BLOCK), 0, s, counts, S, H,    \
+                       (const T*)self_in, (const T*)out, (const T*)gout, aux, (T*)gself, op, inc);                 \
     return (int)hipGetLastError();                                                                                  \
   }                                                                                                                 \
   }

@@ -127,15 +127,16 @@ class _Scatter(torch.autograd.Function):
         counts, perm = _buckets(index, S)
         lay = M.lay_cat(counts, S, int(source.size(0)))
         hidden = tuple(tensor.shape[1:])
+        # (row-major whatever the strides of `tensor`: the kernel addresses out[s * H + h])
         if op == K.SUM and not include_self:
-            out, mode = torch.empty_like(tensor), 0            # index_add into zeros (reduce.py:15)
+            out, mode = torch.empty(tensor.shape, dtype=tensor.dtype, device=tensor.device), 0   # index_add into zeros (reduce.py:15)
         else:
-            out = tensor.detach().clone()
+            out = tensor.detach().clone(memory_format=torch.contiguous_format)
             # include_self: fold the old row in; otherwise rows no index names keep their value
             # and touched rows start from the identity (torch.index_reduce semantics)
             mode = 1 if include_self else 2
         if op == K.LOGSUMEXP and not include_self:
-            out, mode = torch.empty_like(tensor), 0            # untouched rows -> log(0) = -inf (reduce.py:26-31)
+            out, mode = torch.empty(tensor.shape, dtype=tensor.dtype, device=tensor.device), 0   # untouched rows -> log(0) = -inf (reduce.py:26-31)
         ties = None
         if op in (K.MAX, K.MIN) and (ctx.needs_input_grad[0] or ctx.needs_input_grad[2]):
             # source rows equal to the result, counted by the forward (the backward is then one walk)
@@ -151,49 +152,54 @@ class _Scatter(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, grad: T):
         """Gradient w.r.t. the source rows: the fused kernel walking every destination's bucket
-        (rua_segment_reduce_backward with the row indirection; for max/min the tie count is seeded with the old
-        destination row when include_self).  The [S, H]-sized gradient w.r.t. `tensor` is elementwise torch."""
+        (rua_segment_reduce_backward with the row indirection; the old destination row `tensor` rides along as
+        `self_in`: one more tie candidate for max/min, one more factor for prod with include_self).  Gradient w.r.t.
+        `tensor`: one elementwise launch over [S, H] (rua_scatter_self_grad).  No ATen kernel touches either."""
         tensor, index, source, out, counts = ctx.saved_tensors
         op, inc = ctx.op, ctx.include_self
-        grad = grad.contiguous()
-        view = (-1,) + (1,) * (grad.dim() - 1)
-        touched = (counts > 0).view(view)
-        untouched_pass = torch.where(touched, torch.zeros_like(grad), grad)     # rows no index names keep `tensor`
-        g_src = g_ten = None
+        lib = K.load()
         dev = K.require_device(source)
-        H = 1
-        for d in out.shape[1:]:
+        dt = K.DTYPES[source.dtype]
+        grad = grad.contiguous()
+        tensor_c = tensor.contiguous()
+        hidden = tuple(out.shape[1:])
+        S, H = out.size(0), 1
+        for d in hidden:
             H *= d
-        ties, final = None, 0
-        if op in (K.MAX, K.MIN):
-            # ties the source rows do not see: the old destination row where it equals the result.  torch's
-            # index_reduce backward counts it even when include_self=False (FunctionsManual index_reduce_backward:
-            # N = self_is_result.index_add(source_is_result)) and the reference inherits that (reduce.py:6-11),
-            # so it is reproduced here.
-            acc = torch.float64 if source.dtype == torch.float64 else torch.float32
-            hit_t = (tensor == out).to(acc)
-            if ctx.ties is not None:          # the forward counted the source rows: totals are complete, one walk
-                ties, final = hit_t + ctx.ties, K.TIES_FINAL
+        g_src = g_ten = None
+        if ctx.needs_input_grad[2]:
+            g_src = torch.empty(source.shape, dtype=source.dtype, device=dev)   # every source row sits in one bucket
+            ties, mode, self_in = None, (1 if inc else 0), None
+            if op in (K.MAX, K.MIN):
+                # the forward counted the source rows equal to the result; the kernel adds the old row's tie
+                # (torch counts it with and without include_self: index_reduce_backward) -> one walk
+                ties, mode, self_in = ctx.ties, K.TIES_FINAL, tensor_c
+            elif op == K.PROD and inc:
+                self_in = tensor_c
+            split, ws = O.split_workspace(ctx.lay, H, source.dtype, dev)
+            K.check(lib.rua_segment_reduce_backward(ctx.lay.ref(), K.ptr(ctx.perm), K.ptr(source.contiguous()),
+                                                    K.ptr(out), K.ptr(grad), K.ptr(g_src), H, dt, op, mode, split,
+                                                    K.ptr(ws), K.ptr(ties), K.ptr(self_in), K.stream_ptr(dev)),
+                    'rua_segment_reduce_backward')
+        if ctx.needs_input_grad[0]:
+            if op == K.SUM:
+                g_ten = grad if inc else None            # index_add: d out / d tensor = 1 (reduce.py:14-15 adds into zeros)
+            elif op == K.LOGSUMEXP and not inc:
+                g_ten = None                             # reduce.py:26-31 scatters into a fresh buffer
             else:
-                ties = hit_t.clone()
-        g_src = torch.empty_like(source)       # every source row belongs to exactly one bucket
-        split, ws = O.split_workspace(ctx.lay, H, source.dtype, dev)
-        K.check(K.load().rua_segment_reduce_backward(ctx.lay.ref(), K.ptr(ctx.perm), K.ptr(source.contiguous()),
-                                                     K.ptr(out), K.ptr(grad), K.ptr(g_src), H, K.DTYPES[source.dtype],
-                                                     op, final if final else (1 if inc else 0), split, K.ptr(ws), K.ptr(ties),
-                                                     K.stream_ptr(dev)), 'rua_segment_reduce_backward')
-        if op == K.SUM:
-            g_ten = grad if inc else None
-        elif op == K.MEAN:
-            n = (counts + (1 if inc else 0)).clamp_min(1).to(grad.dtype).view(view)
-            g_ten = grad / n if inc else untouched_pass
-        elif op in (K.MAX, K.MIN):
-            # `ties` now holds the total tie count of every destination (the kernel added the sources' share)
-            g_ten = (grad / ties.clamp_min(1).to(grad.dtype)) * hit_t.to(grad.dtype) if inc else untouched_pass
-        elif op == K.PROD:
-            g_ten = grad * out / tensor if inc else untouched_pass
-        else:  # LOGSUMEXP
-            g_ten = grad * (tensor - out).exp() if inc else None
+                aux = None
+                if op in (K.MAX, K.MIN) and inc:
+                    aux = ctx.ties
+                elif op == K.PROD and inc:
+                    # d out / d tensor = product of the bucket's source rows.  `out / tensor` loses it where
+                    # tensor == 0 (torch masks those and reduces again): one more launch of the reducer, into ones
+                    aux = torch.ones(out.shape, dtype=out.dtype, device=dev)
+                    O.launch_reduce(ctx.lay, source.detach(), K.PROD, out=aux, include_self=2, perm=ctx.perm,
+                                    hidden=hidden, reference_initial=False, name='scatter')
+                g_ten = torch.empty(out.shape, dtype=out.dtype, device=dev)
+                K.check(lib.rua_scatter_self_grad(K.ptr(counts), S, H, K.ptr(tensor_c), K.ptr(out), K.ptr(grad),
+                                                  K.ptr(aux), K.ptr(g_ten), dt, op, 1 if inc else 0,
+                                                  K.stream_ptr(dev)), 'rua_scatter_self_grad')
         return g_ten, None, g_src, None, None
 
 
@@ -203,6 +209,18 @@ def _scatter(tensor: T, index: T, source: T, op: int, include_self: bool, dim: i
     K.require_device(tensor, index, source)
     if tensor.dtype not in K.DTYPES:
         raise K.RuaError(f'reductions support {list(K.DTYPES)}; got {tensor.dtype}')
+    # what torch.index_add / index_reduce reject (reduce.py:6-31 inherit their checks): the kernel is launched with
+    # the source's element type and the destination's row width, so a mismatch would write out of bounds
+    if source.dtype != tensor.dtype:
+        raise K.RuaError(f'scatter_*: source is {source.dtype} but tensor is {tensor.dtype}')
+    if tensor.dim() < 1 or source.dim() != tensor.dim() or tuple(source.shape[1:]) != tuple(tensor.shape[1:]):
+        raise K.RuaError(f'scatter_*: source rows {tuple(source.shape[1:])} do not match tensor rows '
+                         f'{tuple(tensor.shape[1:])}')
+    if index.dim() != 1 or index.numel() != source.size(0):
+        raise K.RuaError(f'scatter_*: index must be 1-D with one entry per source row '
+                         f'(got {tuple(index.shape)} for {source.size(0)} rows)')
+    if index.dtype not in (torch.long, torch.int32):
+        raise K.RuaError(f'scatter_*: index must be int64 or int32 (got {index.dtype})')
     return _Scatter.apply(tensor, index, source, op, bool(include_self))
 
 
