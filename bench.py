@@ -111,13 +111,51 @@ def cpu_baseline(args):
                       f'pack -> cat -> segment_sum, median of 3, {t:.2f} s each'}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here, one fresh child process per GPU, BEFORE
+    anything in this process touches the GPU (the parent never does), and leave with their exit code.  The children
+    are this same script with the rendezvous environment torch.distributed.run would have set."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = torch.cuda.device_count()          # counts devices without initialising the runtime
+    if 'RUA_BENCH_DEVICE' not in os.environ and have < n:
+        raise SystemExit(f'bench.py: --gpus {n} but this node shows {have} GPU(s)')
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = dict(enumerate(procs))
+    while pending:
+        for r, pr in list(pending.items()):
+            code = pr.poll()
+            if code is None:
+                continue
+            del pending[r]
+            if code != 0 and rc == 0:
+                rc = code
+                print(f'bench.py: rank {r} exited with {code}; stopping the other ranks', file=sys.stderr)
+                for other in pending.values():     # exactly the children started above
+                    other.terminate()
+        time.sleep(0.05)
+    raise SystemExit(rc)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for a '
+                         f'different number of ranks than was asked for')
     # rehearsal knobs (1-GPU box): RUA_BENCH_DEVICE pins every rank to one card, RUA_BENCH_BACKEND=gloo replaces RCCL
     dev = torch.device('cuda', int(os.environ.get('RUA_BENCH_DEVICE', local_rank)))
     torch.cuda.set_device(dev)
@@ -203,7 +241,13 @@ def main():
         for _ in range(k):
             p, out = step(host_mirror=False)
         sync()
-        extra['value_device_lens'] = round(N * H / ((time.perf_counter() - t1) / k) / 1e6, 1)
+        dl_ms = (time.perf_counter() - t1) / k * 1e3
+        extra['value_device_lens'] = round(N * H / (dl_ms * 1e-3) / 1e6, 1)
+        extra['device_lens'] = {
+            'call': 'C(data, token_sizes_on_device).pack() -> reduce_sum: the reference\'s own constructor signature; '
+                    'every pack() reads the lengths back (blocking D2H) before the host sort',
+            'value': extra['value_device_lens'], 'unit': 'M elements/s', 'ms_per_step': round(dl_ms, 4), 'steps': k,
+            'frac_of_hbm_peak_wall': round((3.0 * N * H * e + 1.0 * B * H * e + 8.0 * (4 * B + T)) / (dl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         # extension, reported beside the graded pipeline: pack + reduce fused into one pass (same outputs)
         del p
         for _ in range(2):      # allocator warm-up for the fused variant's buffers
@@ -224,15 +268,20 @@ def main():
             'note': 'one kernel returns the PackedSequence AND the [B,H] sums; 2/3 of the pipeline traffic'}
 
 
+    # per-rank facts: rows, own wall clock, own kernel times (HIP events on the launch stream)
+    mine = [float(N), dt, timer.mean_ms('to_pack') or 0.0, timer.mean_ms('reduce') or 0.0]
+    per_rank = [mine]
+    ranks_reported = 1
     if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        ntot = torch.tensor([N], dtype=torch.float64, device=dev)
-        dist.all_reduce(ntot)
-        n_total = float(ntot.item())
-    else:
-        n_total = float(N)
+        ranks_reported = dist.get_world_size()
+        if ranks_reported != args.gpus:
+            raise SystemExit(f'bench.py: the process group reports {ranks_reported} ranks, --gpus {args.gpus}')
+        table = torch.zeros((world, len(mine)), dtype=torch.float64, device=dev)
+        table[rank] = torch.tensor(mine, dtype=torch.float64, device=dev)
+        dist.all_reduce(table)                      # every rank fills its own row
+        per_rank = table.cpu().tolist()
+        dt = max(row[1] for row in per_rank)        # the slowest rank sets the job's time
+    n_total = sum(row[0] for row in per_rank)
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -253,8 +302,14 @@ def main():
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': f'pack->reduce_sum: {B} seqs/GPU, len~U({args.lo},{args.hi}), hidden={H}, bf16 '
                                    f'({"north-star shape" if (B, H, args.lo, args.hi) == (65536, 512, 8, 512) else "custom shape"}; N={N} rows on rank 0)',
-                       'sharding': f'{world} x contiguous batch shards, one all-gather of [B,H]' if world > 1 else 'none',
-                       'lens_source': 'host (C.new-style hand-over)'},
+                       'sharding': f'{world} x contiguous batch shards ({B * world} sequences in all), one all-gather of [B,H]' if world > 1 else 'none',
+                       'lens_source': 'host (C.new-style hand-over)',
+                       'ranks_reported_by_process_group': ranks_reported,
+                       'backend': (os.environ.get('RUA_BENCH_BACKEND', 'nccl') + (' (RCCL)' if os.environ.get('RUA_BENCH_BACKEND', 'nccl') == 'nccl' else '')) if use_dist else None},
+            'per_rank': [{'rank': r, 'rows': int(row[0]), 'ms_per_step': round(row[1] / args.steps * 1e3, 4),
+                          'pack_kernel_GBps': round((2.0 * row[0] * H * e + 8.0 * (3 * B + T)) / (row[2] * 1e-3) / 1e9, 1) if row[2] else None,
+                          'reduce_kernel_GBps': round((row[0] * H * e + 1.0 * B * H * e + 8.0 * B) / (row[3] * 1e-3) / 1e9, 1) if row[3] else None}
+                         for r, row in enumerate(per_rank)],
             'roofline': {'bound': 'hbm', 'kernel': 'move_rows_kernel<16,false,NT> (C->P pack)',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,

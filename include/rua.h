@@ -232,6 +232,21 @@ int64_t rua_bucket_ws_elems(int64_t M, int64_t S);
 int rua_index_buckets(const int64_t* index, int64_t M, int64_t S, int64_t* counts, int64_t* off,
                       int64_t* perm, int64_t* ws, void* stream);
 
+/* ---- host side of pack() (no GPU involved; plain host pointers) ------------------------------------------
+ * sorted_indices of core/view.py:48 — `torch.sort(token_sizes.cpu(), descending=True)` — for int64 keys, with the
+ * SAME tie order: ATen's CPU kernel is the C++ library's introsort over (key, index) pairs compared by key only,
+ * a deterministic function of the input that is reproduced here step for step, the two halves of every partition
+ * on different threads (n_threads >= 1, the caller included).  The Python layer verifies the equality against
+ * torch.sort itself at first use and otherwise keeps making the reference's call. */
+int rua_host_sort_desc(const int64_t* keys, int64_t n, int64_t* sorted_indices, int32_t n_threads);
+/* diagnostics for the tests: how many segments, over all calls so far, exhausted the introsort's depth budget and
+ * were heap-sorted (the branch a random input never reaches; tests/golden/sort_killer.npy does) */
+int64_t rua_host_sort_heap_segments(void);
+
+/* batch_sizes[t] = #{b : lens[b] > t}, t < T — the CPU tensor PackedSequence mandates
+ * (core/view.py:55: get_mask(self).sum(dim=0).cpu()), from the host copy of the lengths. */
+int rua_host_batch_sizes(const int64_t* lens, int64_t B, int64_t T, int64_t* batch_sizes);
+
 /* Introspection: ABI version and the gfx target the code objects were built for. */
 int rua_abi_version(void);
 const char* rua_build_target(void);

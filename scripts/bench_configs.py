@@ -85,9 +85,13 @@ def main():
     timeit('l.pack()', lambda: lft.pack(), 2 * N * H * e)
     del lft, p, c, data
 
-    print('--- cfg4: B=65536 U(16,1024) H=1024 bf16')
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
-    B = 65536 if free > 230e9 else 16384
+    B = 65536 if free > 215e9 else 16384
+    print(f'--- cfg4: B={B} U(16,1024) H=1024 bf16   ({free / 1e9:.0f} GB free before allocation'
+          f'{"" if B == 65536 else "; REDUCED from the BASELINE size 65536"})')
     lens, data = inputs(4, B, 16, 1024, 1024)
     N, H = data.size(0), 1024
     p = ta.with_host_sizes(data, lens).pack()

@@ -130,10 +130,16 @@ def test_full_cfg3_segment_max():
 
 
 def test_full_cfg4_roll_head_last():
+    """BASELINE.json cfg4 at its real size: B = 65 536, len~U(16,1024), H = 1 024, bf16 — 69.8 GB of payload, three
+    such buffers alive at the peak (p, roll(1), roll(-1))."""
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()           # earlier tests leave their blocks in torch's caching allocator
     free, _ = torch.cuda.mem_get_info()
     B, H = 65536, 1024
-    if free < 230e9:
-        B = 16384
+    if free < 215e9:
+        pytest.skip(f'cfg4 needs ~210 GB of HBM for B = {B}; only {free / 1e9:.0f} GB free on this card')
+    print(f'cfg4 runs at B = {B} ({free / 1e9:.0f} GB free)')
     lens, data = _device_inputs(4, B, 16, 1024, H)
     p = ta.with_host_sizes(data, lens).pack()
     del data

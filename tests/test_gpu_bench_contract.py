@@ -6,10 +6,10 @@ import sys
 
 import pytest
 
-pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.mark.gpu
 def test_bench_json_line():
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--batch', '512', '--hidden', '64', '--steps', '3',
                           '--warmup', '1', '--cpu-sample', '64'], capture_output=True, text=True, timeout=600, cwd=ROOT)
@@ -29,3 +29,50 @@ def test_bench_json_line():
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and 'sample' in c
     assert d['value'] > 0 and d['ms_per_step'] > 0
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: the script itself starts two ranks (fresh children, before any GPU
+    call in the parent) and rank 0 prints ONE line for a two-rank job.  Rehearsed on the one-GPU box: both ranks on
+    card 0, gloo instead of RCCL (RCCL refuses two ranks on one device)."""
+    env = dict(os.environ, RUA_BENCH_DEVICE='0', RUA_BENCH_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--batch', '512', '--hidden', '64',
+                          '--steps', '3', '--warmup', '1'], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['ranks_reported_by_process_group'] == 2
+    assert [r['rank'] for r in d['per_rank']] == [0, 1]
+    assert all(r['rows'] > 0 and r['pack_kernel_GBps'] > 0 and r['reduce_kernel_GBps'] > 0 for r in d['per_rank'])
+    assert d['per_rank'][0]['rows'] != d['per_rank'][1]['rows']          # every rank draws its own shard
+    total = sum(r['rows'] for r in d['per_rank'])
+    assert abs(d['value'] - total * 64 / (d['ms_per_step'] * 1e-3) / 1e6) / d['value'] < 1e-3
+    assert 'cpu_baseline' not in d                                       # rank 0 at N = 1 only
+
+
+def test_bench_refuses_a_world_that_is_not_what_was_asked_for():
+    """--gpus N must never end as a line for a different number of ranks: a launcher environment that disagrees is an
+    error (checked before anything touches a GPU, so this runs anywhere)."""
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29999')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and 'WORLD_SIZE=1' in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    env['WORLD_SIZE'] = '4'
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '1', '--warmup', '0'],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and 'WORLD_SIZE=4' in out.stderr
+
+
+def test_bench_self_launch_needs_the_gpus_it_was_asked_for():
+    """No launcher, --gpus 16: more ranks than any single node of this pool has cards — a loud non-zero exit, never a
+    one-rank run that prints n_gpus: 1 (what round 1 did)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'RUA_BENCH_DEVICE')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '16', '--steps', '1', '--warmup', '0'],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and '--gpus 16' in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith('{')]

@@ -68,6 +68,9 @@ SYMBOLS = {
     'rua_fill_empty': (c_int, [POINTER(RuaLayout), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     'rua_bucket_ws_elems': (c_int64, [c_int64, c_int64]),
     'rua_index_buckets': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rua_host_sort_desc': (c_int, [c_void_p, c_int64, c_void_p, c_int32]),
+    'rua_host_sort_heap_segments': (c_int64, []),
+    'rua_host_batch_sizes': (c_int, [c_void_p, c_int64, c_int64, c_void_p]),
     'rua_abi_version': (c_int, []),
     'rua_build_target': (c_char_p, []),
 }

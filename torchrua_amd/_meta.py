@@ -7,6 +7,8 @@ TENSOR OBJECT they were derived from (guarded by the tensor's `_version`), so a 
 touches payload bytes.
 """
 import ctypes
+import os
+import time
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -86,20 +88,44 @@ def _as_lens(t: Tensor) -> Tensor:
 
 
 def host_lens(token_sizes: Tensor) -> Tensor:
-    """CPU copy of a length vector.  Free when the vector was built from host data
-    (C.new attaches the mirror); otherwise ONE blocking D2H, then memoised.
+    """CPU copy of a length vector.  Free when the vector was built from host data (C.new / with_host_sizes attach
+    the mirror); otherwise ONE blocking D2H, then memoised.
     The reference pays a sync of this kind in every size() (layout/cat.py:61-66)."""
     if not token_sizes.is_cuda:
         return token_sizes
     hit = _memo_get(token_sizes, 'host')
     if hit is not None:
         return hit
-    with host_serial():
-        return _memo_put(token_sizes, 'host', token_sizes.detach().cpu())
+    alias = _memo_get(token_sizes, 'host_alias')
+    if alias is not None:
+        # the caller's own host tensor (with_host_sizes does not copy it): valid while nobody wrote into it
+        if _version(alias[0]) == alias[1]:
+            return alias[0]
+        token_sizes.__dict__['_rua_memo'].pop('host_alias', None)
+    return _memo_put(token_sizes, 'host', _read_back(token_sizes))
 
 
-def attach_host(token_sizes: Tensor, host: Tensor) -> None:
-    _memo_put(token_sizes, 'host', host)
+def _read_back(t: Tensor) -> Tensor:
+    """Blocking D2H of a small vector into PINNED memory: no staging through a pageable bounce buffer, and no fresh
+    pageable allocation per call (on this platform freeing one can stall the GPU queues: an munmap runs the driver's
+    MMU notifier — measured 90 ms every few steps at the north-star size).  torch's caching host allocator hands the
+    same pinned blocks out again once their copy is complete, which it is when this returns."""
+    src = t.detach()
+    if not src.is_contiguous():
+        src = src.contiguous()
+    out = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+    out.copy_(src, non_blocking=True)
+    torch.cuda.current_stream(src.device).synchronize()
+    return out
+
+
+def attach_host(token_sizes: Tensor, host: Tensor, alias: bool = False) -> None:
+    """Record the host copy of a device length vector.  alias=True: `host` belongs to the caller and is only
+    borrowed, guarded by its version counter (a later in-place write sends host_lens() back to the device copy)."""
+    if alias:
+        _memo_put(token_sizes, 'host_alias', (host, _version(host)))
+    else:
+        _memo_put(token_sizes, 'host', host)
 
 
 def max_len(token_sizes: Tensor) -> int:
@@ -190,7 +216,7 @@ def adopt_pack(p, lens: Tensor, boff: Tensor, bsz_dev: Tensor) -> None:
     # plain-data memos: `lens` itself memoises this very batch_sizes (core._pack_meta), and batch_sizes pointing
     # back at it would close a reference cycle per pack() — cyclic garbage that forces full GC passes.
     alias = lens.detach()
-    for key in ('host', 'max', 'sum', 'off'):
+    for key in ('host', 'host_alias', 'max', 'sum', 'off'):
         hit = _memo_get(lens, key)
         if hit is not None:
             _memo_put(alias, key, hit)
@@ -199,13 +225,95 @@ def adopt_pack(p, lens: Tensor, boff: Tensor, bsz_dev: Tensor) -> None:
 
 def batch_sizes_from_host_lens(h: Tensor, T: int) -> Tensor:
     """batch_sizes[t] = #{b: len[b] > t} as the CPU int64 tensor PackedSequence mandates
-    (reference core/view.py:55: get_mask(self).sum(dim=0).cpu())."""
-    B = h.numel()
-    if T == 0:
-        return torch.zeros(0, dtype=torch.long)
+    (reference core/view.py:55: get_mask(self).sum(dim=0).cpu()) — a histogram and a running sum on the host
+    (rua_host_batch_sizes), T * 8 bytes of fresh host memory per call."""
+    out = torch.empty(T, dtype=torch.long)
+    if T:
+        h = _as_lens(h)
+        L.check(L.load().rua_host_batch_sizes(h.data_ptr(), h.numel(), T, out.data_ptr()), 'rua_host_batch_sizes')
+    return out
+
+
+# ------------------------------------------------------------------ the reference's host sort (core/view.py:48)
+_host_sort_threads: Optional[int] = None      # None: not decided yet; 0: torch.sort; n >= 1: rua_host_sort_desc
+
+
+def _selftest_inputs():
+    g = torch.Generator().manual_seed(20261004)
+    for n in (1, 2, 3, 16, 17, 18, 31, 33, 100, 1000, 4097, 9000, 40000):
+        for hi in (1, 3, 500, 1 << 40):
+            yield torch.randint(0, hi + 1, (n,), generator=g)
+    n = 5000
+    up = torch.arange(n)
+    yield up
+    yield up.flip(0)
+    yield torch.zeros(n, dtype=torch.long)
+    yield torch.cat([up[:n // 2], up[:n // 2].flip(0)])          # organ pipe
+    yield (up * 7919) % 13                                       # few distinct values, periodic
+    yield torch.cat([torch.zeros(n // 2, dtype=torch.long), torch.ones(n // 2, dtype=torch.long)])
+
+
+def _host_sort_decide() -> int:
+    """Pick how sorted_indices is computed on the host, once per process.
+
+    RUA_HOST_SORT=torch keeps the reference's own call; RUA_HOST_SORT=<n> fixes the thread count.  Otherwise the
+    library's reproduction of that sort (rua_host.cpp) is used IF it returns exactly torch.sort's permutation on a
+    battery of inputs (tie-heavy, sorted, reversed, constant, organ-pipe, sizes around the 16-element leaf) —
+    a mismatch (another C++ runtime behind torch, say) silently keeps the reference's call.  The thread count is the
+    fastest of {1, 2, 4, 8} on a 64 Ki-element sample, so a host that serialises threads is not made slower."""
+    env = os.environ.get('RUA_HOST_SORT', '').strip().lower()
+    if env == 'torch':
+        return 0
+    lib = L.load()
+
+    def ours(keys: Tensor, threads: int) -> Tensor:
+        out = torch.empty_like(keys)
+        L.check(lib.rua_host_sort_desc(keys.data_ptr(), keys.numel(), out.data_ptr(), threads), 'rua_host_sort_desc')
+        return out
+
     with host_serial():
-        cnt = torch.bincount(h, minlength=T + 1)
-        return B - torch.cumsum(cnt, 0)[:T]
+        for keys in _selftest_inputs():
+            ref = torch.sort(keys, descending=True)[1]
+            for threads in (1, 3):
+                if not torch.equal(ours(keys, threads), ref):
+                    return 0
+        if env.isdigit() and int(env) >= 1:
+            return min(int(env), 64)
+        cpus = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        sample = torch.randint(8, 513, (65536,), generator=torch.Generator().manual_seed(1))
+        best, best_t = 1, None
+        for threads in (1, 2, 4, 8):
+            if threads > max(1, cpus):
+                break
+            ours(sample, threads)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                ours(sample, threads)
+            dt = time.perf_counter() - t0
+            if best_t is None or dt < 0.9 * best_t:
+                best, best_t = threads, dt
+        return best
+
+
+def host_sort_desc(host: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """sorted_indices = torch.sort(host, descending=True)[1] (core/view.py:48) — the same permutation, tie order
+    included — into `out` if given (e.g. a pinned staging slot)."""
+    global _host_sort_threads
+    if _host_sort_threads is None:
+        _host_sort_threads = _host_sort_decide()
+    host = _as_lens(host.detach())
+    if _host_sort_threads == 0:
+        with host_serial():
+            index = torch.sort(host, descending=True)[1]
+        if out is None:
+            return index
+        out.copy_(index)
+        return out
+    if out is None:
+        out = torch.empty(host.shape, dtype=torch.long)
+    L.check(L.load().rua_host_sort_desc(host.data_ptr(), host.numel(), out.data_ptr(), _host_sort_threads),
+            'rua_host_sort_desc')
+    return out
 
 
 # ------------------------------------------------------------------ rua_layout descriptors
@@ -216,7 +324,8 @@ def known_max_len(token_sizes: Optional[Tensor]) -> Optional[int]:
     hit = _memo_get(token_sizes, 'max')
     if hit is not None:
         return hit
-    if not token_sizes.is_cuda or _memo_get(token_sizes, 'host') is not None:
+    if not token_sizes.is_cuda or _memo_get(token_sizes, 'host') is not None or \
+            _memo_get(token_sizes, 'host_alias') is not None:
         return max_len(token_sizes)
     return None
 
@@ -331,22 +440,29 @@ class _StagingRing:
         self.i = 0
         self.side = None      # the upload stream of this device
 
-    def upload(self, host: Tensor, dev: torch.device) -> Tensor:
+    def reserve(self, shape, dtype: torch.dtype) -> Tuple[int, Tensor]:
+        """Claim the next slot and return (slot, pinned tensor of `shape`) for the caller to fill."""
         i = self.i
         self.i = (i + 1) % self.SLOTS
         if self.events[i] is not None:
             self.events[i].synchronize()
-        nbytes = host.numel() * host.element_size()
+            self.events[i] = None
+        n = 1
+        for d in shape:
+            n *= d
+        nbytes = n * dtype.itemsize
         buf = self.bufs[i]
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, pin_memory=True)
             self.bufs[i] = buf
-        staged = buf[:nbytes].view(host.dtype).view(host.shape)
-        staged.copy_(host)
+        return i, buf[:nbytes].view(dtype).view(shape)
+
+    def commit(self, i: int, staged: Tensor, dev: torch.device) -> Tensor:
+        """Enqueue the H2D of a slot filled through reserve()."""
         cur = torch.cuda.current_stream(dev)
         ev = torch.cuda.Event()
-        if host.numel() < self.SIDE_MIN_ELEMS or torch.cuda.is_current_stream_capturing():
-            out = torch.empty(host.shape, dtype=host.dtype, device=dev)
+        if staged.numel() < self.SIDE_MIN_ELEMS or torch.cuda.is_current_stream_capturing():
+            out = torch.empty(staged.shape, dtype=staged.dtype, device=dev)
             out.copy_(staged, non_blocking=True)
             ev.record(cur)
         else:
@@ -365,7 +481,7 @@ class _StagingRing:
             # runs twice per pack())
             torch.cuda.set_stream(side)
             try:
-                out = torch.empty(host.shape, dtype=host.dtype, device=dev)
+                out = torch.empty(staged.shape, dtype=staged.dtype, device=dev)
                 out.copy_(staged, non_blocking=True)
                 ev.record(side)
             finally:
@@ -375,8 +491,20 @@ class _StagingRing:
         self.events[i] = ev
         return out
 
+    def upload(self, host: Tensor, dev: torch.device) -> Tensor:
+        i, staged = self.reserve(host.shape, host.dtype)
+        staged.copy_(host)
+        return self.commit(i, staged, dev)
+
 
 _rings = {}
+
+
+def _ring(dev: torch.device) -> _StagingRing:
+    ring = _rings.get(dev)
+    if ring is None:
+        ring = _rings[dev] = _StagingRing()
+    return ring
 
 
 def to_device_async(host: Tensor, dev: torch.device) -> Tensor:
@@ -384,11 +512,19 @@ def to_device_async(host: Tensor, dev: torch.device) -> Tensor:
     for it) without blocking the host."""
     if dev.type != 'cuda' or host.numel() == 0 or not host.is_contiguous():
         return host.to(dev)
-    ring = _rings.get(dev)
-    if ring is None:
-        ring = _rings[dev] = _StagingRing()
     with host_serial():
-        return ring.upload(host, dev)
+        return _ring(dev).upload(host, dev)
+
+
+def sorted_indices_to_device(host_lens_: Tensor, dev: torch.device) -> Tensor:
+    """The reference's host sort (core/view.py:48), written straight into a pinned staging slot and uploaded."""
+    n = host_lens_.numel()
+    if dev.type != 'cuda' or n == 0:
+        return host_sort_desc(host_lens_).to(dev)
+    ring = _ring(dev)
+    i, staged = ring.reserve((n,), torch.long)
+    host_sort_desc(host_lens_, out=staged)
+    return ring.commit(i, staged, dev)
 
 
 def lay_list(bptr: Optional[Tensor], tptr: Tensor) -> Lay:

@@ -24,8 +24,7 @@ __all__ = ['compose']
 def _interleaved(counts: List[int]) -> np.ndarray:
     """Position j of the composed batch -> index of that sequence in container-major numbering."""
     counts_t = torch.tensor(counts, dtype=torch.long)
-    with M.host_serial():                      # the order pack() gives containers: its own host sort, same tie order
-        rank = torch.sort(counts_t, descending=True)[1].numpy()
+    rank = M.host_sort_desc(counts_t).numpy()  # the order pack() gives containers: its own host sort, same tie order
     first = np.concatenate(([0], np.cumsum(counts)[:-1]))
     step = np.arange(max(counts))[:, None]                             # [steps, 1]
     grid = first[rank][None, :] + step                                 # sequence `step` of container rank[k]

@@ -60,16 +60,6 @@ def _padded_view(cls):
     return view
 
 
-def _sorted_indices(token_sizes: Tensor) -> Tuple[Tensor, Tensor]:
-    """The reference's order: a HOST torch.sort(descending=True) on the lengths (core/view.py:48).
-    Its tie order is implementation-defined, so bit-exact parity means making the identical call
-    (SURVEY.md §8a note).  Returns (host lengths, sorted_indices on the host)."""
-    host = M.host_lens(token_sizes)
-    with M.host_serial():
-        _, index = torch.sort(host.detach(), descending=True)
-    return host, index
-
-
 def _pack_meta(token_sizes: Tensor, dev: torch.device):
     """sorted/unsorted indices (device), batch_sizes (CPU, as PackedSequence mandates), and the
     device-side boff — K3 + K1.  One host sort, no B x T mask (core/view.py:47-58)."""
@@ -81,10 +71,14 @@ def _pack_meta(token_sizes: Tensor, dev: torch.device):
     hit = M._memo_get(token_sizes, key)
     if hit is not None and all(M._version(t) == v for t, v in zip(hit[0], hit[1])):
         return (lens,) + hit[0]
-    host, index = _sorted_indices(token_sizes)
+    # The reference's order: a HOST sort of the lengths, descending (core/view.py:48).  Its tie order is
+    # implementation-defined, so bit-exact parity means reproducing that very call (SURVEY.md §8a note;
+    # _meta.host_sort_desc).  With device-only lengths the GPU idles from the read-back until the mover below is
+    # launched, so nothing else sits between the two.
+    host = M.host_lens(token_sizes)
     B = lens.numel()
+    sorted_indices = M.sorted_indices_to_device(host, dev)
     T = M.max_len(token_sizes)
-    sorted_indices = M.to_device_async(index, dev)
     batch_sizes = M.batch_sizes_from_host_lens(host, T)
     # one call for everything derived on the device; the internal vectors share one allocation:
     # batch_sizes [T] | their offsets [T] | offsets of the lengths [B] | scan scratch
@@ -334,9 +328,11 @@ R.new = staticmethod(lambda tensors, fill_value=0: _new_cat(tensors).right(fill_
 
 def with_host_sizes(data: Tensor, token_sizes_host: Tensor) -> C:
     """C(data, token_sizes) from lengths that live on the host (what C.new does for a list)."""
-    # a private copy (B * 8 bytes): the mirror outlives this call, and a loader that reuses its length buffer must
-    # not be able to change what later pack()/size() calls sort and size from
-    host = token_sizes_host.to(dtype=torch.long, device='cpu', copy=True)
+    host = token_sizes_host.to(dtype=torch.long, device='cpu')
     dev_sizes = M.to_device_async(host, data.device)
-    M.attach_host(dev_sizes, host)
+    # The mirror outlives this call.  When `host` is the caller's own tensor it is borrowed, not copied, and guarded
+    # by its version counter: a loader that reuses its length buffer (an in-place write) invalidates the mirror and
+    # later pack()/size() calls read the lengths back from the device copy instead.  (A private copy per call would
+    # be a fresh 512 KiB host allocation per step at the north-star size; see _meta._read_back for what that costs.)
+    M.attach_host(dev_sizes, host, alias=host is token_sizes_host)
     return C(data=data, token_sizes=dev_sizes)
