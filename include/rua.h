@@ -85,6 +85,12 @@ enum rua_tmap {
                                them to the rows computed from `src` layout (core/set.py)        */
 #define RUA_MOVE_NT_ON   2  /* force / forbid non-temporal payload accesses; default: on when the   */
 #define RUA_MOVE_NT_OFF  4  /* destination is >= 512 MiB (cannot stay in the 256 MiB Infinity Cache) */
+/* launch geometry of the mover (default: ~16 KiB of destination rows per workgroup, one contiguous span of tiles
+ * per XCD on big launches; these override it, for A/B runs):
+ * bits 4-7 = log2 of the destination rows one workgroup takes (2..8 -> 4..256 rows), */
+#define RUA_MOVE_TILE_LOG2(k) (((k) & 0xf) << 4)
+#define RUA_MOVE_XCD_SPAN_ON  256  /* every XCD takes ONE contiguous span of tiles (blockIdx % 8 picks the span) */
+#define RUA_MOVE_XCD_SPAN_OFF 512  /* tiles in plain blockIdx order                                             */
 
 /* K1. Exclusive prefix sum of n int64 (wavefront scan).  out[i] = sum(in[0..i)).
  * `ws` must hold rua_scan_ws_elems(n) int64.  If total != NULL, *total (device) = sum(in).

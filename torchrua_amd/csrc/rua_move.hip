@@ -23,10 +23,11 @@ namespace rua {
 #define RUA_MOVE_UNROLL 4
 #endif
 constexpr int MOVE_BLOCK = RUA_MOVE_BLOCK;          // threads per workgroup of the generic mover
-constexpr int MOVE_WAVES = MOVE_BLOCK / RUA_WAVE;
 constexpr int MOVE_TILE = MOVE_BLOCK;               // one lane per row in phase 1
 constexpr int TILE_ROWS = 256;                      // the (rank x time) tile of pack_tile_kernel: 16 x 16
 constexpr int UNROLL = RUA_MOVE_UNROLL;             // row groups in flight per wave in phase 2
+constexpr int64_t MOVE_TILE_BYTES = 16 << 10;       // destination bytes one workgroup takes (rows: a power of two, 4..256)
+constexpr int64_t MOVE_SPAN_MIN_TILES = 2048;       // launches at least this large give every XCD one contiguous span
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -58,25 +59,69 @@ template <typename V, bool NT> __device__ __forceinline__ void st_row(char* p, V
   else *reinterpret_cast<V*>(p) = v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Phase 1 of a small tile is a latency chain, not work: a plain binary search of `boff` / `off` is 9-17 DEPENDENT
+// L2 loads (3-6 us) in front of ~2.5 us of payload traffic, and the workgroup's bytes are not in flight meanwhile.
+// Here the wave searches TOGETHER: 64 samples per step (a 64-ary search: 2 dependent loads for T <= 1 024, 3 for
+// B <= 65 536), and the last step is a contiguous 64-entry window from which every row of the wave reads its own
+// answer (consecutive rows resolve to the same or the next few entries).
+//   f        non-decreasing over [0, n_total), f(0) <= j0
+//   returns  for lane i < nw: k = largest index with f(k) <= j0 + i, fk = f(k); false = the window ran out for
+//            this lane (more than ~48 boundaries inside the wave's rows: runs of zero-length sequences) -> the
+//            caller falls back to its own binary search.  ALL 64 lanes must call.
+template <typename F>
+__device__ __forceinline__ bool coop_resolve(F f, int64_t n_total, int64_t j0, int nw, int lane, int64_t& k,
+                                             int64_t& fk) {
+  constexpr int64_t BIG = 0x7fffffffffffffffLL;
+  int64_t lo = 0, n = n_total;
+  while (n > 16) {                                   // wave-uniform
+    const int64_t step = (n + 63) >> 6;
+    const int64_t at = (int64_t)lane * step;
+    const int64_t v = at < n ? f(lo + at) : BIG;
+    int c = __popcll(__ballot(v <= j0));
+    if (c < 1) c = 1;
+    const int64_t adv = (int64_t)(c - 1) * step;
+    lo += adv;
+    n = (n - adv) < step ? (n - adv) : step;
+  }
+  const int64_t W = (lo + lane < n_total) ? f(lo + lane) : BIG;      // the window: f(lo .. lo + 63)
+  int mine = 0;
+  for (int i = 0; i < nw; ++i) {                     // wave-uniform; nw <= 64
+    const int c = __popcll(__ballot(W <= j0 + i));
+    if (lane == i) mine = c;
+  }
+  if (mine < 1) mine = 1;
+  k = lo + mine - 1;
+  fk = __shfl(W, mine - 1, RUA_WAVE);
+  return !(mine == RUA_WAVE && lo + RUA_WAVE < n_total);
+}
+
 // lpr      : lanes (VEC-byte columns) per row = ceil(row_bytes / VEC)
 // lp_log2  : log2 of lanes a wave gives one row per instruction (<= 6); rows narrower than
 //            1 KiB share a wave instruction (64 >> lp_log2 rows at a time)
 // cpr      : 64-lane column chunks per row (1 unless row_bytes > 64*VEC)
 // RPT      : destination rows per lane in phase 1 (1; 4 = the narrow-row variant of roll / rev inside one
 //            PackedSequence, see below)
-template <int VEC, bool SCATTER, bool NT, int RPT = 1>
-__global__ __launch_bounds__(MOVE_BLOCK) void move_rows_kernel(rua_layout D, rua_layout S, int32_t tmap,
+// TROWS    : destination rows per workgroup tile (<= MOVE_BLOCK; RPT == 1).  Small tiles in launch order make the
+//            chip sweep the destination almost sequentially (see tile_of below and DESIGN.md §4).
+// tiles_per_xcd > 0: workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8); give every XCD ONE contiguous
+//            span of tiles_per_xcd tiles instead of every eighth tile.
+template <int VEC, bool SCATTER, bool NT, int RPT = 1, int TROWS = MOVE_TILE, int BLOCK = MOVE_BLOCK, int UNR = UNROLL>
+__global__ __launch_bounds__(BLOCK) void move_rows_kernel(rua_layout D, rua_layout S, int32_t tmap,
                                                               int64_t targ, char* __restrict__ dst,
                                                               const char* __restrict__ src, int64_t row_bytes,
                                                               int64_t lpr, int lp_log2, int cpr, uint4 fillpat,
-                                                              int64_t pad_row) {
+                                                              int64_t pad_row, int64_t tiles_per_xcd) {
   using V = typename vec_of<VEC>::type;
-  constexpr int TILE = MOVE_TILE * RPT;
+  constexpr int TILE = TROWS * RPT;
   __shared__ int64_t s_ld[TILE];
   __shared__ int64_t s_st[TILE];
 
-  const int64_t tile0 = (int64_t)blockIdx.x * TILE;
+  int64_t tile = blockIdx.x;
+  if (tiles_per_xcd > 0) tile = (int64_t)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+  const int64_t tile0 = tile * TILE;
   const int64_t left = D.n_rows - tile0;
+  if (left <= 0 || (tiles_per_xcd > 0 && (int64_t)(blockIdx.x >> 3) >= tiles_per_xcd)) return;
   const int nrows = left < TILE ? (int)left : TILE;
 
   // ---- phase 1: one lane per destination row
@@ -90,7 +135,7 @@ __global__ __launch_bounds__(MOVE_BLOCK) void move_rows_kernel(rua_layout D, rua
     // for the same latency.
     int64_t j[RPT], lo[RPT], hi[RPT], t[RPT], r[RPT];
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) { j[k] = tile0 + threadIdx.x + k * MOVE_BLOCK; lo[k] = 0; hi[k] = D.T; }
+    for (int k = 0; k < RPT; ++k) { j[k] = tile0 + threadIdx.x + k * BLOCK; lo[k] = 0; hi[k] = D.T; }
     for (int64_t span = D.T; span > 1; span = (span + 1) >> 1) {     // largest t with boff[t] <= j
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
@@ -113,7 +158,7 @@ __global__ __launch_bounds__(MOVE_BLOCK) void move_rows_kernel(rua_layout D, rua
     }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-      const int i = threadIdx.x + k * MOVE_BLOCK;
+      const int i = threadIdx.x + k * BLOCK;
       if (i < nrows) {
         const int64_t len = lo[k];
         const int64_t ts = apply_tmap(tmap, targ, t[k], len, len);
@@ -125,40 +170,68 @@ __global__ __launch_bounds__(MOVE_BLOCK) void move_rows_kernel(rua_layout D, rua
       }
     }
   } else {
+    // every wave resolves the (up to) 64 tile rows that sit in its lanes
     const int i = threadIdx.x;
-    if (i < nrows) {
+    const int lane1 = threadIdx.x & (RUA_WAVE - 1);
+    const int w0 = i - lane1;                                     // first tile row of this wave
+    const int nw = nrows - w0 < RUA_WAVE ? nrows - w0 : RUA_WAVE; // rows in this wave (<= 0: none)
+    if (nw > 0) {                                                 // wave-uniform
       const int64_t j = tile0 + i;
-      int64_t b, t, other = -1;
-      if (same_pack) {
-        // roll / rev inside ONE PackedSequence: the rank r of a row is its own source rank, and its length is
-        // #{t : bsz[t] > r} — a search in the (L1-resident) batch_sizes instead of two random gathers per row
-        t = search_boff(D.boff, D.T, j);
-        const int64_t r = j - D.boff[t];
-        int64_t lo = 0, hi = D.T;
-        while (lo < hi) {
-          const int64_t mid = (lo + hi) >> 1;
-          if (D.bsz[mid] > r) lo = mid + 1; else hi = mid;
+      const bool mine = i < nrows;
+      int64_t b = 0, t = 0, other = -1;
+      bool token = false;
+      bool resolved = false;
+      bool done = false;
+      if (D.kind == RUA_PACK && D.T > 0 && D.boff) {
+        int64_t bt;
+        const bool ok = coop_resolve([&](int64_t k) { return D.boff[k]; }, D.T, tile0 + w0, nw, lane1, t, bt);
+        if (mine && ok) {
+          resolved = true;
+          const int64_t r = j - bt;
+          if (same_pack) {
+            // roll / rev inside ONE PackedSequence: the rank r of a row is its own source rank, and its length is
+            // #{t : bsz[t] > r} — a search in the (L1-resident) batch_sizes instead of two random gathers per row
+            int64_t lo = 0, hi = D.T;
+            while (lo < hi) {
+              const int64_t mid = (lo + hi) >> 1;
+              if (D.bsz[mid] > r) lo = mid + 1; else hi = mid;
+            }
+            const int64_t len = lo;
+            const int64_t ts = apply_tmap(tmap, targ, t, len, len);
+            if (ts >= 0 && ts < len) other = S.boff[ts] + r;
+            if (other >= S.n_rows) other = -1;
+            s_ld[i] = other;
+            s_st[i] = j;
+            done = true;
+          } else if (r >= 0 && r < D.B) {
+            b = D.sorted ? D.sorted[r] : r;
+            token = b >= 0 && b < D.B;
+          }
         }
-        const int64_t len = lo;
-        const int64_t ts = apply_tmap(tmap, targ, t, len, len);
-        if (ts >= 0 && ts < len) other = S.boff[ts] + r;
-        if (other >= S.n_rows) other = -1;
-      } else if (row_to_token(D, j, b, t)) {
-        // caller-supplied (batch_ptr, token_ptr) pairs are range-checked: a bad pair yields the fill /
-        // is skipped instead of faulting the GPU (the reference raises an IndexError there)
-        if (D.kind == RUA_LIST && (b < 0 || b >= S.B)) { b = 0; t = -1; }
-        const int64_t slen = seq_len(S, b);
-        const int64_t dlen = D.kind == RUA_LIST ? slen : seq_len(D, b);
-        const int64_t ts = apply_tmap(tmap, targ, t, slen, dlen);
-        if (ts >= 0 && ts < slen) other = token_to_row(S, b, ts, slen);
-        // metadata that does not match the storage (lengths summing past the payload, a corrupt
-        // PackedSequence) must not become an out-of-bounds access: such rows read as padding
-        if (other >= S.n_rows) other = -1;
-      } else {
-        other = pad_row;  // padding row: fill (-1) or a copy of one fixed source row
+      } else if (D.kind == RUA_CAT && D.off && D.B > 0) {
+        int64_t ob;
+        const bool ok = coop_resolve([&](int64_t k) { return cat_off(D, k); }, D.B, tile0 + w0, nw, lane1, b, ob);
+        if (mine && ok) { resolved = true; token = true; t = j - ob; }
       }
-      if (SCATTER) { s_ld[i] = j; s_st[i] = other; }   // enumerated rows are the source
-      else         { s_ld[i] = other; s_st[i] = j; }   // enumerated rows are the destination
+      if (mine && !done) {
+        if (!resolved) token = row_to_token(D, j, b, t);
+        if (token) {
+          // caller-supplied (batch_ptr, token_ptr) pairs are range-checked: a bad pair yields the fill /
+          // is skipped instead of faulting the GPU (the reference raises an IndexError there)
+          if (D.kind == RUA_LIST && (b < 0 || b >= S.B)) { b = 0; t = -1; }
+          const int64_t slen = seq_len(S, b);
+          const int64_t dlen = D.kind == RUA_LIST ? slen : seq_len(D, b);
+          const int64_t ts = apply_tmap(tmap, targ, t, slen, dlen);
+          if (ts >= 0 && ts < slen) other = token_to_row(S, b, ts, slen);
+          // metadata that does not match the storage (lengths summing past the payload, a corrupt
+          // PackedSequence) must not become an out-of-bounds access: such rows read as padding
+          if (other >= S.n_rows) other = -1;
+        } else {
+          other = pad_row;  // padding row: fill (-1) or a copy of one fixed source row
+        }
+        if (SCATTER) { s_ld[i] = j; s_st[i] = other; }   // enumerated rows are the source
+        else         { s_ld[i] = other; s_st[i] = j; }   // enumerated rows are the destination
+      }
     }
   }
   __syncthreads();
@@ -170,15 +243,15 @@ __global__ __launch_bounds__(MOVE_BLOCK) void move_rows_kernel(rua_layout D, rua
   const int64_t col0 = lane & ((1 << lp_log2) - 1);
   const V fillv = fill_of<VEC>(fillpat);
 
-  for (int g0 = wave; g0 * rpw < nrows; g0 += MOVE_WAVES * UNROLL) {
+  for (int g0 = wave; g0 * rpw < nrows; g0 += (BLOCK / RUA_WAVE) * UNR) {
     for (int c = 0; c < cpr; ++c) {
       const int64_t col = col0 + (int64_t)c * RUA_WAVE;
       const bool colok = col < lpr;
-      V val[UNROLL];
-      int64_t st[UNROLL];
+      V val[UNR];
+      int64_t st[UNR];
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        const int r = (g0 + u * MOVE_WAVES) * rpw + rsub;
+      for (int u = 0; u < UNR; ++u) {
+        const int r = (g0 + u * (BLOCK / RUA_WAVE)) * rpw + rsub;
         st[u] = -1;
         val[u] = fillv;
         if (colok && r < nrows) {
@@ -188,7 +261,7 @@ __global__ __launch_bounds__(MOVE_BLOCK) void move_rows_kernel(rua_layout D, rua
         }
       }
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u)
+      for (int u = 0; u < UNR; ++u)
         if (st[u] >= 0) st_row<V, NT>(dst + st[u] * row_bytes + col * VEC, val[u]);
     }
   }
@@ -375,30 +448,54 @@ static int check_layout(const rua_layout* L, bool is_dst) {
 constexpr int NARROW_RPT = 4;
 
 template <bool SCATTER, bool NT>
-static int launch_move(int vec, unsigned grid, hipStream_t s, const rua_layout& D, const rua_layout& S, int32_t tmap,
+static int launch_move(int vec, int64_t n_rows, hipStream_t s, const rua_layout& D, const rua_layout& S, int32_t tmap,
                        int64_t targ, char* dst, const char* src, int64_t row_bytes, uint4 fp, int64_t pad_row,
-                       bool narrow_same_pack = false) {
+                       bool narrow_same_pack, int tile_rows, bool xcd_span) {
   const int64_t lpr = (row_bytes + vec - 1) / vec;
   int lp_log2 = 0;
   while ((1 << lp_log2) < lpr && lp_log2 < 6) ++lp_log2;
   const int cpr = (int)((lpr + RUA_WAVE - 1) / RUA_WAVE);
-  const dim3 g(grid), b(MOVE_BLOCK);
+  const dim3 b(MOVE_BLOCK);
   if (narrow_same_pack) {   // vec == 16, gather: see move_rows_kernel<..., RPT>
-    const dim3 gn((grid + NARROW_RPT - 1) / NARROW_RPT);
-    hipLaunchKernelGGL((move_rows_kernel<16, false, NT, NARROW_RPT>), gn, b, 0, s, D, S, tmap, targ, dst, src, row_bytes,
-                       lpr, lp_log2, cpr, fp, pad_row);
+    const int64_t nt4 = (n_rows + MOVE_TILE * NARROW_RPT - 1) / (MOVE_TILE * NARROW_RPT);
+    hipLaunchKernelGGL((move_rows_kernel<16, false, NT, NARROW_RPT>), dim3((unsigned)nt4), b, 0, s, D, S, tmap, targ, dst,
+                       src, row_bytes, lpr, lp_log2, cpr, fp, pad_row, (int64_t)0);
     return (int)hipGetLastError();
   }
-#define RUA_LAUNCH(VEC) \
-  hipLaunchKernelGGL((move_rows_kernel<VEC, SCATTER, NT>), g, b, 0, s, D, S, tmap, targ, dst, src, row_bytes, lpr, lp_log2, cpr, fp, pad_row)
+  const int64_t ntiles = (n_rows + tile_rows - 1) / tile_rows;
+  const int64_t per_xcd = xcd_span ? (ntiles + 7) / 8 : 0;
+  const int64_t grid = xcd_span ? per_xcd * 8 : ntiles;
+  if (grid > 0x7fffffffLL) return RUA_ERANGE;
+  const dim3 g((unsigned)grid);
+#define RUA_LAUNCH_T(VEC, TR) \
+  hipLaunchKernelGGL((move_rows_kernel<VEC, SCATTER, NT, 1, TR>), g, b, 0, s, D, S, tmap, targ, dst, src, row_bytes, lpr, lp_log2, cpr, fp, pad_row, per_xcd)
+  // 16-byte rows get every tile size; the narrower vector widths (odd row sizes) a coarser choice
+#define RUA_LAUNCH16()                         \
+  switch (tile_rows) {                         \
+    case 4: RUA_LAUNCH_T(16, 4); break;        \
+    case 8: RUA_LAUNCH_T(16, 8); break;        \
+    case 16: RUA_LAUNCH_T(16, 16); break;      \
+    case 32: RUA_LAUNCH_T(16, 32); break;      \
+    case 64: RUA_LAUNCH_T(16, 64); break;      \
+    case 128: RUA_LAUNCH_T(16, 128); break;    \
+    default: RUA_LAUNCH_T(16, MOVE_TILE); break; \
+  }
+#define RUA_LAUNCH(VEC)                        \
+  switch (tile_rows) {                         \
+    case 16: RUA_LAUNCH_T(VEC, 16); break;     \
+    case 64: RUA_LAUNCH_T(VEC, 64); break;     \
+    default: RUA_LAUNCH_T(VEC, MOVE_TILE); break; \
+  }
   switch (vec) {
-    case 16: RUA_LAUNCH(16); break;
+    case 16: RUA_LAUNCH16(); break;
     case 8:  RUA_LAUNCH(8); break;
     case 4:  RUA_LAUNCH(4); break;
     case 2:  RUA_LAUNCH(2); break;
     default: RUA_LAUNCH(1); break;
   }
 #undef RUA_LAUNCH
+#undef RUA_LAUNCH16
+#undef RUA_LAUNCH_T
   return (int)hipGetLastError();
 }
 
@@ -416,8 +513,6 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
   if (dst->n_rows == 0 || row_bytes == 0) return 0;
   if (!dst_data || !src_data) return RUA_EINVAL;
   if (pad_row < -1 || pad_row >= src->n_rows) return RUA_EINVAL;
-  const int64_t ntiles = (dst->n_rows + MOVE_TILE - 1) / MOVE_TILE;
-  if (ntiles > 0x7fffffffLL) return RUA_ERANGE;
 
   // widest power-of-two access that divides the row size and both base addresses
   const uint64_t mix = (uint64_t)row_bytes | (uint64_t)(uintptr_t)dst_data | (uint64_t)(uintptr_t)src_data | 16u;
@@ -443,14 +538,28 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
   const bool nt = (flags & RUA_MOVE_NT_ON) ? true : (flags & RUA_MOVE_NT_OFF) ? false : big;
   char* d = (char*)dst_data;
   const char* c = (const char*)src_data;
-  const unsigned g = (unsigned)ntiles;
+  // Launch geometry (profiles/r02_copy_probe.txt, r02_mover_geometry.txt): HBM rewards a launch whose
+  // in-flight addresses form a small window sweeping the destination in order, so a workgroup takes only ~16 KiB
+  // of destination rows (workgroups are dispatched in blockIdx order), and on big launches every XCD sweeps ONE
+  // contiguous span of the destination instead of every eighth tile.  At the north-star shape (1 KiB rows):
+  // 256-row tiles 5.6 TB/s -> 16-row tiles 6.15 TB/s for C->P, 5.3 -> 6.1 for P->C.
+  int tile_rows = MOVE_TILE;
+  for (int64_t tb = MOVE_TILE * row_bytes; tile_rows > 4 && tb > MOVE_TILE_BYTES; tb >>= 1) tile_rows >>= 1;
+  const int tsel = (flags >> 4) & 0xf;               // developer override: RUA_MOVE_TILE_LOG2 / RUA_MOVE_XCD_SPAN_*
+  if (tsel >= 2 && tsel <= 8) tile_rows = 1 << tsel;
+  if (tile_rows > MOVE_BLOCK) tile_rows = MOVE_BLOCK;
+  if (vec != 16) tile_rows = tile_rows <= 16 ? 16 : tile_rows <= 64 ? 64 : MOVE_TILE;
+  const int64_t nr = dst->n_rows;
+  bool xcd_span = (nr + tile_rows - 1) / tile_rows >= MOVE_SPAN_MIN_TILES;
+  if (flags & RUA_MOVE_XCD_SPAN_ON) xcd_span = true;
+  if (flags & RUA_MOVE_XCD_SPAN_OFF) xcd_span = false;
   if (flags & RUA_MOVE_SCATTER)
-    return nt ? launch_move<true, true>(vec, g, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row)
-              : launch_move<true, false>(vec, g, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row);
+    return nt ? launch_move<true, true>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, false, tile_rows, xcd_span)
+              : launch_move<true, false>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, false, tile_rows, xcd_span);
   // roll / rev inside ONE PackedSequence with rows of at most 32 B (3.1 -> 3.9 TB/s; no gain at 64 B): RPT rows per lane (the kernel's `same_pack` test)
   const bool narrow_same_pack = vec == 16 && row_bytes <= 32 && dst->kind == RUA_PACK && src->kind == RUA_PACK &&
                                 dst->bsz && dst->boff && dst->boff == src->boff && dst->sorted == src->sorted &&
                                 dst->len_add == 0 && src->len_add == 0 && dst->T == src->T && dst->T > 0;
-  return nt ? launch_move<false, true>(vec, g, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, narrow_same_pack)
-            : launch_move<false, false>(vec, g, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, narrow_same_pack);
+  return nt ? launch_move<false, true>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, narrow_same_pack, tile_rows, xcd_span)
+            : launch_move<false, false>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, narrow_same_pack, tile_rows, xcd_span);
 }
