@@ -1,6 +1,4 @@
 set -e
-python -m pytest tests -x -q -m gpu 2>&1 | tail -4
-python scripts/width_sweep.py > gpurun_out/width_sweep.txt 2>&1
-cat gpurun_out/width_sweep.txt
-python scripts/bench_configs.py > gpurun_out/configs.txt 2>&1
-cat gpurun_out/configs.txt
+python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+python scripts/split_probe.py 2>&1 | grep -E "GB|split=None|split=0"
+python scripts/skew_probe.py 2>&1 | tail -12

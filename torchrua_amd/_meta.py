@@ -558,6 +558,7 @@ ENOUGH_UNITS = 4096          # (sequence, column chunk) units that keep every SI
 WAVE_RATE = 4e9              # bytes/s ONE wave streams (8 KiB in flight / ~2 us; profiles/r01_skew.txt)
 STREAM_RATE = 5e12           # bytes/s the whole chip reads through the reducer
 SPLIT_FIXED_S = 30e-6        # what arming costs: one memset, a tail and a combine launch
+TEAM_MAX_UNITS = 16384       # rua_reduce_impl.h: units up to which a team of waves may share one unit
 
 
 def reduce_split_rows(lay: Lay, row_bytes: int = 1024) -> int:
@@ -574,8 +575,19 @@ def reduce_split_rows(lay: Lay, row_bytes: int = 1024) -> int:
     n = lay.n_rows
     rb_unit = max(1, min(int(row_bytes), 1024))        # wider rows: 4 KiB per wave, 4x the loads in flight
     n_chunks = -(-int(row_bytes) // (1024 if row_bytes <= 1024 else 4096)) if row_bytes > 0 else 1
-    ideal_rows = int(0.75 * n * row_bytes / STREAM_RATE * WAVE_RATE / rb_unit)   # rows a wave walks in 3/4 of the balanced time
-    fixed_rows = int(SPLIT_FIXED_S * WAVE_RATE / rb_unit)
+    # few-but-long units are shared by a TEAM of 2 or 4 waves (seg_reduce_team_kernel; the same rule as the C side:
+    # rows up to 1 KiB on the vector path, at most 16 384 units, >= 4 row groups per wave): a unit then streams
+    # 2-4x as fast, and splitting — three launches and a pass over fp32 partials — is for real outliers only
+    team = 1
+    units = max(lay.B, 1) * n_chunks
+    if 0 < row_bytes <= 1024 and row_bytes % 16 == 0 and units <= TEAM_MAX_UNITS:
+        lanes = -(-int(row_bytes) // 16)
+        rows_per_group = max(1, 64 // (1 << max(0, (lanes - 1).bit_length()))) * 8
+        groups = n // max(lay.B, 1) // rows_per_group
+        team = 4 if groups >= 16 else 2 if groups >= 8 else 1
+    wave_rate = WAVE_RATE * team
+    ideal_rows = int(0.75 * n * row_bytes / STREAM_RATE * wave_rate / rb_unit)   # rows a unit walks in 3/4 of the balanced time
+    fixed_rows = int(SPLIT_FIXED_S * wave_rate / rb_unit)
     part_min = max(SPLIT_MIN_ROWS, SPLIT_MIN_BYTES // rb_unit)
     part = max(part_min, min(SPLIT_ROWS, n // FILL_WAVES))
     if max(lay.B, 1) * n_chunks >= ENOUGH_UNITS:

@@ -187,7 +187,7 @@ template <typename T, int EPL, int OP, bool NT, bool COPY, int CPW = 1, bool RAN
 __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, int64_t t_hi,
                                           const T* __restrict__ data, int64_t H,
                                           Fold<typename elem<T>::acc, EPL * CPW>& f, const rua_layout& CD,
-                                          T* __restrict__ copy, int lane) {
+                                          T* __restrict__ copy, int lane, int team_w = 0, int team_n = 1) {
   using A = typename elem<T>::acc;
   constexpr int UT = CPW == 1 ? UNROLL_T : UNROLL_T / 2;     // rows in flight (x CPW loads each)
   constexpr int CW = RUA_WAVE * EPL;                          // elements per 64-lane column chunk
@@ -209,6 +209,8 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
     const int64_t cv_next = (COPY && nxt < t_hi) ? CD.boff[nxt] : 0;
     const int nblk = (t_hi - tblk) < RUA_WAVE ? (int)(t_hi - tblk) : RUA_WAVE;
     for (int k = 0; k < nblk; k += (RANKS ? 1 : rpw) * UT) {
+      // a team of waves shares one sequence (seg_reduce_team_kernel): wave w takes every team_n-th row group
+      if (team_n > 1 && (int)(((tblk - t_lo) / ((RANKS ? 1 : rpw) * UT) + k / ((RANKS ? 1 : rpw) * UT)) % team_n) != team_w) continue;
       int64_t row[UT];
       int64_t crow[UT];
       Pack p[UT][CPW];
@@ -544,6 +546,47 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
     fold_store<T, EPL, OP, CPW>(U, f, out, H, include_self, empty_val, (A*)W.ties);
   }
   fold_flags<A, NE, OP>(f, extreme, lane, U.len <= 0);
+}
+
+// Few but long sequences (units <= the wave slots of the chip, hundreds of rows each): with one wave per sequence
+// everything starts at once, the short sequences leave early and the long ones finish on a half-empty chip.  Here a
+// TEAM of waves (one workgroup) shares each (sequence, column chunk): wave w folds every TEAM-th group of rows —
+// at any moment the team reads one contiguous run — the partials meet in LDS and wave 0 merges them in wave order
+// (a fixed association: bitwise reproducible).  TEAM = blockDim.x / 64 (2 or 4).
+constexpr int TEAM_MAX = 4;
+constexpr int64_t TEAM_MAX_UNITS = 16384;   // beyond this one wave per unit keeps the chip balanced by itself
+template <typename T, int EPL, int OP, bool NT>
+__global__ __launch_bounds__(RUA_WAVE * TEAM_MAX) void seg_reduce_team_kernel(
+    rua_layout L, const int64_t* __restrict__ perm, const T* __restrict__ data, T* __restrict__ out, int64_t H,
+    int lp_log2, int64_t n_chunks, int include_self, T empty_val, unsigned long long* __restrict__ extreme,
+    typename elem<T>::acc* __restrict__ ties) {
+  using A = typename elem<T>::acc;
+  __shared__ A s_acc[TEAM_MAX][RUA_WAVE * EPL];
+  __shared__ A s_aux[TEAM_MAX][RUA_WAVE * EPL];
+  const int lane = threadIdx.x & (RUA_WAVE - 1), wave = threadIdx.x >> 6, team = blockDim.x >> 6;
+  const int64_t wid = blockIdx.x;
+  const int64_t q = wid / n_chunks;
+  if (q >= L.B) return;                                   // block-uniform
+  const Unit<T, EPL> U = make_unit<T, EPL, false, 1>(L, L, perm, q, wid - q * n_chunks, H, lp_log2, lane);
+  Fold<A, EPL> f;
+  fold_init<A, EPL, OP>(f);
+  fold_rows<T, EPL, OP, NT, false, 1>(U, 0, U.len, data, H, f, L, nullptr, lane, wave, team);
+  fold_wave<A, EPL, OP>(f, lp_log2);
+  fold_flags<A, EPL, OP>(f, extreme, lane, wave == 0 && U.len <= 0);
+  if (wave > 0) {
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) { s_acc[wave][lane * EPL + k] = f.acc[k]; s_aux[wave][lane * EPL + k] = f.aux[k]; }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    for (int w = 1; w < team; ++w) {
+      A a2[EPL], x2[EPL];
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) { a2[k] = s_acc[w][lane * EPL + k]; x2[k] = s_aux[w][lane * EPL + k]; }
+      fold_merge<A, EPL, OP>(f, a2, x2);
+    }
+    fold_store<T, EPL, OP, 1>(U, f, out, H, include_self, empty_val, ties);
+  }
 }
 
 // reduce over a PackedSequence with narrow rows: adjacent ranks side by side (see make_unit)
@@ -1148,6 +1191,36 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
 #undef RUA_RANKS_OP
 #undef RUA_RANKS
     return (int)hipGetLastError();
+  }
+  // few-but-long units: a team of waves per unit (seg_reduce_team_kernel) — vector path, rows up to 1 KiB, no split
+  if (vec_ok && !wide && !copy && !(split > 0 && ws) && blocks > 0 && blocks <= TEAM_MAX_UNITS) {
+    const int64_t rows_per_group = (int64_t)(RUA_WAVE >> lp_log2) * UNROLL_T;
+    const int64_t groups = L.n_rows / (L.B > 0 ? L.B : 1) / rows_per_group;       // row groups of an average unit
+    const int team = groups >= 4 * 4 ? 4 : groups >= 4 * 2 ? 2 : 1;
+    if (team > 1) {
+      T ev;
+      __builtin_memcpy(&ev, &empty_bits, sizeof(T));
+      const dim3 gg((unsigned)blocks), bb(RUA_WAVE * team);
+      unsigned long long* ext = (unsigned long long*)extreme;
+      using A = typename elem<T>::acc;
+#define RUA_TEAM(NTV, OPV)                                                                                           \
+  hipLaunchKernelGGL((seg_reduce_team_kernel<T, FULL, OPV, NTV>), gg, bb, 0, s, L, perm, (const T*)data, (T*)out, H, \
+                     lp_log2, n_chunks, include_self, ev, ext, (A*)ties)
+#define RUA_TEAM_OP(NTV)                                                                           \
+  switch (op) {                                                                                    \
+    case RUA_SUM: RUA_TEAM(NTV, RUA_SUM); break;                                                   \
+    case RUA_MEAN: RUA_TEAM(NTV, RUA_MEAN); break;                                                 \
+    case RUA_MAX: if (ties) RUA_TEAM(NTV, RUA_MAX_T); else RUA_TEAM(NTV, RUA_MAX); break;          \
+    case RUA_MIN: if (ties) RUA_TEAM(NTV, RUA_MIN_T); else RUA_TEAM(NTV, RUA_MIN); break;          \
+    case RUA_PROD: RUA_TEAM(NTV, RUA_PROD); break;                                                 \
+    case RUA_LOGSUMEXP: RUA_TEAM(NTV, RUA_LOGSUMEXP); break;                                       \
+    default: return RUA_EINVAL;                                                                    \
+  }
+      if (nt) { RUA_TEAM_OP(true) } else { RUA_TEAM_OP(false) }
+#undef RUA_TEAM_OP
+#undef RUA_TEAM
+      return (int)hipGetLastError();
+    }
   }
 #define RUA_GO(EPLV, NTV, COPYV, CPWV)                                                                             \
   return launch_reduce<T, EPLV, NTV, COPYV, CPWV>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self, \
