@@ -289,5 +289,47 @@ def main():
     print('wrote', len(store), 'arrays;', os.path.getsize(os.path.join(OUT, 'small.npz')), 'bytes')
 
 
+def extra():
+    """Round-2 additions (tests/golden/extra.npz; small.npz is left byte-for-byte as it was): the sizes SURVEY.md
+    §8c(ii) asked for beyond B = 200 — a tie-heavy batch of 1 000 sequences, 512-wide reductions, sequences of
+    512-1 024 rows — and a batch with zero-length sequences through pack()."""
+    global store
+    store = {}
+    rng = np.random.RandomState(20)
+    layout_case('layout.b1000ties', rng.randint(1, 5, 1000), 2, torch.float32, seed=400)
+    layout_case('layout.b120wide', rng.randint(1, 40, 120), 1, torch.float32, seed=401)
+    reduce_case('reduce.h512', rng.randint(1, 32, 12), 512, seed=402)
+    reduce_case('reduce.long', rng.randint(512, 1025, 6), 8, seed=403)
+    zl = rng.randint(0, 3, 1000)
+    zl[0] = 2
+    reduce_case('reduce.b1000zero', zl, 3, seed=404, zero_len=True)
+    # zero-length sequences through pack() (core/cast.py:41-49 handles them; P -> anything raises in the reference)
+    for name, lens, H in (('empty.a', [0, 3, 0, 2], 4), ('empty.b', [2, 0, 0, 5, 1, 0], 40), ('empty.c', [0, 0, 4], 1)):
+        g = torch.Generator().manual_seed(len(lens))
+        data = torch.randn((sum(lens), H), generator=g)
+        c = C(data, torch.tensor(lens))
+        put(name, 'lens', np.asarray(lens, dtype=np.int64))
+        put(name, 'data', data)
+        put_seq(name, 'pack', c.pack())
+        put_seq(name, 'left', c.left(FILL))
+        put_seq(name, 'right', c.right(FILL))
+        put_seq(name, 'left.pack', c.left(FILL).pack())
+        put_seq(name, 'right.pack', c.right(FILL).pack())
+        for op in ('max', 'sum', 'logsumexp'):
+            put(name, f'segment_{op}', getattr(ref, f'segment_{op}')(data, torch.tensor(lens)))
+    np.savez_compressed(os.path.join(OUT, 'extra.npz'), **store)
+    meta_path = os.path.join(OUT, 'META.json')
+    meta = json.load(open(meta_path))
+    meta['extra_n_arrays'] = len(store)
+    meta['extra_reference_raised'] = [x for x in skipped if x.split('/')[0] in ('layout.b1000ties', 'layout.b120wide')]
+    with open(meta_path, 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print('wrote', len(store), 'extra arrays;', os.path.getsize(os.path.join(OUT, 'extra.npz')), 'bytes')
+
+
 if __name__ == '__main__':
-    main()
+    if '--extra' in sys.argv:
+        extra()
+    else:
+        main()
+        extra()

@@ -167,3 +167,50 @@ def test_with_host_sizes_keeps_its_own_copy():
     assert p.batch_sizes.tolist() == [4, 3, 2, 1]
     assert torch.equal(p.data, expect.data) and torch.equal(p.sorted_indices, expect.sorted_indices)
     assert c.size()[:2] == (4, 4)
+
+
+# ------------------------------------------------------------------ row gathers: index dtypes, deterministic adjoint
+def test_gather_with_narrow_int_and_bool_keys():
+    data = torch.randn(12, 6, device=DEV)
+    c = ta.C(data, torch.tensor([5, 3, 4], device=DEV))
+    idx = torch.tensor([[3, 0], [11, 3]], device=DEV)
+    ref = data[idx]
+    for dt in (torch.long, torch.int32, torch.int16):
+        assert torch.equal(c[idx.to(dt)], ref)
+    mask = torch.zeros(12, dtype=torch.bool, device=DEV)
+    mask[[1, 4, 9]] = True
+    assert torch.equal(c[mask], data[mask])
+    buf = data.clone()
+    cc = ta.C(buf, c.token_sizes)
+    cc[idx.int()] = 7.0
+    ref2 = data.clone()
+    ref2[idx] = 7.0
+    assert torch.equal(buf, ref2)
+
+
+@pytest.mark.parametrize('kind', ['C', 'L', 'P', 'R'])
+def test_gather_backward_is_a_deterministic_scatter_sum(kind):
+    """X[batch_ptr, token_ptr] with repeated pairs: the adjoint sums the repeats (torch: index_add_) — here through the
+    bucketed reducer, bit-identical from run to run."""
+    g = torch.Generator().manual_seed(7)
+    lens = [4, 1, 6, 3]
+    xs = [torch.randn(n, 5, generator=g) for n in lens]
+    bp = torch.tensor([2, 0, 2, 2, 3, 0, 2], device=DEV)
+    tp = torch.tensor([5, 3, 5, 0, 1, 3, 5], device=DEV)
+    w = torch.randn(7, 5, generator=g).to(DEV)
+    grads = []
+    for _ in range(2):
+        c = ta.C.new([x.to(DEV) for x in xs])
+        z = {'C': c, 'L': c.left(), 'P': c.pack(), 'R': c.right()}[kind]
+        leaf = z.data.detach().clone().requires_grad_()
+        z = z._replace(data=leaf)
+        (z[bp, tp] * w).sum().backward()
+        grads.append(leaf.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    # expectation from the catted form: token (b, t) gets the sum of the weights of the pairs that name it
+    exp = torch.zeros(sum(lens), 5, device=DEV)
+    off = torch.tensor([0, 4, 5, 11], device=DEV)
+    exp.index_add_(0, off[bp] + tp, w)
+    back = {'C': lambda d: d, 'L': lambda d: ta.L(d, c.token_sizes).cat().data, 'R': lambda d: ta.R(d, c.token_sizes).cat().data,
+            'P': lambda d: c.pack()._replace(data=d).cat().data}[kind](grads[0])
+    torch.testing.assert_close(back, exp, rtol=1e-6, atol=1e-6)

@@ -101,19 +101,27 @@ class _ListGather(torch.autograd.Function):
     """X[batch_ptr, token_ptr] (core/get.py tuple keys): rows may repeat, so the adjoint accumulates."""
 
     @staticmethod
-    def forward(ctx, src_data: Tensor, plan: MovePlan, flat_fn):
+    def forward(ctx, src_data: Tensor, plan: MovePlan, flat_fn, lead: int = 1):
         ctx.flat_fn = flat_fn
         ctx.src_shape = tuple(src_data.shape)
+        ctx.lead = lead                 # leading dims of src_data that enumerate storage rows (2 for [B, T, *H])
         return launch_move(plan, src_data)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad: Tensor):
-        flat = ctx.flat_fn()
-        g = torch.zeros(ctx.src_shape, dtype=grad.dtype, device=grad.device)
-        lead = len(ctx.src_shape) - (grad.dim() - 1)
-        g.flatten(0, lead - 1).index_add_(0, flat, grad.contiguous()) if lead > 1 else g.index_add_(0, flat, grad)
-        return g, None, None
+        """d/d src = the rows of `grad` summed into the storage rows they were gathered from.  Rows may repeat, so this
+        is a scatter-sum: bucket the flat row numbers (stable radix sort, rua_index_buckets) and fold every bucket in
+        ascending entry order with the segmented reducer — no float atomics, bitwise reproducible (torch's index_add_
+        is neither)."""
+        flat = ctx.flat_fn().reshape(-1)
+        grad = grad.contiguous()
+        hidden = tuple(ctx.src_shape[ctx.lead:])
+        n_rows = 1
+        for d in ctx.src_shape[:ctx.lead]:
+            n_rows *= d
+        g = scatter_sum_rows(grad.reshape((flat.numel(),) + hidden), flat, n_rows)
+        return g.reshape(ctx.src_shape), None, None, None
 
 
 # ------------------------------------------------------------------ reductions
@@ -209,3 +217,32 @@ def reduce(data: Tensor, lay: M.Lay, op: int, hidden, lens: Optional[Tensor]) ->
     if data.requires_grad and torch.is_grad_enabled():
         return _Reduce.apply(data, lay, op, tuple(hidden), lens)
     return launch_reduce(lay, data.detach() if data.requires_grad else data, op, hidden=tuple(hidden))
+
+
+# ------------------------------------------------------------------ scatter-sum of rows (adjoint of a row gather)
+def index_buckets(index: Tensor, S: int) -> Tuple[Tensor, Tensor]:
+    """(counts[S], perm[M]): the entries of `index` bucketed by destination, every bucket in ascending entry order
+    (rua_index_buckets: a stable LSD radix sort, deterministic for any fan-in)."""
+    dev = L.require_device(index)
+    lib = L.load()
+    index = M._as_lens(index)
+    m = index.numel()
+    counts = torch.empty(S, dtype=torch.long, device=dev)
+    off = torch.empty(S, dtype=torch.long, device=dev)
+    perm = torch.empty(m, dtype=torch.long, device=dev)
+    ws = torch.empty(lib.rua_bucket_ws_elems(m, S), dtype=torch.long, device=dev)
+    L.check(lib.rua_index_buckets(L.ptr(index), m, S, L.ptr(counts), L.ptr(off), L.ptr(perm), L.ptr(ws),
+                                  L.stream_ptr(dev)), 'rua_index_buckets')
+    M._memo_put(counts, 'off', off)
+    return counts, perm
+
+
+def scatter_sum_rows(rows: Tensor, index: Tensor, n_out: int) -> Tensor:
+    """out[s] = sum of rows[i] over the entries i with index[i] == s, s < n_out (rows nobody names are 0)."""
+    hidden = tuple(rows.shape[1:])
+    if rows.dtype not in L.DTYPES:        # integer payloads have no gradient; kept for completeness
+        out = torch.zeros((n_out,) + hidden, dtype=rows.dtype, device=rows.device)
+        return out.index_add_(0, index, rows)
+    counts, perm = index_buckets(index, n_out)
+    lay = M.lay_cat(counts, n_out, int(rows.size(0)))
+    return launch_reduce(lay, rows, L.SUM, perm=perm, hidden=hidden, reference_initial=False, name='scatter')

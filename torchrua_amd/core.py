@@ -202,10 +202,25 @@ def _flat_rows(z: Z, key: Tuple[Tensor, Tensor]) -> Tensor:
     return O.launch_move(O.MovePlan(M.lay_list(*key), describe(z), (key[0].numel(),), name='flat_rows'), iota)
 
 
+def _row_index(index: Tensor, n_rows: int):
+    """An index tensor as int64 row numbers, or None when it is not a plain row index.  Narrower integer types are
+    widened (an index-sized cast; the payload still moves through the row mover); a 1-D bool / uint8 mask over the
+    rows selects the rows where it is set, like torch (the count is data-dependent: one sync, as in torch)."""
+    if index.dtype == torch.long:
+        return index
+    if index.dtype in (torch.int32, torch.int16, torch.int8):
+        return index.to(torch.long)
+    if index.dtype in (torch.bool, torch.uint8) and index.dim() == 1 and index.numel() == n_rows:
+        return torch.nonzero(index).reshape(-1)
+    return None
+
+
 def _gather_flat(raw: Tensor, index: Tensor) -> Tensor:
-    """raw[index] for an int64 row index of any shape (core/get.py:29,42,61,74) via the mover."""
-    if index.dtype != torch.long:
-        return raw[index]   # bool masks etc.: not a row-index gather
+    """raw[index] for a row index of any shape (core/get.py:29,42,61,74) via the mover."""
+    rows = _row_index(index, int(raw.size(0)))
+    if rows is None:
+        return raw[index]   # multi-dimensional masks etc.: not a row-index gather
+    index = rows
     flat = index.reshape(-1)
     shape = tuple(index.shape) + tuple(raw.shape[1:])
     plan = O.MovePlan(M.lay_list(None, flat), M.lay_flat(int(raw.size(0))), shape, name='gather_flat')
@@ -216,9 +231,11 @@ def _gather_flat(raw: Tensor, index: Tensor) -> Tensor:
 
 def _scatter_flat(raw: Tensor, index: Tensor, value) -> None:
     """raw[index] = value (core/set.py:30,45,67,82) via the mover in scatter mode."""
-    if index.dtype != torch.long or not raw.is_contiguous():
+    rows = _row_index(index, int(raw.size(0)))
+    if rows is None or not raw.is_contiguous():
         raw[index] = value
         return
+    index = rows
     flat = index.reshape(-1)
     value = torch.as_tensor(value, dtype=raw.dtype, device=raw.device)
     value = value.expand(tuple(index.shape) + tuple(raw.shape[1:])).contiguous()
@@ -239,7 +256,7 @@ def _getitem(cls):
             plan = O.MovePlan(M.lay_list(bp.reshape(-1), tp.reshape(-1)), describe(self), shape, name='getitem')
             if self.data.requires_grad and torch.is_grad_enabled():
                 k = (bp.reshape(-1), tp.reshape(-1))
-                return O._ListGather.apply(self.data, plan, lambda: _flat_rows(self, k))
+                return O._ListGather.apply(self.data, plan, lambda: _flat_rows(self, k), len(self.data.shape) - len(_hidden(self)))
             return O.launch_move(plan, self.data)
         if isinstance(key, Tensor):
             return _gather_flat(self.raw(), key)

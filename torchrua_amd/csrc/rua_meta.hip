@@ -237,13 +237,39 @@ __global__ __launch_bounds__(RUA_BLOCK) void enum_rows_kernel(rua_layout L, int6
 }
 
 // ------------------------------------------------------------------ masks
+// One lane writes 16 bytes (EPV elements) of the flat [B, T] grid: ONE integer division per 16-byte store locates
+// the first element, the rest walk along the row (and into the next one where a vector straddles a row end).
+// The B x T int64 grid of get_mask is 256 MiB at the north-star shape: a pure store stream.
 template <typename E>
 __global__ __launch_bounds__(RUA_BLOCK) void mask_kernel(const int64_t* __restrict__ lens, int64_t B, int64_t T,
-                                                         E* __restrict__ out, E zero, E one) {
-  const int64_t i = (int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x;
-  if (i >= B * T) return;
-  const int64_t b = i / T, t = i - b * T;
-  out[i] = t < lens[b] ? one : zero;
+                                                         E* __restrict__ out, E zero, E one, int64_t n,
+                                                         int64_t head) {
+  constexpr int EPV = 16 / sizeof(E);
+  struct alignas(16) Vec { E v[EPV]; };
+  // elements [0, head) in front of the first 16-byte boundary and the tail behind the last one go one by one
+  const int64_t nvec = (n - head) / EPV;
+  const int64_t k = (int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x;
+  if (k < nvec) {
+    const int64_t e0 = head + k * EPV;
+    int64_t b = e0 / T, t = e0 - b * T;
+    int64_t len = lens[b];
+    Vec v;
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) {
+      v.v[i] = t < len ? one : zero;
+      if (++t == T) { t = 0; ++b; len = b < B ? lens[b] : 0; }
+    }
+    *reinterpret_cast<Vec*>(out + e0) = v;
+  } else {
+    // the few unaligned elements: element `head - 1 - j` for j < head, then the tail
+    const int64_t j = k - nvec;
+    const int64_t tail0 = head + nvec * EPV;
+    const int64_t e = j < head ? j : tail0 + (j - head);
+    if (e < n) {
+      const int64_t b = e / T, t = e - b * T;
+      out[e] = t < lens[b] ? one : zero;
+    }
+  }
 }
 
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + RUA_BLOCK - 1) / RUA_BLOCK); }
@@ -339,14 +365,27 @@ int rua_mask(const int64_t* lens, int64_t B, int64_t T, void* out, int32_t elem_
   if (n == 0) return 0;
   if (!lens || !out) return RUA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const dim3 g(grid_for(n)), blk(RUA_BLOCK);
+  const dim3 blk(RUA_BLOCK);
+#define RUA_MASK(E)                                                                                             \
+  {                                                                                                             \
+    constexpr int64_t EPV = 16 / sizeof(E);                                                                      \
+    int64_t head = (int64_t)((16 - ((uintptr_t)out & 15)) & 15) / (int64_t)sizeof(E);                            \
+    if (((uintptr_t)out % sizeof(E)) != 0) return RUA_EALIGN;                                                    \
+    if (head > n) head = n;                                                                                      \
+    const int64_t nvec = (n - head) / EPV;                                                                       \
+    const int64_t threads = nvec + head + (n - head - nvec * EPV);                                               \
+    if ((threads + RUA_BLOCK - 1) / RUA_BLOCK > 0x7fffffffLL) return RUA_ERANGE;                                 \
+    hipLaunchKernelGGL(mask_kernel<E>, dim3(grid_for(threads)), blk, 0, s, lens, B, T, (E*)out, (E)zero_bits,    \
+                       (E)one_bits, n, head);                                                                    \
+  }
   switch (elem_bytes) {
-    case 1: hipLaunchKernelGGL(mask_kernel<uint8_t>, g, blk, 0, s, lens, B, T, (uint8_t*)out, (uint8_t)zero_bits, (uint8_t)one_bits); break;
-    case 2: hipLaunchKernelGGL(mask_kernel<uint16_t>, g, blk, 0, s, lens, B, T, (uint16_t*)out, (uint16_t)zero_bits, (uint16_t)one_bits); break;
-    case 4: hipLaunchKernelGGL(mask_kernel<uint32_t>, g, blk, 0, s, lens, B, T, (uint32_t*)out, (uint32_t)zero_bits, (uint32_t)one_bits); break;
-    case 8: hipLaunchKernelGGL(mask_kernel<uint64_t>, g, blk, 0, s, lens, B, T, (uint64_t*)out, (uint64_t)zero_bits, (uint64_t)one_bits); break;
+    case 1: RUA_MASK(uint8_t); break;
+    case 2: RUA_MASK(uint16_t); break;
+    case 4: RUA_MASK(uint32_t); break;
+    case 8: RUA_MASK(uint64_t); break;
     default: return RUA_EINVAL;
   }
+#undef RUA_MASK
   return (int)hipGetLastError();
 }
 

@@ -105,19 +105,7 @@ def reduce_logsumexp(sequence: Z) -> T:
 
 
 # ------------------------------------------------------------------ scatter_* (reduce.py:6-31)
-def _buckets(index: T, S: int):
-    dev = K.require_device(index)
-    lib = K.load()
-    index = M._as_lens(index)
-    m = index.numel()
-    counts = torch.empty(S, dtype=torch.long, device=dev)
-    off = torch.empty(S, dtype=torch.long, device=dev)
-    perm = torch.empty(m, dtype=torch.long, device=dev)
-    ws = torch.empty(lib.rua_bucket_ws_elems(m, S), dtype=torch.long, device=dev)
-    K.check(lib.rua_index_buckets(K.ptr(index), m, S, K.ptr(counts), K.ptr(off), K.ptr(perm), K.ptr(ws),
-                                  K.stream_ptr(dev)), 'rua_index_buckets')
-    M._memo_put(counts, 'off', off)
-    return counts, perm
+_buckets = O.index_buckets
 
 
 class _Scatter(torch.autograd.Function):
