@@ -146,6 +146,33 @@ def self_launch(args):
     raise SystemExit(rc)
 
 
+def cpu_baseline_torch(args):
+    """The library-independent calls the reference's own tests use as oracles, on this box's host cores
+    (SURVEY.md §8d (2)(i)): torch.nn.utils.rnn.pack_sequence(enforce_sorted=False) — tests/expected.py:21-22 —
+    then torch.segment_reduce(x.float(), 'sum', lengths) — reduce.py:44-45; fp32 because ATen's CPU kernel
+    accumulates bf16 sequentially in bf16.  Same bounded sample as the port."""
+    from torch.nn.utils.rnn import pack_sequence
+    B = args.cpu_sample
+    g = torch.Generator().manual_seed(5)
+    lens = torch.randint(args.lo, args.hi + 1, (B,), generator=g)
+    n = int(lens.sum())
+    data = torch.randn((n, args.hidden), generator=g).to(torch.bfloat16)
+    xs = list(torch.split(data, lens.tolist()))              # views: the list form pack_sequence takes
+    threads = torch.get_num_threads()
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        p = pack_sequence(xs, enforce_sorted=False)
+        out = torch.segment_reduce(data.float(), 'sum', lengths=lens, unsafe=True)
+        times.append(time.perf_counter() - t0)
+    assert p.data.shape == data.shape and out.shape == (B, args.hidden)
+    t = sorted(times)[len(times) // 2]
+    return {'value': round(n * args.hidden / t / 1e6, 1), 'unit': 'M elements/s', 'cores': threads, 'kind': 'stock torch',
+            'sample': f'{B} sequences len~U({args.lo},{args.hi}) hidden={args.hidden} bf16 ({n} rows), '
+                      f'pack_sequence(enforce_sorted=False) + segment_reduce(x.float(), sum), torch intra-op threads = '
+                      f'{threads}, median of 3, {t:.2f} s each'}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
@@ -290,11 +317,16 @@ def main():
         pack_bytes = 2.0 * N * H * e + 8.0 * (3 * B + T)
         reduce_bytes = 1.0 * N * H * e + 1.0 * B * H * e + 8.0 * B
         achieved = pack_bytes / (move_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+        # HBM bytes per launch from the PMC counters are NOT measured by this run (rocprofv3 --pmc needs its own
+        # passes): the figure is carried from the committed profile of this same command and shape, with its source
+        # named beside it, and is null for any other shape
+        traffic, traffic_source = None, None
+        tpath = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
         if os.path.exists(tpath) and (B, H, args.lo, args.hi) == (65536, 512, 8, 512):
             with open(tpath) as f:
-                traffic = json.load(f).get('to_pack_hbm_bytes_per_launch')
+                tj = json.load(f)
+            traffic = tj.get('to_pack_hbm_bytes_per_launch')
+            traffic_source = f"profiles/r02_traffic.json ({tj.get('collected', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes')})"
         line = {
             'metric': f'pack->reduce throughput, {B} seqs/GPU h={H} bf16 (M elements/s) + % HBM roofline',
             'value': round(value, 1), 'unit': 'M elements/s', 'n_gpus': world, 'steps': args.steps,
@@ -310,9 +342,9 @@ def main():
                           'pack_kernel_GBps': round((2.0 * row[0] * H * e + 8.0 * (3 * B + T)) / (row[2] * 1e-3) / 1e9, 1) if row[2] else None,
                           'reduce_kernel_GBps': round((row[0] * H * e + 1.0 * B * H * e + 8.0 * B) / (row[3] * 1e-3) / 1e9, 1) if row[3] else None}
                          for r, row in enumerate(per_rank)],
-            'roofline': {'bound': 'hbm', 'kernel': 'move_rows_kernel<16,false,NT> (C->P pack)',
+            'roofline': {'bound': 'hbm', 'kernel': 'move_rows_kernel<16,false,NT,1,16,256,4> (C->P pack, 16-row tiles)',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_source,
                          'algorithmic_bytes': pack_bytes, 'avg_ms': round(move_ms, 4)},
             'reduce_kernel': {'kernel': 'seg_reduce_kernel<bf16,8,SUM,NT> (over P)', 'avg_ms': round(red_ms, 4),
                               'achieved': round(reduce_bytes / (red_ms * 1e-3) / 1e9, 1), 'unit': 'GB/s',
@@ -325,6 +357,7 @@ def main():
         line.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args)
+            line['cpu_baseline_torch'] = cpu_baseline_torch(args)
         print(json.dumps(line), flush=True)
 
     if use_dist:

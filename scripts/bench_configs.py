@@ -83,6 +83,18 @@ def main():
     lft = c.left()
     timeit('l.cat()   (unpad)', lambda: lft.cat(), 2 * N * H * e)
     timeit('l.pack()', lambda: lft.pack(), 2 * N * H * e)
+    # ---- the integer kernels at the same shape (bytes = what they write; all int64 like the reference's)
+    from torchrua_amd import _ops as O
+    timeit('c.ptr()  (batch_ptr, token_ptr)', lambda: c.ptr(), 2 * N * 8)
+    timeit('p.ptr()', lambda: p.ptr(), 2 * N * 8)
+    timeit('c.idx()', lambda: c.idx(), N * 8)
+    timeit('l.idx()  (flat index of a padded batch)', lambda: lft.idx(), N * 8)
+    timeit('get_mask(c)  [B, T] int64', lambda: ta.get_mask(c), B * T * 8)
+    timeit('c.bmask()    [B, T] bool', lambda: c.bmask(), B * T)
+    bp = c.ptr()[0]
+    shuffled = bp[torch.randperm(N, device=dev)]
+    timeit('index_buckets (17 M keys, 65 536 destinations)', lambda: O.index_buckets(shuffled, B), 2 * N * 8)
+    del bp, shuffled
     del lft, p, c, data
 
     import gc
@@ -100,6 +112,10 @@ def main():
     timeit('p.last()', lambda: p.last(), 2 * B * H * e)
     timeit('p.head(16) (view)', lambda: p.head(16), 1)
     timeit('p.rev()', lambda: p.rev(), 2 * N * H * e, iters=5)
+    T4 = int(lens.max())
+    timeit('p.ptr()      (cfg4)', lambda: p.ptr(), 2 * N * 8, iters=5)
+    timeit('p.idx()      (cfg4)', lambda: p.idx(), N * 8, iters=5)
+    timeit('get_mask(p)  (cfg4) [B, T] int64', lambda: ta.get_mask(p), B * T4 * 8, iters=5)
 
 
 if __name__ == '__main__':

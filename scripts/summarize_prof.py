@@ -16,6 +16,7 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, 'gpurun_out')
+PRE = os.environ.get('PROF_PREFIX', 'prof_')      # gpurun_out/<PRE>stats, <PRE>fetch, <PRE>write
 P = os.path.join(ROOT, 'profiles')
 os.makedirs(P, exist_ok=True)
 
@@ -28,12 +29,12 @@ def short(name):
 def kernel_stats():
     """Per-kernel stats from `rocprofv3 --kernel-trace --stats`: the CSV when the run wrote one, else the rocpd
     SQLite database (ROCm 7.2's default output format)."""
-    files = glob.glob(os.path.join(G, 'prof_stats', '*', '*_kernel_stats.csv'))
+    files = glob.glob(os.path.join(G, PRE + 'stats', '**', '*_kernel_stats.csv'), recursive=True)
     if files:
         return [(r['Name'], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs'])
                 for r in csv.DictReader(open(files[0]))]
     import sqlite3
-    con = sqlite3.connect(glob.glob(os.path.join(G, 'prof_stats', '*', '*_results.db'))[0])
+    con = sqlite3.connect(glob.glob(os.path.join(G, PRE + 'stats', '**', '*_results.db'), recursive=True)[0])
     total = con.execute('select sum(duration) from kernels').fetchone()[0]
     q = ('select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels '
          'group by name order by sum(duration) desc')
@@ -41,10 +42,10 @@ def kernel_stats():
 
 
 def counter_rows(kind):
-    files = glob.glob(os.path.join(G, f'prof_{kind}', '*', '*_counter_collection.csv'))
+    files = glob.glob(os.path.join(G, f'{PRE}{kind}', '**', '*_counter_collection.csv'), recursive=True)
     if files:
         return [(r['Kernel_Name'], r['Counter_Name'], float(r['Counter_Value'])) for r in csv.DictReader(open(files[0]))]
-    dbs = glob.glob(os.path.join(G, f'prof_{kind}', '*', '*_results.db'))
+    dbs = glob.glob(os.path.join(G, f'{PRE}{kind}', '**', '*_results.db'), recursive=True)
     if not dbs:
         return []
     import sqlite3
@@ -82,8 +83,11 @@ with open(os.path.join(P, f'{tag}_pmc.json'), 'w') as f:
 move = [v for k, v in out['kernels'].items() if 'move_rows_kernel<16, false' in k]
 if move:
     with open(os.path.join(P, f'{tag}_traffic.json'), 'w') as f:
+        import datetime
         json.dump({'to_pack_hbm_bytes_per_launch': move[0]['hbm_bytes_per_launch'],
-                   'source': f'profiles/{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 corrections)'},
+                   'collected': f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `bench.py --no-cpu-baseline`, '
+                                f'gfx950 corrections per MI355X_MICROARCH.md, summarised {datetime.date.today().isoformat()}',
+                   'source': f'profiles/{tag}_pmc.json'},
                   f, indent=1)
 print(open(os.path.join(P, f'{tag}_kernel_stats.csv')).read()[:1500])
 print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != 'raw'} for k, v in out['kernels'].items()}, indent=1)[:2000])

@@ -101,7 +101,11 @@ def test_reducer_split_policy():
     assert M.reduce_split_rows(ns, 1024) == 0
     assert M.reduce_split_rows(FakeLay(34_000_000, 65536, 1024), 2048) == 0    # cfg4
     assert M.reduce_split_rows(FakeLay(1_070_000, 4096, 512), 512) == 0        # cfg2: LPT hides 512-row sequences
-    assert M.reduce_split_rows(FakeLay(133_000, 512, 512), 1024) == 64         # few units: fill the chip
+    # few units: a team of 4 waves per unit (rows up to 1 KiB on the vector path) fills the chip without the three
+    # launches of the split; rows the team kernel does not take (wider than 1 KiB, odd widths) are still cut
+    assert M.reduce_split_rows(FakeLay(133_000, 512, 512), 1024) == 0
+    assert M.reduce_split_rows(FakeLay(133_000, 512, 512), 2048) == 64
+    assert M.reduce_split_rows(FakeLay(133_000, 512, 512), 1000) == 65
     assert M.reduce_split_rows(FakeLay(533_000, 2048, 512), 128) == 0          # narrow rows: the longest walk is 16 us
     assert 64 <= M.reduce_split_rows(FakeLay(1_131_008, 2048, 1_000_000), 1024) <= 256   # one giant sequence
     assert M.reduce_split_rows(FakeLay(100_000_000, 64, 5_000_000), 1024) == 4096

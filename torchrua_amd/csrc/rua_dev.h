@@ -102,4 +102,48 @@ __device__ __forceinline__ int64_t apply_tmap(int32_t tmap, int64_t arg, int64_t
   return -1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Resolving a run of consecutive storage rows is a latency chain, not work: a plain binary search of `boff` / `off` is 9-17 DEPENDENT
+// L2 loads (3-6 us) in front of ~2.5 us of payload traffic, and the workgroup's bytes are not in flight meanwhile.
+// Here the wave searches TOGETHER: 64 samples per step (a 64-ary search: 2 dependent loads for T <= 1 024, 3 for
+// B <= 65 536), and the last step is a contiguous 64-entry window from which every row of the wave reads its own
+// answer (consecutive rows resolve to the same or the next few entries).
+//   f        non-decreasing over [0, n_total), f(0) <= j0
+//   returns  for lane i < nw: k = largest index with f(k) <= j0 + i, fk = f(k); false = the window ran out for
+//            this lane (more than ~48 boundaries inside the wave's rows: runs of zero-length sequences) -> the
+//            caller falls back to its own binary search.  ALL 64 lanes must call.
+template <typename F>
+__device__ __forceinline__ bool coop_resolve(F f, int64_t n_total, int64_t j0, int nw, int lane, int64_t& k,
+                                             int64_t& fk) {
+  constexpr int64_t BIG = 0x7fffffffffffffffLL;
+  int64_t lo = 0, n = n_total;
+  while (n > 16) {                                   // wave-uniform
+    const int64_t step = (n + 63) >> 6;
+    const int64_t at = (int64_t)lane * step;
+    const int64_t v = at < n ? f(lo + at) : BIG;
+    int c = __popcll(__ballot(v <= j0));
+    if (c < 1) c = 1;
+    const int64_t adv = (int64_t)(c - 1) * step;
+    lo += adv;
+    n = (n - adv) < step ? (n - adv) : step;
+  }
+  const int64_t W = (lo + lane < n_total) ? f(lo + lane) : BIG;      // the window: f(lo .. lo + 63)
+  // every lane counts the window entries <= its own row: a 6-step binary search through the (sorted) window by
+  // lane shuffles — all 64 lanes search at once (a ballot per row would serialise the wave's rows)
+  (void)nw;
+  const int64_t x = j0 + lane;
+  int mine = 0;
+#pragma unroll
+  for (int s = RUA_WAVE / 2; s >= 1; s >>= 1) {
+    const int64_t w = __shfl(W, mine + s - 1, RUA_WAVE);
+    if (w <= x) mine += s;
+  }
+  const int64_t w_last = __shfl(W, RUA_WAVE - 1, RUA_WAVE);       // (unconditional: every lane takes part in a shuffle)
+  if (mine == RUA_WAVE - 1 && w_last <= x) mine = RUA_WAVE;
+  if (mine < 1) mine = 1;
+  k = lo + mine - 1;
+  fk = __shfl(W, mine - 1, RUA_WAVE);
+  return !(mine == RUA_WAVE && lo + RUA_WAVE < n_total);
+}
+
 }  // namespace rua

@@ -218,19 +218,38 @@ __global__ __launch_bounds__(RUA_BLOCK) void lens_from_pack_kernel(const int64_t
 __global__ __launch_bounds__(RUA_BLOCK) void enum_rows_kernel(rua_layout L, int64_t n, int64_t* __restrict__ bp,
                                                               int64_t* __restrict__ tp,
                                                               int64_t* __restrict__ flat) {
-  const int64_t j = (int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x;
-  if (j >= n) return;
-  int64_t b, t, row;
-  if (L.kind == RUA_PACK) {
-    t = search_boff(L.boff, L.T, j);
-    int64_t r = j - L.boff[t];
-    b = L.sorted ? L.sorted[r] : r;
-    row = j;
-  } else {  // CAT / LEFT / RIGHT enumerate tokens batch-major
-    b = search_cat(L, j);
-    t = j - cat_off(L, b);
-    row = L.kind == RUA_CAT ? j : token_to_row(L, b, t, seq_len(L, b));
+  // a wave owns 64 consecutive tokens and resolves them together (coop_resolve: a 64-ary search + one window
+  // instead of a 9-17 step binary search per token); a lane that the window does not cover searches by itself
+  const int lane = threadIdx.x & (RUA_WAVE - 1);
+  const int64_t j0 = ((int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x) - lane;
+  if (j0 >= n) return;                                         // wave-uniform
+  const int nw = n - j0 < RUA_WAVE ? (int)(n - j0) : RUA_WAVE;
+  const int64_t j = j0 + lane;
+  const bool mine = lane < nw;
+  if (!bp && !tp && (L.kind == RUA_CAT || L.kind == RUA_PACK)) {   // C.idx() / P.idx(): storage order IS token order
+    if (mine && flat) flat[j] = j;
+    return;
   }
+  int64_t b = 0, t = 0, row = j;
+  if (L.kind == RUA_PACK) {
+    int64_t bt = 0;
+    const bool ok = coop_resolve([&](int64_t k) { return L.boff[k]; }, L.T, j0, nw, lane, t, bt);
+    if (mine) {
+      if (!ok) { t = search_boff(L.boff, L.T, j); bt = L.boff[t]; }
+      const int64_t r = j - bt;
+      b = L.sorted ? L.sorted[r] : r;
+    }
+  } else {  // CAT / LEFT / RIGHT enumerate tokens batch-major
+    int64_t ob = 0;
+    bool ok = false;
+    if (L.off) ok = coop_resolve([&](int64_t k) { return cat_off(L, k); }, L.B, j0, nw, lane, b, ob);
+    if (mine) {
+      if (!ok) { b = search_cat(L, j); ob = cat_off(L, b); }
+      t = j - ob;
+      row = L.kind == RUA_CAT ? j : token_to_row(L, b, t, seq_len(L, b));
+    }
+  }
+  if (!mine) return;
   if (bp) bp[j] = b;
   if (tp) tp[j] = t;
   if (flat) flat[j] = row;

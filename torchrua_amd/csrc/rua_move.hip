@@ -59,43 +59,6 @@ template <typename V, bool NT> __device__ __forceinline__ void st_row(char* p, V
   else *reinterpret_cast<V*>(p) = v;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Phase 1 of a small tile is a latency chain, not work: a plain binary search of `boff` / `off` is 9-17 DEPENDENT
-// L2 loads (3-6 us) in front of ~2.5 us of payload traffic, and the workgroup's bytes are not in flight meanwhile.
-// Here the wave searches TOGETHER: 64 samples per step (a 64-ary search: 2 dependent loads for T <= 1 024, 3 for
-// B <= 65 536), and the last step is a contiguous 64-entry window from which every row of the wave reads its own
-// answer (consecutive rows resolve to the same or the next few entries).
-//   f        non-decreasing over [0, n_total), f(0) <= j0
-//   returns  for lane i < nw: k = largest index with f(k) <= j0 + i, fk = f(k); false = the window ran out for
-//            this lane (more than ~48 boundaries inside the wave's rows: runs of zero-length sequences) -> the
-//            caller falls back to its own binary search.  ALL 64 lanes must call.
-template <typename F>
-__device__ __forceinline__ bool coop_resolve(F f, int64_t n_total, int64_t j0, int nw, int lane, int64_t& k,
-                                             int64_t& fk) {
-  constexpr int64_t BIG = 0x7fffffffffffffffLL;
-  int64_t lo = 0, n = n_total;
-  while (n > 16) {                                   // wave-uniform
-    const int64_t step = (n + 63) >> 6;
-    const int64_t at = (int64_t)lane * step;
-    const int64_t v = at < n ? f(lo + at) : BIG;
-    int c = __popcll(__ballot(v <= j0));
-    if (c < 1) c = 1;
-    const int64_t adv = (int64_t)(c - 1) * step;
-    lo += adv;
-    n = (n - adv) < step ? (n - adv) : step;
-  }
-  const int64_t W = (lo + lane < n_total) ? f(lo + lane) : BIG;      // the window: f(lo .. lo + 63)
-  int mine = 0;
-  for (int i = 0; i < nw; ++i) {                     // wave-uniform; nw <= 64
-    const int c = __popcll(__ballot(W <= j0 + i));
-    if (lane == i) mine = c;
-  }
-  if (mine < 1) mine = 1;
-  k = lo + mine - 1;
-  fk = __shfl(W, mine - 1, RUA_WAVE);
-  return !(mine == RUA_WAVE && lo + RUA_WAVE < n_total);
-}
-
 // lpr      : lanes (VEC-byte columns) per row = ceil(row_bytes / VEC)
 // lp_log2  : log2 of lanes a wave gives one row per instruction (<= 6); rows narrower than
 //            1 KiB share a wave instruction (64 >> lp_log2 rows at a time)

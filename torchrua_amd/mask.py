@@ -10,8 +10,8 @@ __all__ = []  # methods are attached to the layout classes
 
 
 def _mask(self: Z, zero, one, dtype: torch.dtype = None) -> T:
-    n_seq, n_steps = self.size()[:2]
-    return _mask_grid(lens_of(self), n_seq, n_steps, zero, one, self.data.dtype if dtype is None else dtype)
+    lens = lens_of(self)        # (one row per sequence of the batch, zero-length ones included)
+    return _mask_grid(lens, lens.numel(), self.size()[1], zero, one, self.data.dtype if dtype is None else dtype)
 
 
 # the two fixed flavours: which (zero, one, dtype) a container asks `mask` for
