@@ -19,10 +19,11 @@ from torchrua_amd import _lib as L
 
 
 class host_serial:
-    """Run the tiny host-side metadata ops (a 1-D sort, bincount, cumsum, staging copies of B int64)
-    on ONE thread.  Handing a 512 KB op to a 128-thread OpenMP team costs 10-100x its serial time
-    (measured on the MI355X box: torch.sort of 65 536 lengths 20 ms vs 1.9 ms), and the sort's result
-    does not depend on the thread count (SURVEY.md §8a note)."""
+    """Run a torch CPU op on ONE thread.  Handing a 512 KB op to a 128-thread OpenMP team costs 10-100x its serial
+    time (measured on the MI355X box: torch.sort of 65 536 lengths 20 ms vs 1.9 ms), and the sort's result does not
+    depend on the thread count (SURVEY.md §8a note).  Flipping torch's thread count is process-global, so the hot
+    path no longer does it: the host sort, batch_sizes and the staging copies are the library's own C / numpy code;
+    this is left for the one-off self-test and the RUA_HOST_SORT=torch fallback."""
 
     def __enter__(self):
         self.n = torch.get_num_threads()
@@ -493,7 +494,10 @@ class _StagingRing:
 
     def upload(self, host: Tensor, dev: torch.device) -> Tensor:
         i, staged = self.reserve(host.shape, host.dtype)
-        staged.copy_(host)
+        # a plain memcpy on the calling thread: torch's copy_ hands a 512 KiB vector to its whole OpenMP team
+        # (128 threads on the GPU box: 10-100x the serial time), and flipping torch.set_num_threads around it — what
+        # round 1 did — is a process-global side effect
+        np.copyto(staged.numpy(), host.detach().numpy())
         return self.commit(i, staged, dev)
 
 
@@ -512,8 +516,7 @@ def to_device_async(host: Tensor, dev: torch.device) -> Tensor:
     for it) without blocking the host."""
     if dev.type != 'cuda' or host.numel() == 0 or not host.is_contiguous():
         return host.to(dev)
-    with host_serial():
-        return _ring(dev).upload(host, dev)
+    return _ring(dev).upload(host, dev)
 
 
 def sorted_indices_to_device(host_lens_: Tensor, dev: torch.device) -> Tensor:
