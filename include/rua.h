@@ -157,7 +157,7 @@ enum rua_op {
  * `perm` (may be NULL) indirects CAT rows: row = perm[off[b]+t] — the sorted-by-destination
  * form of scatter_* (reduce.py:6-31).
  * Empty sequence -> `empty_bits` (the reference's `initial`: 0, 1, or the global min/max).
- * If `extreme` != NULL (MAX/MIN/LOGSUMEXP; 65 uint64 of scratch, initialised by the library) the call reproduces
+ * If `extreme` != NULL (MAX/MIN/LOGSUMEXP; 66 uint64 of scratch, initialised by the library) the call reproduces
  * the reference's `initial = tensor.min()` / `.max()` (reduce.py:35,40,57) without its extra pass over the data:
  * the reduce only raises flags in extreme[64] — bit 0: some element is NaN (then `initial` is NaN and poisons every
  * segment), bit 1: some segment is empty — and a second walk for the global extreme (into extreme[0..63]) runs, on
@@ -171,7 +171,15 @@ enum rua_op {
  * ties_out (MAX/MIN; may be NULL): [B, H] f32 (f64 for RUA_F64) that receives, per output element, how many elements
  * of the sequence equal it (with include_self == 1 the old row is folded into the result but not counted; rows that
  * include_self == 2 leaves untouched are not written: pre-zero the buffer) — what the backward needs, for free in the pass that
- * reads the payload anyway (rua_segment_reduce_backward with include_self = RUA_TIES_FINAL then takes ONE walk). */
+ * reads the payload anyway (rua_segment_reduce_backward with include_self = RUA_TIES_FINAL then takes ONE walk).
+ * Two bits may be OR-ed into `op` (here, in rua_pack_reduce and in rua_fill_empty) by a caller that keeps ONE
+ * persistent `extreme` scratch of 66 uint64 per stream, zeroed once when it was allocated:
+ *   RUA_OP_SCRATCH_CLEAN  the scratch arrives zeroed: no initialising launch; rua_fill_empty (which must then be
+ *                         called with the same bit) hands it back zeroed — its last workgroup resets it;
+ *   RUA_OP_NO_EMPTY       the caller knows that no sequence is empty: the second walk is not even armed.
+ * With both, max / min / logsumexp cost the reduce plus ONE trailing launch instead of three. */
+#define RUA_OP_SCRATCH_CLEAN 0x100
+#define RUA_OP_NO_EMPTY      0x200
 int64_t rua_reduce_ws_bytes(int64_t n_rows, int64_t H, int32_t dtype, int64_t split_rows);
 int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* data, void* out,
                        int64_t H, int32_t dtype, int32_t op, int32_t include_self,
@@ -227,7 +235,7 @@ int rua_scatter_self_grad(const int64_t* counts, int64_t S, int64_t H, const voi
 /* After rua_segment_reduce / rua_pack_reduce with `extreme` (MAX/MIN/LOGSUMEXP): write the global extreme into the
  * rows of empty sequences, or NaN into every row when the NaN flag is up (the reference's initial=NaN behaviour). */
 int rua_fill_empty(const rua_layout* lay, void* out, int64_t H, int32_t dtype, int32_t op,
-                   const void* extreme, void* stream);
+                   void* extreme, void* stream);
 
 /* Bucket `index` (values in [0,S); others are ignored): counts[S], off[S] (exclusive scan) and perm[M] such that
  * perm[off[s] .. off[s]+counts[s]) are the rows i with index[i] == s IN ASCENDING ORDER — a stable LSD radix sort

@@ -137,6 +137,19 @@ def max_len(token_sizes: Tensor) -> int:
     return _memo_put(token_sizes, 'max', int(h.detach().numpy().max()) if h.numel() else 0)
 
 
+def known_no_empty(token_sizes: Optional[Tensor]) -> bool:
+    """True when the host can tell WITHOUT a device sync that every sequence holds at least one row."""
+    if token_sizes is None:
+        return False
+    hit = _memo_get(token_sizes, 'min')
+    if hit is None:
+        if token_sizes.is_cuda and _memo_get(token_sizes, 'host') is None and _memo_get(token_sizes, 'host_alias') is None:
+            return False
+        h = host_lens(token_sizes)
+        hit = _memo_put(token_sizes, 'min', int(h.detach().numpy().min()) if h.numel() else 1)
+    return hit > 0
+
+
 def total_len(token_sizes: Tensor) -> int:
     hit = _memo_get(token_sizes, 'sum')
     if hit is not None:
@@ -333,7 +346,7 @@ def known_max_len(token_sizes: Optional[Tensor]) -> Optional[int]:
 
 class Lay:
     """A rua_layout plus the tensors its pointers borrow (kept alive with it)."""
-    __slots__ = ('c', 'keep', 'kind', 'n_rows', 'B', 'max_len')
+    __slots__ = ('c', 'keep', 'kind', 'n_rows', 'B', 'max_len', 'no_empty')
 
     def __init__(self, keep: List[Optional[Tensor]], max_len: Optional[int] = None, **fields):
         self.c = L.RuaLayout(**fields)
@@ -342,6 +355,7 @@ class Lay:
         self.n_rows = fields['n_rows']
         self.B = fields['B']
         self.max_len = max_len      # longest sequence, when the host knows it for free
+        self.no_empty = False       # the host knows that every sequence holds a row (set by the lay_* builders)
 
     def ref(self):
         return ctypes.byref(self.c)
@@ -354,7 +368,9 @@ def lay_cat(lens: Optional[Tensor], B: int, n_rows: int, len_add: int = 0) -> La
     lens = _as_lens(lens)
     off = dev_off(lens)
     mx = known_max_len(lens)
-    return Lay([lens, off], max_len=None if mx is None else mx + len_add, kind=L.CAT, n_rows=n_rows, B=B, lens=L.ptr(lens), len_add=len_add, off=L.ptr(off))
+    lay = Lay([lens, off], max_len=None if mx is None else mx + len_add, kind=L.CAT, n_rows=n_rows, B=B, lens=L.ptr(lens), len_add=len_add, off=L.ptr(off))
+    lay.no_empty = len_add >= 0 and known_no_empty(lens)
+    return lay
 
 
 def lay_padded(kind: int, lens: Optional[Tensor], B: int, T_phys: int, T_log: int, len_add: int = 0,
@@ -370,7 +386,9 @@ def lay_padded(kind: int, lens: Optional[Tensor], B: int, T_phys: int, T_log: in
             keep.append(off)
             f['off'] = L.ptr(off)
     mx = len_add if lens is None else known_max_len(lens)
-    return Lay(keep, max_len=mx if lens is None or mx is None else mx + len_add, **f)
+    lay = Lay(keep, max_len=mx if lens is None or mx is None else mx + len_add, **f)
+    lay.no_empty = (len_add > 0) if lens is None else (len_add >= 0 and known_no_empty(lens))
+    return lay
 
 
 TILE_R, TILE_T = 16, 16     # (rank x time) tile of the narrow-row pack kernel
@@ -419,9 +437,12 @@ def lay_pack(p, lens: Optional[Tensor] = None, len_add: int = 0, boff: Optional[
         t = pack_tiling(p)       # narrow rows: hand the (rank x time) tile table to the mover
         keep += [t.bsz, t.tile_start]
         extra.update(bsz=L.ptr(t.bsz), tile_start=L.ptr(t.tile_start), n_tchunks=t.n_tchunks, n_tiles=t.n_tiles)
-    return Lay(keep, max_len=T, kind=L.PACK, n_rows=n_rows, B=pack_nseq(p),
-               lens=L.ptr(lens), len_add=len_add, boff=L.ptr(boff), T=T, sorted=L.ptr(p.sorted_indices),
-               unsorted=L.ptr(p.unsorted_indices), **extra)
+    lay = Lay(keep, max_len=T, kind=L.PACK, n_rows=n_rows, B=pack_nseq(p),
+              lens=L.ptr(lens), len_add=len_add, boff=L.ptr(boff), T=T, sorted=L.ptr(p.sorted_indices),
+              unsorted=L.ptr(p.unsorted_indices), **extra)
+    # batch_sizes[0] counts the sequences that hold a row (a host tensor): all of them, unless some are empty
+    lay.no_empty = len_add == 0 and T == p.batch_sizes.numel() and T > 0 and pack_B(p) == pack_nseq(p)
+    return lay
 
 
 class _StagingRing:

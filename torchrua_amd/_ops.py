@@ -125,6 +125,28 @@ class _ListGather(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------ reductions
+# max / min / logsumexp track the reference's global `initial` through a small scratch (rua.h: `extreme`).  One
+# persistent, zeroed scratch per (device, stream): the reduce needs no initialising launch (RUA_OP_SCRATCH_CLEAN) and
+# rua_fill_empty's last workgroup hands it back zeroed — stream order makes that safe for one stream, hence the key.
+_scratch = {}
+
+
+def extreme_scratch(dev, lay: M.Lay) -> Tuple[Tensor, int]:
+    key = (dev.index, torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if dev.index is None else dev.index))
+    buf = _scratch.get(key)
+    if buf is None:
+        if torch.cuda.is_current_stream_capturing():
+            # first use inside a graph capture: a buffer of the capture's own (zeroed by the legacy initialising launch)
+            return torch.empty(66, dtype=torch.long, device=dev), (L.OP_NO_EMPTY if lay.no_empty else 0)
+        buf = _scratch[key] = torch.zeros(66, dtype=torch.long, device=dev)
+    return buf, L.OP_SCRATCH_CLEAN | (L.OP_NO_EMPTY if lay.no_empty else 0)
+
+
+def forget_extreme_scratch(dev) -> None:
+    for key in [k for k in _scratch if k[0] == dev.index]:
+        del _scratch[key]
+
+
 _EMPTY = {L.SUM: 0.0, L.MEAN: 0.0, L.PROD: 1.0, L.MAX: 0.0, L.MIN: 0.0, L.LOGSUMEXP: float('-inf')}
 
 
@@ -158,20 +180,24 @@ def launch_reduce(lay: M.Lay, data: Tensor, op: int, out: Optional[Tensor] = Non
         out = torch.empty((lay.B,) + tuple(hidden), dtype=data.dtype, device=dev)
     elif not out.is_contiguous() or out.dtype != data.dtype or out.numel() != lay.B * H:
         raise L.RuaError('reduce target must be a contiguous [B, *hidden] tensor of the payload dtype')
-    extreme = None
+    extreme, op_bits = None, 0
     if reference_initial and op in (L.MAX, L.MIN, L.LOGSUMEXP) and include_self == 0:
-        extreme = torch.empty(65, dtype=torch.long, device=dev)  # initialised by the library
+        extreme, op_bits = extreme_scratch(dev, lay)
     split, ws = split_workspace(lay, H, data.dtype, dev)
     if _kernel_hook:
         _kernel_hook(name, True)
-    L.check(lib.rua_segment_reduce(lay.ref(), L.ptr(perm), L.ptr(data), L.ptr(out), H, L.DTYPES[data.dtype], op,
-                                   include_self, _bits(_EMPTY[op], data.dtype), L.ptr(extreme), split, L.ptr(ws),
-                                   L.ptr(ties_out), L.stream_ptr(dev)), 'rua_segment_reduce')
-    if _kernel_hook:
-        _kernel_hook(name, False)
-    if extreme is not None:
-        L.check(lib.rua_fill_empty(lay.ref(), L.ptr(out), H, L.DTYPES[data.dtype], op, L.ptr(extreme),
-                                   L.stream_ptr(dev)), 'rua_fill_empty')
+    try:
+        L.check(lib.rua_segment_reduce(lay.ref(), L.ptr(perm), L.ptr(data), L.ptr(out), H, L.DTYPES[data.dtype],
+                                       op | op_bits, include_self, _bits(_EMPTY[op], data.dtype), L.ptr(extreme), split,
+                                       L.ptr(ws), L.ptr(ties_out), L.stream_ptr(dev)), 'rua_segment_reduce')
+        if _kernel_hook:
+            _kernel_hook(name, False)
+        if extreme is not None:
+            L.check(lib.rua_fill_empty(lay.ref(), L.ptr(out), H, L.DTYPES[data.dtype], op | (op_bits & L.OP_SCRATCH_CLEAN),
+                                       L.ptr(extreme), L.stream_ptr(dev)), 'rua_fill_empty')
+    except L.RuaError:
+        forget_extreme_scratch(dev)        # a refused launch may have left the flags raised
+        raise
     return out
 
 

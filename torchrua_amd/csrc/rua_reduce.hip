@@ -8,17 +8,18 @@ namespace rua {
 constexpr int EXTREME_SLOTS_ENTRY = 64;
 __global__ void extreme_init_entry_kernel(unsigned long long* ext, int want_max_of_data) {
   const int i = threadIdx.x;
-  if (i < EXTREME_SLOTS_ENTRY) ext[i] = want_max_of_data ? 0ull : ~0ull;
-  if (i == EXTREME_SLOTS_ENTRY) ext[i] = 0ull;
+  (void)want_max_of_data;                       // the slots are zero-neutral for the maximum and the minimum alike
+  if (i <= EXTREME_SLOTS_ENTRY + 1) ext[i] = 0ull;   // slots, flags, ticket
 }
 #define RUA_DECL(NAME)                                                                                              \
   int reduce_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data, void* out,  \
                     int64_t H, int include_self, uint64_t empty_bits, void* extreme, int64_t split, void* ws,     \
-                    const rua_layout* CD, void* copy, void* ties);                                                 \
+                    const rua_layout* CD, void* copy, void* ties, bool no_empty);                                  \
   int backward_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,           \
                       const void* out, const void* gout, void* gin, int64_t H, int extra_count, int64_t split,    \
                       void* ws, void* ties, bool ties_final, const void* self_in);                                 \
-  int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, const void* ext);  \
+  int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, void* ext,        \
+                        int reset);                                                                              \
   int self_grad_##NAME(hipStream_t s, const int64_t* counts, int64_t S, int64_t H, const void* self_in,            \
                        const void* out, const void* gout, const void* aux, void* gself, int op, int inc);
 RUA_DECL(f32) RUA_DECL(bf16) RUA_DECL(f16) RUA_DECL(f64)
@@ -94,17 +95,19 @@ int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* d
   if (perm && lay->kind != RUA_CAT) return RUA_EINVAL;
   if (lay->B == 0 || H == 0) return 0;
   if (!out || (lay->n_rows > 0 && !data)) return RUA_EINVAL;
+  const bool clean = (op & RUA_OP_SCRATCH_CLEAN) != 0, no_empty = (op & RUA_OP_NO_EMPTY) != 0;
+  op &= 0xff;
   if (ties && op != RUA_MAX && op != RUA_MIN) return RUA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (extreme && (op == RUA_MAX || op == RUA_MIN || op == RUA_LOGSUMEXP)) {
+  if (extreme && !clean && (op == RUA_MAX || op == RUA_MIN || op == RUA_LOGSUMEXP)) {
     hipLaunchKernelGGL(extreme_init_entry_kernel, dim3(1), dim3(128), 0, s, (unsigned long long*)extreme,
                        op == RUA_MIN ? 1 : 0);
   }
   switch (dtype) {
-    case RUA_F32: return reduce_f32(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr, ties);
-    case RUA_BF16: return reduce_bf16(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr, ties);
-    case RUA_F16: return reduce_f16(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr, ties);
-    case RUA_F64: return reduce_f64(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr, ties);
+    case RUA_F32: return reduce_f32(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr, ties, no_empty);
+    case RUA_BF16: return reduce_bf16(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr, ties, no_empty);
+    case RUA_F16: return reduce_f16(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr, ties, no_empty);
+    case RUA_F64: return reduce_f64(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr, ties, no_empty);
   }
   return RUA_EINVAL;
 }
@@ -119,33 +122,36 @@ int rua_pack_reduce(const rua_layout* src, const rua_layout* pack, const void* d
   if (src->B == 0 || H == 0) return 0;
   if (!out || !pack_data || !data) return RUA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (extreme && (op == RUA_MAX || op == RUA_MIN || op == RUA_LOGSUMEXP))
+  const bool clean = (op & RUA_OP_SCRATCH_CLEAN) != 0, no_empty = (op & RUA_OP_NO_EMPTY) != 0;
+  op &= 0xff;
+  if (extreme && !clean && (op == RUA_MAX || op == RUA_MIN || op == RUA_LOGSUMEXP))
     hipLaunchKernelGGL(extreme_init_entry_kernel, dim3(1), dim3(128), 0, s, (unsigned long long*)extreme,
                        op == RUA_MIN ? 1 : 0);
   switch (dtype) {
-    case RUA_F32: return reduce_f32(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data, nullptr);
-    case RUA_BF16: return reduce_bf16(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data, nullptr);
-    case RUA_F16: return reduce_f16(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data, nullptr);
-    case RUA_F64: return reduce_f64(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data, nullptr);
+    case RUA_F32: return reduce_f32(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data, nullptr, no_empty);
+    case RUA_BF16: return reduce_bf16(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data, nullptr, no_empty);
+    case RUA_F16: return reduce_f16(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data, nullptr, no_empty);
+    case RUA_F64: return reduce_f64(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data, nullptr, no_empty);
   }
   return RUA_EINVAL;
 }
 
-int rua_fill_empty(const rua_layout* lay, void* out, int64_t H, int32_t dtype, int32_t op, const void* extreme,
+int rua_fill_empty(const rua_layout* lay, void* out, int64_t H, int32_t dtype, int32_t op, void* extreme,
                    void* stream) {
   if (!lay || H < 0 || !extreme) return RUA_EINVAL;
+  const int reset = (op & RUA_OP_SCRATCH_CLEAN) ? 1 : 0;
+  op &= 0xff;
   if (op != RUA_MAX && op != RUA_MIN && op != RUA_LOGSUMEXP) return RUA_EINVAL;
   const int64_t n = lay->B * H;
   if (n == 0) return 0;
   if (!out) return RUA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int wmax = op == RUA_MIN ? 1 : 0;
-  const unsigned long long* e = (const unsigned long long*)extreme;
   switch (dtype) {
-    case RUA_F32: return fill_empty_f32(s, *lay, out, H, wmax, e);
-    case RUA_BF16: return fill_empty_bf16(s, *lay, out, H, wmax, e);
-    case RUA_F16: return fill_empty_f16(s, *lay, out, H, wmax, e);
-    case RUA_F64: return fill_empty_f64(s, *lay, out, H, wmax, e);
+    case RUA_F32: return fill_empty_f32(s, *lay, out, H, wmax, extreme, reset);
+    case RUA_BF16: return fill_empty_bf16(s, *lay, out, H, wmax, extreme, reset);
+    case RUA_F16: return fill_empty_f16(s, *lay, out, H, wmax, extreme, reset);
+    case RUA_F64: return fill_empty_f64(s, *lay, out, H, wmax, extreme, reset);
     default: return RUA_EINVAL;
   }
 }

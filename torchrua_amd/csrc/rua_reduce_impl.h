@@ -60,6 +60,14 @@ __device__ __forceinline__ double fminx(double a, double b) { return fmin(a, b);
 
 __device__ __forceinline__ float fexp(float x) { return __expf(x); }
 __device__ __forceinline__ double fexp(double x) { return exp(x); }
+// exp(x - m) for a whole chunk of x against one m: the subtraction and __expf's scaling by log2(e) fold into ONE fma
+// in front of v_exp_f32 (the online logsumexp is the one reduction whose ALU time shows next to its memory time).
+// `ms` = exp_shift(m), computed once per chunk and column.
+constexpr float RUA_LOG2E = 1.44269504088896340736f;
+__device__ __forceinline__ float exp_shift(float m) { return -m * RUA_LOG2E; }
+__device__ __forceinline__ double exp_shift(double m) { return m; }
+__device__ __forceinline__ float exp_shifted(float x, float ms) { return __builtin_amdgcn_exp2f(__builtin_fmaf(x, RUA_LOG2E, ms)); }
+__device__ __forceinline__ double exp_shifted(double x, double m) { return exp(x - m); }
 __device__ __forceinline__ float flog(float x) { return logf(x); }
 __device__ __forceinline__ double flog(double x) { return log(x); }
 
@@ -283,8 +291,9 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
           // are not there into NaN.  (A sequence whose elements are ALL -inf is NaN in the reference — exp(-inf - -inf)
           // — and fold_store restores that from the final maximum.)
           const A m = (f.acc[ce] == -acc_inf<A>()) ? (A)0 : f.acc[ce];
+          const A ms = exp_shift(m);
 #pragma unroll
-          for (int u = 0; u < UT; ++u) f.aux[ce] += fexp(x[u] - m);   // NaN x -> NaN sum, as the reference
+          for (int u = 0; u < UT; ++u) f.aux[ce] += exp_shifted(x[u], ms);   // NaN x -> NaN sum, as the reference
         }
       } else if (op_counts(OP)) {
         // max / min that also count the elements equal to the extreme, chunk-wise like logsumexp so that it stays
@@ -984,27 +993,53 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_extreme_kernel(rua_layout L, con
   }
   if (lane == 0) {
     const int slot = (int)(blockIdx.x & (EXTREME_SLOTS - 1));
+    // zero-neutral in both directions (a scratch that arrives zeroed needs no initialising launch): the maximum is
+    // kept as its ordered bits, the minimum as their complement, both under atomicMax
     if (WANT_MAX) atomicMax(&extreme[slot], (unsigned long long)ordered_bits(ext));
-    else atomicMin(&extreme[slot], (unsigned long long)ordered_bits(ext));
+    else atomicMax(&extreme[slot], ~(unsigned long long)ordered_bits(ext));
   }
 }
 
-// extreme scratch: [0..63] hashed ordered-bit slots, [64] flags (initialised by rua_reduce.hip)
+// extreme scratch: [0..63] hashed slots (zero-neutral, see seg_extreme_kernel), [64] flags, [65] a ticket counter.
+// `reset`: the scratch is the caller's persistent, zeroed buffer (RUA_OP_SCRATCH_CLEAN): the LAST workgroup to have
+// read it (ticket) puts it back to zero, so the next call needs no initialising launch either.
+template <typename T>
+__device__ __forceinline__ void fill_empty_body(const rua_layout& L, T* __restrict__ out, int64_t H,
+                                                int want_max_of_data, const unsigned long long* __restrict__ ext,
+                                                unsigned long long flags);
+
 template <typename T>
 __global__ __launch_bounds__(RUA_BLOCK) void fill_empty_kernel(rua_layout L, T* __restrict__ out, int64_t H,
                                                                int want_max_of_data,
-                                                               const unsigned long long* __restrict__ ext) {
-  using A = typename elem<T>::acc;
+                                                               unsigned long long* __restrict__ ext, int reset) {
   const unsigned long long flags = ext[EXTREME_SLOTS];
-  if (flags == 0ull) return;                       // the common case: no NaN, no empty segment
+  if (flags != 0ull) fill_empty_body<T>(L, out, H, want_max_of_data, ext, flags);   // rare: a NaN or an empty segment
+  if (!reset) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned long long t = atomicAdd(&ext[EXTREME_SLOTS + 1], 1ull);
+    if (t == (unsigned long long)gridDim.x - 1ull) {
+      for (int i = 0; i < EXTREME_SLOTS + 2; ++i) ext[i] = 0ull;
+      __threadfence();
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void fill_empty_body(const rua_layout& L, T* __restrict__ out, int64_t H,
+                                                int want_max_of_data, const unsigned long long* __restrict__ ext,
+                                                unsigned long long flags) {
+  using A = typename elem<T>::acc;
   // decode the tracked extreme: lane i reads slot i, 6-step butterfly
   const int lane = threadIdx.x & (RUA_WAVE - 1);
   unsigned long long best = ext[lane];
 #pragma unroll
   for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {
     const unsigned long long o = __shfl_xor(best, d, RUA_WAVE);
-    best = want_max_of_data ? (o > best ? o : best) : (o < best ? o : best);
+    best = o > best ? o : best;
   }
+  if (!want_max_of_data) best = ~best;
   const bool poison = (flags & 1ull) != 0ull;
   A val;
   if (sizeof(A) == 8) val = (A)unordered_f64(best); else val = (A)unordered_f32(best);
@@ -1244,10 +1279,11 @@ template <typename T>
 static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,
                            void* out, int64_t H, int include_self, uint64_t empty_bits, void* extreme,
                            int64_t split, void* ws, const rua_layout* CD = nullptr, void* copy = nullptr,
-                           void* ties = nullptr) {
+                           void* ties = nullptr, bool no_empty = false) {
   const int r = dispatch_reduce_main<T>(op, s, L, perm, data, out, H, include_self, empty_bits, extreme, split, ws, CD,
                                         copy, ties);
   if (r != 0 || !extreme || !(op == RUA_MAX || op == RUA_MIN || op == RUA_LOGSUMEXP)) return r;
+  if (no_empty) return r;     // the caller vouches that no sequence is empty (RUA_OP_NO_EMPTY): no second walk to arm
   // (a PackedSequence may carry zero-length sequences too — C.pack() of lens such as [0,3,0,2] — so PACK takes the
   // same lazy second walk: every workgroup leaves on the flag word unless a sequence was empty or a NaN showed)
   constexpr int FULL = 16 / sizeof(T);
@@ -1373,11 +1409,12 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
 #define RUA_DECLARE_REDUCE_DTYPE(NAME)                                                                              \
   int reduce_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data, void* out,  \
                     int64_t H, int include_self, uint64_t empty_bits, void* extreme, int64_t split, void* ws,     \
-                    const rua_layout* CD, void* copy, void* ties);                                                 \
+                    const rua_layout* CD, void* copy, void* ties, bool no_empty);                                  \
   int backward_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,           \
                       const void* out, const void* gout, void* gin, int64_t H, int extra_count, int64_t split,    \
                       void* ws, void* ties, bool ties_final, const void* self_in);                                 \
-  int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, const void* ext); \
+  int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, void* ext,        \
+                        int reset);                                                                              \
   int self_grad_##NAME(hipStream_t s, const int64_t* counts, int64_t S, int64_t H, const void* self_in,            \
                        const void* out, const void* gout, const void* aux, void* gself, int op, int inc);
 RUA_DECLARE_REDUCE_DTYPE(f32)
@@ -1389,9 +1426,9 @@ RUA_DECLARE_REDUCE_DTYPE(f64)
   namespace rua {                                                                                                   \
   int reduce_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data, void* out,  \
                     int64_t H, int include_self, uint64_t empty_bits, void* extreme, int64_t split, void* ws,     \
-                    const rua_layout* CD, void* copy, void* ties) {                                                \
+                    const rua_layout* CD, void* copy, void* ties, bool no_empty) {                                 \
     return dispatch_reduce<T>(op, s, L, perm, data, out, H, include_self, empty_bits, extreme, split, ws, CD,      \
-                              copy, ties);                                                                         \
+                              copy, ties, no_empty);                                                               \
   }                                                                                                                 \
   int backward_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,           \
                       const void* out, const void* gout, void* gin, int64_t H, int extra_count, int64_t split,    \
@@ -1399,9 +1436,10 @@ RUA_DECLARE_REDUCE_DTYPE(f64)
     return dispatch_backward<T>(op, s, L, perm, data, out, gout, gin, H, extra_count, split, ws, ties, ties_final, \
                                 self_in);                                                                          \
   }                                                                                                                 \
-  int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, const void* ext) { \
+  int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, void* ext,        \
+                        int reset) {                                                                             \
     hipLaunchKernelGGL(fill_empty_kernel<T>, dim3(grid_for(L.B)), dim3(RUA_BLOCK), 0, s, L, (T*)out, H, want_max,  \
-                       (const unsigned long long*)ext);                                                            \
+                       (unsigned long long*)ext, reset);                                                           \
     return (int)hipGetLastError();                                                                                  \
   }                                                                                                                 \
   int self_grad_##NAME(hipStream_t s, const int64_t* counts, int64_t S, int64_t H, const void* self_in,            \
