@@ -252,6 +252,9 @@ def main():
     dt = time.perf_counter() - t0
     if args.trace_host and rank == 0:
         print('host enqueue ms per step:', ' '.join(f'{x:.2f}' for x in host_ms), file=sys.stderr)
+        for name in ('to_pack', 'reduce'):
+            print(f'{name} kernel ms per step:', ' '.join(f'{a.elapsed_time(b):.2f}' for a, b in timer.pairs.get(name, [])),
+                  file=sys.stderr)
     timer.enabled = False
 
     # sanity inside the bench: the last step's output is a real PackedSequence and a [B, H] sum

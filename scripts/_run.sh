@@ -1,3 +1,4 @@
 set -e
-python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-python scripts/cfg3_probe.py
+python bench.py --steps 24 --warmup 3 --trace-host --no-cpu-baseline > gpurun_out/bench_b.json 2> gpurun_out/bench_b.err
+grep -E "kernel ms|host enqueue" gpurun_out/bench_b.err
+python scripts/bench_configs.py 2>&1 | grep -E "c.pack\(\)|reduce_sum\(p\)" | tail -2
