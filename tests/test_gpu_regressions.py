@@ -214,3 +214,44 @@ def test_gather_backward_is_a_deterministic_scatter_sum(kind):
     back = {'C': lambda d: d, 'L': lambda d: ta.L(d, c.token_sizes).cat().data, 'R': lambda d: ta.R(d, c.token_sizes).cat().data,
             'P': lambda d: c.pack()._replace(data=d).cat().data}[kind](grads[0])
     torch.testing.assert_close(back, exp, rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------ long runs of zero-length sequences
+@pytest.mark.parametrize('hidden', [(8,), (256,), (1,)], ids=['32B', '1KiB', '4B'])
+def test_runs_of_empty_sequences_between_real_ones(hidden):
+    """More than 64 sequence starts inside one wave's rows: the wave-cooperative row resolution (a 64-entry window of
+    offsets) cannot cover them and every lane must fall back to its own search — for the mover (CAT destinations), for
+    ptr()/idx() and for the reducers."""
+    g = torch.Generator().manual_seed(3)
+    lens = []
+    for k in range(40):
+        lens += [int(torch.randint(1, 9, (1,), generator=g))] + [0] * int(torch.randint(0, 300, (1,), generator=g))
+    lens += [5, 0, 0, 3]
+    lt = torch.tensor(lens, dtype=torch.long)
+    n = int(lt.sum())
+    data = torch.randn((n,) + hidden, generator=g)
+    c = ta.C(data.to(DEV), lt.to(DEV))
+    oc = orc.C(data.numpy(), lt.numpy())
+    # enumeration
+    bp, tp = c.ptr()
+    obp, otp = orc.ptr(oc)
+    assert np.array_equal(to_np(bp), obp) and np.array_equal(to_np(tp), otp)
+    # pads and back (CAT destination = the fallback path), roll inside C
+    left, right = c.left(-2.0), c.right(-2.0)
+    assert np.array_equal(to_np(left.data), orc.to_left(oc, -2.0).data)
+    assert np.array_equal(to_np(right.data), orc.to_right(oc, -2.0).data)
+    assert torch.equal(left.cat().data, c.data) and torch.equal(right.cat().data, c.data)
+    assert np.array_equal(to_np(c.roll(2).data), orc.roll(oc, 2).data)
+    lidx = left.idx()
+    assert np.array_equal(to_np(lidx.data), orc.idx(orc.to_left(oc, -2.0)).data)
+    # pack and back
+    p = c.pack()
+    assert_same_seq(p, orc.to_pack(oc, host_sort(lens)), 'pack')
+    assert torch.equal(p.cat().data, c.data) and p.cat().token_sizes.tolist() == lens
+    # reductions: empty segments take the reference's initial
+    for name in ('sum', 'max', 'logsumexp', 'mean'):
+        ref = getattr(orc, f'segment_{name}')(data.numpy(), lt.numpy())
+        got = getattr(ta, f'segment_{name}')(c.data, c.token_sizes).cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5, err_msg=name)
+        got_p = getattr(ta, f'reduce_{name}')(p).cpu().numpy()
+        np.testing.assert_allclose(got_p, ref, rtol=1e-5, atol=1e-5, err_msg=name + ' over P')
