@@ -157,7 +157,7 @@ enum rua_op {
  * `perm` (may be NULL) indirects CAT rows: row = perm[off[b]+t] — the sorted-by-destination
  * form of scatter_* (reduce.py:6-31).
  * Empty sequence -> `empty_bits` (the reference's `initial`: 0, 1, or the global min/max).
- * If `extreme` != NULL (MAX/MIN/LOGSUMEXP; 66 uint64 of scratch, initialised by the library) the call reproduces
+ * If `extreme` != NULL (MAX/MIN/LOGSUMEXP; 67 uint64 of scratch, initialised by the library) the call reproduces
  * the reference's `initial = tensor.min()` / `.max()` (reduce.py:35,40,57) without its extra pass over the data:
  * the reduce only raises flags in extreme[64] — bit 0: some element is NaN (then `initial` is NaN and poisons every
  * segment), bit 1: some segment is empty — and a second walk for the global extreme (into extreme[0..63]) runs, on
@@ -173,10 +173,11 @@ enum rua_op {
  * include_self == 2 leaves untouched are not written: pre-zero the buffer) — what the backward needs, for free in the pass that
  * reads the payload anyway (rua_segment_reduce_backward with include_self = RUA_TIES_FINAL then takes ONE walk).
  * Two bits may be OR-ed into `op` (here, in rua_pack_reduce and in rua_fill_empty) by a caller that keeps ONE
- * persistent `extreme` scratch of 66 uint64 per stream, zeroed once when it was allocated:
+ * persistent `extreme` scratch of 67 uint64 per stream, zeroed once when it was allocated:
  *   RUA_OP_SCRATCH_CLEAN  the scratch arrives zeroed: no initialising launch; rua_fill_empty (which must then be
  *                         called with the same bit) hands it back zeroed — its last workgroup resets it;
- *   RUA_OP_NO_EMPTY       the caller knows that no sequence is empty: the second walk is not even armed.
+ *   RUA_OP_NO_EMPTY       the second walk is not armed here: the caller knows that no sequence is empty, or hands
+ *                         rua_fill_empty the payload so that it takes the walk itself.
  * With both, max / min / logsumexp cost the reduce plus ONE trailing launch instead of three. */
 #define RUA_OP_SCRATCH_CLEAN 0x100
 #define RUA_OP_NO_EMPTY      0x200
@@ -233,9 +234,13 @@ int rua_scatter_self_grad(const int64_t* counts, int64_t S, int64_t H, const voi
                           int32_t include_self, void* stream);
 
 /* After rua_segment_reduce / rua_pack_reduce with `extreme` (MAX/MIN/LOGSUMEXP): write the global extreme into the
- * rows of empty sequences, or NaN into every row when the NaN flag is up (the reference's initial=NaN behaviour). */
+ * rows of empty sequences, or NaN into every row when the NaN flag is up (the reference's initial=NaN behaviour).
+ * With `data` (and `perm`) — the reduce's own inputs — this call ALSO takes the rare second walk for the global
+ * extreme when a segment is empty (one launch with a grid barrier inside instead of a launch of its own): pass
+ * RUA_OP_NO_EMPTY to the reduce so that it does not arm the walk itself.  data == NULL: the reduce did it, or
+ * nothing is empty. */
 int rua_fill_empty(const rua_layout* lay, void* out, int64_t H, int32_t dtype, int32_t op,
-                   void* extreme, void* stream);
+                   void* extreme, const void* data, const int64_t* perm, void* stream);
 
 /* Bucket `index` (values in [0,S); others are ignored): counts[S], off[S] (exclusive scan) and perm[M] such that
  * perm[off[s] .. off[s]+counts[s]) are the rows i with index[i] == s IN ASCENDING ORDER — a stable LSD radix sort

@@ -1,2 +1,2 @@
 set -e
-python -m pytest tests/test_gpu_regressions.py -x -q -m gpu 2>&1 | tail -5
+timeout -k 10 300 python -m pytest tests/test_gpu_regressions.py -x -q -m gpu -k "grid_that_hits" 2>&1 | tail -3

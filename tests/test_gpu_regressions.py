@@ -255,3 +255,29 @@ def test_runs_of_empty_sequences_between_real_ones(hidden):
         np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5, err_msg=name)
         got_p = getattr(ta, f'reduce_{name}')(p).cpu().numpy()
         np.testing.assert_allclose(got_p, ref, rtol=1e-5, atol=1e-5, err_msg=name + ' over P')
+
+
+def test_empty_segments_at_a_grid_that_hits_the_cap():
+    """max / min / logsumexp with empty segments among 300 000: the one trailing launch walks the payload for the
+    global extreme, meets at its grid barrier (the grid is capped at 1 024 workgroups so that all are resident) and
+    patches the empty rows — against the oracle, twice in a row (the persistent scratch must come back zeroed)."""
+    g = torch.Generator().manual_seed(12)
+    lens = torch.randint(0, 4, (300_000,), generator=g)
+    data = torch.randn(int(lens.sum()), 8, generator=g)
+    d, l = data.to(DEV), lens.to(DEV)
+    for _ in range(2):
+        for name in ('max', 'min', 'logsumexp'):
+            ref = getattr(orc, f'segment_{name}')(data.numpy(), lens.numpy())
+            got = getattr(ta, f'segment_{name}')(d, l).cpu().numpy()
+            if name == 'logsumexp':
+                np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+            else:
+                np.testing.assert_array_equal(got, ref)
+        # and a call with nothing empty and no NaN right after: untouched by leftovers
+        full = torch.ones(300_000, dtype=torch.long, device=DEV)
+        assert torch.equal(ta.segment_max(d[:300_000], full), d[:300_000])
+    # a NaN poisons every segment (reduce.py:35: initial = tensor.min() is NaN), then the next call is clean again
+    d2 = d.clone()
+    d2[12345, 3] = float('nan')
+    assert torch.isnan(ta.segment_max(d2, l)).all()
+    assert not torch.isnan(ta.segment_max(d, l)).any()

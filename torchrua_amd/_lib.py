@@ -66,7 +66,8 @@ SYMBOLS = {
                                             c_void_p]),
     'rua_scatter_self_grad': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_int32, c_int32, c_int32, c_void_p]),
-    'rua_fill_empty': (c_int, [POINTER(RuaLayout), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    'rua_fill_empty': (c_int, [POINTER(RuaLayout), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                               c_void_p]),
     'rua_bucket_ws_elems': (c_int64, [c_int64, c_int64]),
     'rua_index_buckets': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rua_host_sort_desc': (c_int, [c_void_p, c_int64, c_void_p, c_int32]),

@@ -137,8 +137,8 @@ def extreme_scratch(dev, lay: M.Lay) -> Tuple[Tensor, int]:
     if buf is None:
         if torch.cuda.is_current_stream_capturing():
             # first use inside a graph capture: a buffer of the capture's own (zeroed by the legacy initialising launch)
-            return torch.empty(66, dtype=torch.long, device=dev), (L.OP_NO_EMPTY if lay.no_empty else 0)
-        buf = _scratch[key] = torch.zeros(66, dtype=torch.long, device=dev)
+            return torch.empty(67, dtype=torch.long, device=dev), (L.OP_NO_EMPTY if lay.no_empty else 0)
+        buf = _scratch[key] = torch.zeros(67, dtype=torch.long, device=dev)
     return buf, L.OP_SCRATCH_CLEAN | (L.OP_NO_EMPTY if lay.no_empty else 0)
 
 
@@ -187,14 +187,19 @@ def launch_reduce(lay: M.Lay, data: Tensor, op: int, out: Optional[Tensor] = Non
     if _kernel_hook:
         _kernel_hook(name, True)
     try:
+        # (the second walk for the global extreme, should a segment be empty, rides in rua_fill_empty's launch: the
+        # reduce is told not to arm it, and fill_empty gets the payload unless the host knows nothing is empty)
         L.check(lib.rua_segment_reduce(lay.ref(), L.ptr(perm), L.ptr(data), L.ptr(out), H, L.DTYPES[data.dtype],
-                                       op | op_bits, include_self, _bits(_EMPTY[op], data.dtype), L.ptr(extreme), split,
-                                       L.ptr(ws), L.ptr(ties_out), L.stream_ptr(dev)), 'rua_segment_reduce')
+                                       op | op_bits | (L.OP_NO_EMPTY if extreme is not None else 0), include_self,
+                                       _bits(_EMPTY[op], data.dtype), L.ptr(extreme), split, L.ptr(ws), L.ptr(ties_out),
+                                       L.stream_ptr(dev)), 'rua_segment_reduce')
         if _kernel_hook:
             _kernel_hook(name, False)
         if extreme is not None:
+            walk = not (op_bits & L.OP_NO_EMPTY)
             L.check(lib.rua_fill_empty(lay.ref(), L.ptr(out), H, L.DTYPES[data.dtype], op | (op_bits & L.OP_SCRATCH_CLEAN),
-                                       L.ptr(extreme), L.stream_ptr(dev)), 'rua_fill_empty')
+                                       L.ptr(extreme), L.ptr(data) if walk else None, L.ptr(perm) if walk else None,
+                                       L.stream_ptr(dev)), 'rua_fill_empty')
     except L.RuaError:
         forget_extreme_scratch(dev)        # a refused launch may have left the flags raised
         raise

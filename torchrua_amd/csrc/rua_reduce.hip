@@ -9,7 +9,7 @@ constexpr int EXTREME_SLOTS_ENTRY = 64;
 __global__ void extreme_init_entry_kernel(unsigned long long* ext, int want_max_of_data) {
   const int i = threadIdx.x;
   (void)want_max_of_data;                       // the slots are zero-neutral for the maximum and the minimum alike
-  if (i <= EXTREME_SLOTS_ENTRY + 1) ext[i] = 0ull;   // slots, flags, ticket
+  if (i <= EXTREME_SLOTS_ENTRY + 2) ext[i] = 0ull;   // slots, flags, ticket, barrier
 }
 #define RUA_DECL(NAME)                                                                                              \
   int reduce_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data, void* out,  \
@@ -19,7 +19,7 @@ __global__ void extreme_init_entry_kernel(unsigned long long* ext, int want_max_
                       const void* out, const void* gout, void* gin, int64_t H, int extra_count, int64_t split,    \
                       void* ws, void* ties, bool ties_final, const void* self_in);                                 \
   int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, void* ext,        \
-                        int reset);                                                                              \
+                        int reset, const void* data, const int64_t* perm);                                       \
   int self_grad_##NAME(hipStream_t s, const int64_t* counts, int64_t S, int64_t H, const void* self_in,            \
                        const void* out, const void* gout, const void* aux, void* gself, int op, int inc);
 RUA_DECL(f32) RUA_DECL(bf16) RUA_DECL(f16) RUA_DECL(f64)
@@ -137,8 +137,9 @@ int rua_pack_reduce(const rua_layout* src, const rua_layout* pack, const void* d
 }
 
 int rua_fill_empty(const rua_layout* lay, void* out, int64_t H, int32_t dtype, int32_t op, void* extreme,
-                   void* stream) {
+                   const void* data, const int64_t* perm, void* stream) {
   if (!lay || H < 0 || !extreme) return RUA_EINVAL;
+  if (perm && lay->kind != RUA_CAT) return RUA_EINVAL;
   const int reset = (op & RUA_OP_SCRATCH_CLEAN) ? 1 : 0;
   op &= 0xff;
   if (op != RUA_MAX && op != RUA_MIN && op != RUA_LOGSUMEXP) return RUA_EINVAL;
@@ -148,10 +149,10 @@ int rua_fill_empty(const rua_layout* lay, void* out, int64_t H, int32_t dtype, i
   hipStream_t s = (hipStream_t)stream;
   const int wmax = op == RUA_MIN ? 1 : 0;
   switch (dtype) {
-    case RUA_F32: return fill_empty_f32(s, *lay, out, H, wmax, extreme, reset);
-    case RUA_BF16: return fill_empty_bf16(s, *lay, out, H, wmax, extreme, reset);
-    case RUA_F16: return fill_empty_f16(s, *lay, out, H, wmax, extreme, reset);
-    case RUA_F64: return fill_empty_f64(s, *lay, out, H, wmax, extreme, reset);
+    case RUA_F32: return fill_empty_f32(s, *lay, out, H, wmax, extreme, reset, data, perm);
+    case RUA_BF16: return fill_empty_bf16(s, *lay, out, H, wmax, extreme, reset, data, perm);
+    case RUA_F16: return fill_empty_f16(s, *lay, out, H, wmax, extreme, reset, data, perm);
+    case RUA_F64: return fill_empty_f64(s, *lay, out, H, wmax, extreme, reset, data, perm);
     default: return RUA_EINVAL;
   }
 }

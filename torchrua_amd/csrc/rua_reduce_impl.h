@@ -1000,7 +1000,8 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_extreme_kernel(rua_layout L, con
   }
 }
 
-// extreme scratch: [0..63] hashed slots (zero-neutral, see seg_extreme_kernel), [64] flags, [65] a ticket counter.
+// extreme scratch (67 words): [0..63] hashed slots (zero-neutral, see seg_extreme_kernel), [64] flags, [65] a ticket
+// counter, [66] the grid barrier of extreme_fill_kernel.
 // `reset`: the scratch is the caller's persistent, zeroed buffer (RUA_OP_SCRATCH_CLEAN): the LAST workgroup to have
 // read it (ticket) puts it back to zero, so the next call needs no initialising launch either.
 template <typename T>
@@ -1020,7 +1021,7 @@ __global__ __launch_bounds__(RUA_BLOCK) void fill_empty_kernel(rua_layout L, T* 
     __threadfence();
     const unsigned long long t = atomicAdd(&ext[EXTREME_SLOTS + 1], 1ull);
     if (t == (unsigned long long)gridDim.x - 1ull) {
-      for (int i = 0; i < EXTREME_SLOTS + 2; ++i) ext[i] = 0ull;
+      for (int i = 0; i < EXTREME_SLOTS + 3; ++i) ext[i] = 0ull;
       __threadfence();
     }
   }
@@ -1031,9 +1032,9 @@ __device__ __forceinline__ void fill_empty_body(const rua_layout& L, T* __restri
                                                 int want_max_of_data, const unsigned long long* __restrict__ ext,
                                                 unsigned long long flags) {
   using A = typename elem<T>::acc;
-  // decode the tracked extreme: lane i reads slot i, 6-step butterfly
+  // decode the tracked extreme: lane i reads slot i (past this CU's L1: other workgroups' atomics wrote it), 6-step butterfly
   const int lane = threadIdx.x & (RUA_WAVE - 1);
-  unsigned long long best = ext[lane];
+  unsigned long long best = __hip_atomic_load(&ext[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
   for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {
     const unsigned long long o = __shfl_xor(best, d, RUA_WAVE);
@@ -1048,16 +1049,87 @@ __device__ __forceinline__ void fill_empty_body(const rua_layout& L, T* __restri
 
   // only empty sequences (or everything, when a NaN poisoned `initial`) are written.  A lane inspects one sequence,
   // then the wave writes the marked rows together, lanes side by side along H (coalesced stores; the poisoned case
-  // rewrites the whole [B, H] output and used to do it one scalar store per thread)
-  const int64_t b0 = ((int64_t)blockIdx.x * RUA_WAVES_PER_BLOCK + (threadIdx.x >> 6)) * RUA_WAVE;
-  const int64_t b = b0 + lane;
-  const bool mine = b < L.B && (poison || seq_len(L, b) <= 0);
-  unsigned long long todo = __ballot(mine);
-  while (todo) {
-    const int k = __ffsll((long long)todo) - 1;
-    todo &= todo - 1;
-    T* o = out + (b0 + k) * H;
-    for (int64_t h = lane; h < H; h += RUA_WAVE) o[h] = tv;
+  // rewrites the whole [B, H] output).  Workgroups stride over the batch (the merged kernel's grid is capped).
+  for (int64_t base = (int64_t)blockIdx.x * RUA_BLOCK; base < L.B; base += (int64_t)gridDim.x * RUA_BLOCK) {
+    const int64_t b0 = base + (int64_t)(threadIdx.x >> 6) * RUA_WAVE;
+    const int64_t b = b0 + lane;
+    const bool mine = b < L.B && (poison || seq_len(L, b) <= 0);
+    unsigned long long todo = __ballot(mine);
+    while (todo) {
+      const int k = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      T* o = out + (b0 + k) * H;
+      for (int64_t h = lane; h < H; h += RUA_WAVE) o[h] = tv;
+    }
+  }
+}
+
+// rua_fill_empty with the payload at hand (the default from round 2): ONE trailing launch does what seg_extreme_kernel
+// + fill_empty_kernel did in two.  Common case: every workgroup reads the flag word and leaves.  Some segment empty
+// (and no NaN): phase A, the workgroups walk the payload together for its global extreme; a grid barrier — the grid
+// is capped at EXTREME_FILL_GRID workgroups so that all of them are resident, which a spinning barrier needs —;
+// phase B, they patch the empty segments.  scratch word [66] is the barrier counter.
+constexpr int64_t EXTREME_FILL_GRID = 1024;   // x 256 threads = 4 096 waves: half the chip's wave slots
+template <typename T, int EPL, bool WANT_MAX>
+__global__ __launch_bounds__(RUA_BLOCK) void extreme_fill_kernel(rua_layout L, const int64_t* __restrict__ perm,
+                                                                 const T* __restrict__ data, T* __restrict__ out,
+                                                                 int64_t H, int lp_log2, int64_t n_chunks,
+                                                                 unsigned long long* __restrict__ ext, int reset) {
+  using A = typename elem<T>::acc;
+  constexpr int OP2 = WANT_MAX ? RUA_MAX : RUA_MIN;
+  const unsigned long long flags = ext[EXTREME_SLOTS];
+  if (flags != 0ull) {
+    if ((flags & 2ull) != 0ull && (flags & 1ull) == 0ull) {   // grid-uniform: the flags are final
+      const int lane = threadIdx.x & (RUA_WAVE - 1);
+      const int64_t gw = (int64_t)blockIdx.x * RUA_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+      const int64_t nw = (int64_t)gridDim.x * RUA_WAVES_PER_BLOCK;
+      Fold<A, EPL> f;
+      fold_init<A, EPL, OP2>(f);
+      bool any = false;
+      for (int64_t wid = gw; wid < L.B * n_chunks; wid += nw) {
+        const int64_t q = wid / n_chunks;
+        const Unit<T, EPL> U = make_unit<T, EPL, false>(L, L, perm, q, wid - q * n_chunks, H, lp_log2, lane);
+        if (U.len <= 0) continue;
+        fold_rows<T, EPL, OP2, false, false>(U, 0, U.len, data, H, f, L, nullptr, lane);
+        any = true;
+      }
+      if (any) {
+        A e0 = f.acc[0];
+#pragma unroll
+        for (int e = 1; e < EPL; ++e) e0 = WANT_MAX ? fmaxx(e0, f.acc[e]) : fminx(e0, f.acc[e]);
+#pragma unroll
+        for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {
+          const A o = __shfl_xor(e0, d, RUA_WAVE);
+          e0 = WANT_MAX ? fmaxx(e0, o) : fminx(e0, o);
+        }
+        if (lane == 0) {
+          const int slot = (int)(gw & (EXTREME_SLOTS - 1));
+          if (WANT_MAX) atomicMax(&ext[slot], (unsigned long long)ordered_bits(e0));
+          else atomicMax(&ext[slot], ~(unsigned long long)ordered_bits(e0));
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __threadfence();
+        atomicAdd(&ext[EXTREME_SLOTS + 2], 1ull);
+        while (__hip_atomic_load(&ext[EXTREME_SLOTS + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
+               (unsigned long long)gridDim.x)
+          __builtin_amdgcn_s_sleep(16);
+        __threadfence();
+      }
+      __syncthreads();
+    }
+    fill_empty_body<T>(L, out, H, WANT_MAX ? 1 : 0, ext, flags);
+  }
+  if (!reset) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned long long t = atomicAdd(&ext[EXTREME_SLOTS + 1], 1ull);
+    if (t == (unsigned long long)gridDim.x - 1ull) {
+      for (int i = 0; i < EXTREME_SLOTS + 3; ++i) ext[i] = 0ull;
+      __threadfence();
+    }
   }
 }
 
@@ -1404,6 +1476,29 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
                                split, ws, ties, ties_final, self_in);
 }
 
+template <typename T>
+static int launch_extreme_fill(hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data, void* out,
+                               int64_t H, int want_max, void* ext, int reset) {
+  constexpr int FULL = 16 / sizeof(T);
+  const bool vec_ok = (H % FULL == 0) && ((uintptr_t)data % 16 == 0);
+  const int64_t lpr = (H + (vec_ok ? FULL : 1) - 1) / (vec_ok ? FULL : 1);
+  int lp_log2 = 0;
+  while ((1 << lp_log2) < lpr && lp_log2 < 6) ++lp_log2;
+  const int64_t n_chunks = (lpr + RUA_WAVE - 1) / RUA_WAVE;
+  int64_t grid = (L.B + RUA_BLOCK - 1) / RUA_BLOCK;
+  if (grid > EXTREME_FILL_GRID) grid = EXTREME_FILL_GRID;
+  if (grid < 1) grid = 1;
+  const dim3 g((unsigned)grid), b(RUA_BLOCK);
+  unsigned long long* e = (unsigned long long*)ext;
+#define RUA_EF(EPLV, WMAX)                                                                                        \
+  hipLaunchKernelGGL((extreme_fill_kernel<T, EPLV, WMAX>), g, b, 0, s, L, perm, (const T*)data, (T*)out, H, lp_log2, \
+                     n_chunks, e, reset)
+  if (want_max) { if (vec_ok) RUA_EF(FULL, true); else RUA_EF(1, true); }
+  else { if (vec_ok) RUA_EF(FULL, false); else RUA_EF(1, false); }
+#undef RUA_EF
+  return (int)hipGetLastError();
+}
+
 // ---- per-dtype entry points: each element type is compiled in its own translation unit
 // (rua_reduce_<dtype>.hip) so the ~300 kernel instantiations build in parallel
 #define RUA_DECLARE_REDUCE_DTYPE(NAME)                                                                              \
@@ -1414,7 +1509,7 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
                       const void* out, const void* gout, void* gin, int64_t H, int extra_count, int64_t split,    \
                       void* ws, void* ties, bool ties_final, const void* self_in);                                 \
   int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, void* ext,        \
-                        int reset);                                                                              \
+                        int reset, const void* data, const int64_t* perm);                                       \
   int self_grad_##NAME(hipStream_t s, const int64_t* counts, int64_t S, int64_t H, const void* self_in,            \
                        const void* out, const void* gout, const void* aux, void* gself, int op, int inc);
 RUA_DECLARE_REDUCE_DTYPE(f32)
@@ -1437,7 +1532,8 @@ RUA_DECLARE_REDUCE_DTYPE(f64)
                                 self_in);                                                                          \
   }                                                                                                                 \
   int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, void* ext,        \
-                        int reset) {                                                                             \
+                        int reset, const void* data, const int64_t* perm) {                                      \
+    if (data) return launch_extreme_fill<T>(s, L, perm, data, out, H, want_max, ext, reset);                        \
     hipLaunchKernelGGL(fill_empty_kernel<T>, dim3(grid_for(L.B)), dim3(RUA_BLOCK), 0, s, L, (T*)out, H, want_max,  \
                        (unsigned long long*)ext, reset);                                                           \
     return (int)hipGetLastError();                                                                                  \

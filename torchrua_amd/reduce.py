@@ -284,13 +284,16 @@ def pack_reduce(sequence: Z, op: str = 'sum'):
         O._kernel_hook('pack_reduce', True)
     try:
         K.check(lib.rua_pack_reduce(src.ref(), dst.ref(), K.ptr(data), K.ptr(pdata), K.ptr(out), H, K.DTYPES[data.dtype],
-                                    code | op_bits, O._bits(O._EMPTY[code], data.dtype), K.ptr(extreme), split, K.ptr(ws),
+                                    code | op_bits | (K.OP_NO_EMPTY if extreme is not None else 0),
+                                    O._bits(O._EMPTY[code], data.dtype), K.ptr(extreme), split, K.ptr(ws),
                                     K.stream_ptr(dev)), 'rua_pack_reduce')
         if O._kernel_hook:
             O._kernel_hook('pack_reduce', False)
         if extreme is not None:
+            walk = not (op_bits & K.OP_NO_EMPTY)
             K.check(lib.rua_fill_empty(src.ref(), K.ptr(out), H, K.DTYPES[data.dtype], code | (op_bits & K.OP_SCRATCH_CLEAN),
-                                       K.ptr(extreme), K.stream_ptr(dev)), 'rua_fill_empty')
+                                       K.ptr(extreme), K.ptr(data) if walk else None, None, K.stream_ptr(dev)),
+                    'rua_fill_empty')
     except K.RuaError:
         O.forget_extreme_scratch(dev)
         raise
