@@ -1,2 +1,3 @@
 set -e
-timeout -k 10 300 python -m pytest tests/test_gpu_regressions.py -x -q -m gpu -k "grid_that_hits" 2>&1 | tail -3
+python -c "import __graft_entry__ as g; g.smoke()"
+python -m pytest tests -x -q -m gpu 2>&1 | tail -2
