@@ -1,3 +1,3 @@
 set -e
-timeout -k 10 560 python scripts/soak.py 500 777 > gpurun_out/soak_r2_b.txt 2>&1 || { tail -30 gpurun_out/soak_r2_b.txt; exit 1; }
-tail -2 gpurun_out/soak_r2_b.txt
+python scripts/tile2d_ab.py > gpurun_out/tile2d.txt 2>&1 || { tail -20 gpurun_out/tile2d.txt; exit 1; }
+cat gpurun_out/tile2d.txt
