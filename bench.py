@@ -279,21 +279,26 @@ def main():
             'value': extra['value_device_lens'], 'unit': 'M elements/s', 'ms_per_step': round(dl_ms, 4), 'steps': k,
             'frac_of_hbm_peak_wall': round((3.0 * N * H * e + 1.0 * B * H * e + 8.0 * (4 * B + T)) / (dl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         # extension, reported beside the graded pipeline: pack + reduce fused into one pass (same outputs)
+        p_ref = p
         del p
         for _ in range(2):      # allocator warm-up for the fused variant's buffers
-            pf, of = ta.pack_reduce(ta.with_host_sizes(data, lens_host), 'sum')
+            pf, of = ta.pack_reduce(ta.with_host_sizes(data, lens_host), 'sum', fused=True)
         sync()
         timer.enabled = True
         t2 = time.perf_counter()
         for _ in range(k):
-            pf, of = ta.pack_reduce(ta.with_host_sizes(data, lens_host), 'sum')
+            pf, of = ta.pack_reduce(ta.with_host_sizes(data, lens_host), 'sum', fused=True)
         sync()
         fused_ms = (time.perf_counter() - t2) / k * 1e3
         timer.enabled = False
-        assert torch.equal(of, out) and pf.data.shape == data.shape
+        # the same PackedSequence; the sums are the same fp32 accumulation (bit-identical whenever both paths give a
+        # sequence to one wave, as at the north-star shape; few-but-long batches fold through a team of waves in the
+        # two-kernel path, which associates the partial sums differently)
+        assert torch.equal(pf.data, p_ref.data) and pf.data.shape == data.shape
+        assert torch.allclose(of.float(), out.float(), rtol=2 ** -7, atol=1e-2)
         extra['fused_pack_reduce'] = {
             'ms_per_step': round(fused_ms, 4), 'value': round(N * H / (fused_ms * 1e-3) / 1e6, 1),
-            'kernel_ms': round(timer.mean_ms('pack_reduce'), 4),
+            'kernel_ms': round(timer.mean_ms('pack_reduce') or 0.0, 4),
             'hbm_bytes_moved': 2.0 * N * H * e + 1.0 * B * H * e,
             'note': 'one kernel returns the PackedSequence AND the [B,H] sums; 2/3 of the pipeline traffic'}
 

@@ -190,8 +190,9 @@ int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* d
 /* Fused pack + reduce (an EXTENSION: the reference has no one-call equivalent; it is exactly
  * core/cast.py:41-49 followed by the reduction of reduce.py:34-61 over the packed rows).  One pass over
  * the payload of `src` (CAT/LEFT/RIGHT): every row is stored to its row of the PackedSequence `pack`
- * (boff[t] + unsorted[b]) AND folded into out[b, :].  Bit-identical to rua_move_rows(pack <- src) followed
- * by rua_segment_reduce(pack), at 2/3 of the HBM traffic.  Needs H*sizeof(dtype) % 16 == 0 and 16-byte
+ * (boff[t] + unsorted[b]) AND folded into out[b, :].  The same PackedSequence, bit for bit, as rua_move_rows(pack <- src);
+ * the same fp32 accumulation as rua_segment_reduce(pack) (bit-identical whenever that call gives each sequence to one wave —
+ * few-but-long batches go through a team of waves there, which associates the partial sums differently), at 2/3 of the HBM traffic.  Needs H*sizeof(dtype) % 16 == 0 and 16-byte
  * aligned pointers (returns RUA_EALIGN otherwise: run the two-call form). */
 int rua_pack_reduce(const rua_layout* src, const rua_layout* pack, const void* data, void* pack_data, void* out,
                     int64_t H, int32_t dtype, int32_t op, uint64_t empty_bits, void* extreme, int64_t split_rows,

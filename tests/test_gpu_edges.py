@@ -338,7 +338,7 @@ def test_long_sequences_are_split(hidden, dtype):
                 'segment(blind)': getattr(ta, f'segment_{name}')(dd.to(DEV), blind.token_sizes),
                 'reduce(P)': getattr(ta, f'reduce_{name}')(kc.pack())}
         if hidden % (16 // data.element_size()) == 0:
-            pf, of = ta.pack_reduce(kc, name)
+            pf, of = ta.pack_reduce(kc, name, fused=True)
             outs['fused'] = of
             assert torch.equal(pf.data, kc.pack().data)
         if hidden <= 70:

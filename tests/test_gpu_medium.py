@@ -68,7 +68,7 @@ def test_reductions_vs_oracle(shape):
         for what, got in (('segment', getattr(ta, f'segment_{name}')(c.data, c.token_sizes)),
                           ('reduce(P)', getattr(ta, f'reduce_{name}')(p)),
                           ('reduce(L)', getattr(ta, f'reduce_{name}')(c.left())),
-                          ('fused', ta.pack_reduce(c, name)[1])):
+                          ('fused', ta.pack_reduce(c, name, fused=True)[1])):
             # 1e-5 on the fp32 accumulation (scaled by the magnitude that was summed) + output rounding
             scale = np.abs(f32).max() * (lens.max().item() if name == 'sum' else 1)
             np.testing.assert_allclose(got.float().cpu().numpy(), ref, rtol=1e-5 + ulp, atol=1e-5 * scale + 1e-6,

@@ -220,7 +220,7 @@ def test_fused_pack_reduce_equals_two_calls(lens, dim, name, src, dtype):
     z = src.new(xs)
     p1 = z.pack()
     o1 = getattr(ta, f'reduce_{name}')(p1)
-    p2, o2 = ta.pack_reduce(z, name)
+    p2, o2 = ta.pack_reduce(z, name, fused=True)
     assert torch.equal(p1.data, p2.data) and torch.equal(p1.batch_sizes, p2.batch_sizes)
     assert torch.equal(p1.sorted_indices, p2.sorted_indices) and torch.equal(p1.unsorted_indices, p2.unsorted_indices)
     assert torch.equal(o1, o2) or (torch.isnan(o1) == torch.isnan(o2)).all()

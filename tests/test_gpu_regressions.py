@@ -52,7 +52,7 @@ def test_pack_with_empty_sequences(lens, hidden, dtype):
         np.testing.assert_array_equal(out, ref)
         assert torch.equal(ta.reduce_max(p), ta.reduce_max(c))
         assert torch.equal(ta.reduce_logsumexp(p), ta.reduce_logsumexp(c))
-        pf, of = ta.pack_reduce(c, 'sum')
+        pf, of = ta.pack_reduce(c, 'sum', fused=True)
         assert torch.equal(pf.data, p.data) and torch.equal(of, ta.reduce_sum(p))
 
 
@@ -281,3 +281,21 @@ def test_empty_segments_at_a_grid_that_hits_the_cap():
     d2[12345, 3] = float('nan')
     assert torch.isnan(ta.segment_max(d2, l)).all()
     assert not torch.isnan(ta.segment_max(d, l)).any()
+
+
+def test_pack_reduce_picks_the_two_kernel_form_for_few_sequences():
+    """The fused kernel gives one wave to each sequence; with a few thousand sequences the automatic choice is pack()
+    followed by the team reducer (same PackedSequence, sums in the same fp32 arithmetic); fused=True still forces
+    the one-pass kernel."""
+    g = torch.Generator().manual_seed(4)
+    lens = torch.randint(100, 400, (512,), generator=g)
+    data = torch.randn(int(lens.sum()), 64, generator=g).to(DEV)
+    c = ta.with_host_sizes(data, lens)
+    p_auto, s_auto = ta.pack_reduce(c, 'sum')
+    p_two = c.pack()
+    assert torch.equal(p_auto.data, p_two.data) and torch.equal(s_auto, ta.reduce_sum(p_two))
+    p_fused, s_fused = ta.pack_reduce(c, 'sum', fused=True)
+    assert torch.equal(p_fused.data, p_two.data)
+    torch.testing.assert_close(s_fused, s_auto, rtol=1e-5, atol=1e-4)
+    ref = torch.stack([x.sum(0) for x in torch.split(data.double(), lens.tolist())])
+    assert ((s_auto.double() - ref).abs() <= 1e-5 * torch.stack([x.abs().sum(0) for x in torch.split(data.double(), lens.tolist())])).all()

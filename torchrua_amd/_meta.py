@@ -346,7 +346,7 @@ def known_max_len(token_sizes: Optional[Tensor]) -> Optional[int]:
 
 class Lay:
     """A rua_layout plus the tensors its pointers borrow (kept alive with it)."""
-    __slots__ = ('c', 'keep', 'kind', 'n_rows', 'B', 'max_len', 'no_empty')
+    __slots__ = ('c', 'keep', 'kind', 'n_rows', 'B', 'max_len', '_no_empty')
 
     def __init__(self, keep: List[Optional[Tensor]], max_len: Optional[int] = None, **fields):
         self.c = L.RuaLayout(**fields)
@@ -355,10 +355,18 @@ class Lay:
         self.n_rows = fields['n_rows']
         self.B = fields['B']
         self.max_len = max_len      # longest sequence, when the host knows it for free
-        self.no_empty = False       # the host knows that every sequence holds a row (set by the lay_* builders)
+        self._no_empty = False      # bool, or a callable that decides on first use (set by the lay_* builders)
 
     def ref(self):
         return ctypes.byref(self.c)
+
+    @property
+    def no_empty(self) -> bool:
+        """The host knows WITHOUT a device sync that every sequence holds at least one row (decided on first use:
+        only max / min / logsumexp ask)."""
+        if callable(self._no_empty):
+            self._no_empty = bool(self._no_empty())
+        return self._no_empty
 
 
 def lay_cat(lens: Optional[Tensor], B: int, n_rows: int, len_add: int = 0) -> Lay:
@@ -369,7 +377,7 @@ def lay_cat(lens: Optional[Tensor], B: int, n_rows: int, len_add: int = 0) -> La
     off = dev_off(lens)
     mx = known_max_len(lens)
     lay = Lay([lens, off], max_len=None if mx is None else mx + len_add, kind=L.CAT, n_rows=n_rows, B=B, lens=L.ptr(lens), len_add=len_add, off=L.ptr(off))
-    lay.no_empty = len_add >= 0 and known_no_empty(lens)
+    lay._no_empty = (lambda: known_no_empty(lens)) if len_add >= 0 else False
     return lay
 
 
@@ -387,7 +395,7 @@ def lay_padded(kind: int, lens: Optional[Tensor], B: int, T_phys: int, T_log: in
             f['off'] = L.ptr(off)
     mx = len_add if lens is None else known_max_len(lens)
     lay = Lay(keep, max_len=mx if lens is None or mx is None else mx + len_add, **f)
-    lay.no_empty = (len_add > 0) if lens is None else (len_add >= 0 and known_no_empty(lens))
+    lay._no_empty = (len_add > 0) if lens is None else ((lambda: known_no_empty(lens)) if len_add >= 0 else False)
     return lay
 
 
@@ -441,7 +449,7 @@ def lay_pack(p, lens: Optional[Tensor] = None, len_add: int = 0, boff: Optional[
               lens=L.ptr(lens), len_add=len_add, boff=L.ptr(boff), T=T, sorted=L.ptr(p.sorted_indices),
               unsorted=L.ptr(p.unsorted_indices), **extra)
     # batch_sizes[0] counts the sequences that hold a row (a host tensor): all of them, unless some are empty
-    lay.no_empty = len_add == 0 and T == p.batch_sizes.numel() and T > 0 and pack_B(p) == pack_nseq(p)
+    lay._no_empty = len_add == 0 and T == p.batch_sizes.numel() and T > 0 and pack_B(p) == pack_nseq(p)
     return lay
 
 
