@@ -1,2 +1,2 @@
 set -e
-python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+python scripts/reduce_ab.py

@@ -16,7 +16,10 @@
 
 namespace rua {
 
-constexpr int UNROLL_T = 8;
+#ifndef RUA_UNROLL_T
+#define RUA_UNROLL_T 8
+#endif
+constexpr int UNROLL_T = RUA_UNROLL_T;
 constexpr int EXTREME_SLOTS = 64;  // contention spreading for the global min/max tracker
 
 // ---------------------------------------------------------------- element conversion
