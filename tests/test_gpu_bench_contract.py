@@ -28,6 +28,11 @@ def test_bench_json_line():
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and 'traffic' in r
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and 'sample' in c
+    ct = d['cpu_baseline_torch']                      # the stock-torch leg, cores stated
+    assert ct['kind'] == 'stock torch' and ct['cores'] >= 1 and ct['value'] > 0 and 'pack_sequence' in ct['sample']
+    dl = d['device_lens']                             # the reference-signature call, first class with its own fraction
+    assert dl['value'] > 0 and 0 < dl['frac_of_hbm_peak_wall'] < 1 and d['value_device_lens'] == dl['value']
+    assert 'traffic_source' in r and d['config']['ranks_reported_by_process_group'] == 1
     assert d['value'] > 0 and d['ms_per_step'] > 0
 
 
