@@ -114,3 +114,21 @@ def test_host_sort_policy(monkeypatch):
     monkeypatch.setattr(M, '_host_sort_threads', None)
     monkeypatch.setenv('RUA_HOST_SORT', '3')
     assert torch.equal(M.host_sort_desc(keys), ref) and M._host_sort_threads == 3
+
+
+@pytest.mark.parametrize('sanitizer', ['thread', 'address,undefined'])
+def test_host_sort_under_sanitizers(tmp_path, sanitizer):
+    """The host sort keeps worker threads and a grow-only scratch between calls: build it with the sanitizers (CPU
+    build only — the GPU pool has none) and hammer it from three threads at once (tests/c/host_sort_stress.cpp)."""
+    import shutil
+    import subprocess
+    if not shutil.which('g++'):
+        pytest.skip('no g++')
+    exe = str(tmp_path / 'stress')
+    subprocess.run(['g++', '-O1', '-g', '-std=c++17', f'-fsanitize={sanitizer}', '-pthread',
+                    '-I', os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'c', 'host_sort_stress.cpp'),
+                    os.path.join(ROOT, 'torchrua_amd', 'csrc', 'rua_host.cpp'), '-o', exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'mismatches 0' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    assert 'WARNING: ThreadSanitizer' not in out.stderr and 'ERROR: AddressSanitizer' not in out.stderr \
+        and 'runtime error' not in out.stderr, out.stderr[-4000:]
