@@ -112,11 +112,12 @@ __device__ __forceinline__ int64_t apply_tmap(int32_t tmap, int64_t arg, int64_t
 //   returns  for lane i < nw: k = largest index with f(k) <= j0 + i, fk = f(k); false = the window ran out for
 //            this lane (more than ~48 boundaries inside the wave's rows: runs of zero-length sequences) -> the
 //            caller falls back to its own binary search.  ALL 64 lanes must call.
+// part 1: the 64-ary search for row j0 and the window f(lo .. lo + 63) that starts at or just before its answer
 template <typename F>
-__device__ __forceinline__ bool coop_resolve(F f, int64_t n_total, int64_t j0, int nw, int lane, int64_t& k,
-                                             int64_t& fk) {
+__device__ __forceinline__ void coop_window(F f, int64_t n_total, int64_t j0, int lane, int64_t& lo, int64_t& W) {
   constexpr int64_t BIG = 0x7fffffffffffffffLL;
-  int64_t lo = 0, n = n_total;
+  int64_t n = n_total;
+  lo = 0;
   while (n > 16) {                                   // wave-uniform
     const int64_t step = (n + 63) >> 6;
     const int64_t at = (int64_t)lane * step;
@@ -127,11 +128,13 @@ __device__ __forceinline__ bool coop_resolve(F f, int64_t n_total, int64_t j0, i
     lo += adv;
     n = (n - adv) < step ? (n - adv) : step;
   }
-  const int64_t W = (lo + lane < n_total) ? f(lo + lane) : BIG;      // the window: f(lo .. lo + 63)
-  // every lane counts the window entries <= its own row: a 6-step binary search through the (sorted) window by
-  // lane shuffles — all 64 lanes search at once (a ballot per row would serialise the wave's rows)
-  (void)nw;
-  const int64_t x = j0 + lane;
+  W = (lo + lane < n_total) ? f(lo + lane) : BIG;
+}
+
+// part 2: every lane counts the window entries <= its own row x (x >= j0): a 6-step binary search through the
+// (sorted) window by lane shuffles — all 64 lanes search at once (a ballot per row would serialise the wave's rows).
+// ALL 64 lanes must call.  false = the window ran out before x.
+__device__ __forceinline__ bool coop_lookup(int64_t W, int64_t lo, int64_t n_total, int64_t x, int64_t& k, int64_t& fk) {
   int mine = 0;
 #pragma unroll
   for (int s = RUA_WAVE / 2; s >= 1; s >>= 1) {
@@ -144,6 +147,15 @@ __device__ __forceinline__ bool coop_resolve(F f, int64_t n_total, int64_t j0, i
   k = lo + mine - 1;
   fk = __shfl(W, mine - 1, RUA_WAVE);
   return !(mine == RUA_WAVE && lo + RUA_WAVE < n_total);
+}
+
+template <typename F>
+__device__ __forceinline__ bool coop_resolve(F f, int64_t n_total, int64_t j0, int nw, int lane, int64_t& k,
+                                             int64_t& fk) {
+  (void)nw;
+  int64_t lo, W;
+  coop_window(f, n_total, j0, lane, lo, W);
+  return coop_lookup(W, lo, n_total, j0 + lane, k, fk);
 }
 
 }  // namespace rua

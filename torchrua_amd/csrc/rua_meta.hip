@@ -215,44 +215,58 @@ __global__ __launch_bounds__(RUA_BLOCK) void lens_from_pack_kernel(const int64_t
 }
 
 // ------------------------------------------------------------------ ptr() / idx()
+constexpr int ENUM_CHUNKS = 4;     // 64-token chunks one wave enumerates from ONE search + window
 __global__ __launch_bounds__(RUA_BLOCK) void enum_rows_kernel(rua_layout L, int64_t n, int64_t* __restrict__ bp,
                                                               int64_t* __restrict__ tp,
                                                               int64_t* __restrict__ flat) {
-  // a wave owns 64 consecutive tokens and resolves them together (coop_resolve: a 64-ary search + one window
-  // instead of a 9-17 step binary search per token); a lane that the window does not cover searches by itself
+  // a wave owns 256 consecutive tokens: ONE 64-ary search for the first of them and one 64-entry window
+  // (coop_window), from which every lane reads the answers of its four tokens (coop_lookup); a token the window
+  // does not reach (more than ~60 sequence starts inside the wave's tokens) searches by itself
   const int lane = threadIdx.x & (RUA_WAVE - 1);
-  const int64_t j0 = ((int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x) - lane;
+  const int64_t wave_id = ((int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x) >> 6;
+  const int64_t j0 = wave_id * (RUA_WAVE * ENUM_CHUNKS);
   if (j0 >= n) return;                                         // wave-uniform
-  const int nw = n - j0 < RUA_WAVE ? (int)(n - j0) : RUA_WAVE;
-  const int64_t j = j0 + lane;
-  const bool mine = lane < nw;
   if (!bp && !tp && (L.kind == RUA_CAT || L.kind == RUA_PACK)) {   // C.idx() / P.idx(): storage order IS token order
-    if (mine && flat) flat[j] = j;
+#pragma unroll
+    for (int c = 0; c < ENUM_CHUNKS; ++c) {
+      const int64_t j = j0 + c * RUA_WAVE + lane;
+      if (j < n && flat) flat[j] = j;
+    }
     return;
   }
-  int64_t b = 0, t = 0, row = j;
-  if (L.kind == RUA_PACK) {
-    int64_t bt = 0;
-    const bool ok = coop_resolve([&](int64_t k) { return L.boff[k]; }, L.T, j0, nw, lane, t, bt);
-    if (mine) {
-      if (!ok) { t = search_boff(L.boff, L.T, j); bt = L.boff[t]; }
-      const int64_t r = j - bt;
-      b = L.sorted ? L.sorted[r] : r;
-    }
-  } else {  // CAT / LEFT / RIGHT enumerate tokens batch-major
-    int64_t ob = 0;
+  const bool pack = L.kind == RUA_PACK;
+  const int64_t n_total = pack ? L.T : L.B;
+  const bool coop = pack ? (L.boff != nullptr) : (L.off != nullptr);
+  int64_t lo = 0, W = 0;
+  if (coop) {
+    if (pack) coop_window([&](int64_t k) { return L.boff[k]; }, n_total, j0, lane, lo, W);
+    else coop_window([&](int64_t k) { return cat_off(L, k); }, n_total, j0, lane, lo, W);
+  }
+#pragma unroll
+  for (int c = 0; c < ENUM_CHUNKS; ++c) {
+    const int64_t j = j0 + c * RUA_WAVE + lane;
+    if (j0 + c * RUA_WAVE >= n) break;                         // wave-uniform
+    const bool mine = j < n;
+    int64_t k = 0, fk = 0;
     bool ok = false;
-    if (L.off) ok = coop_resolve([&](int64_t k) { return cat_off(L, k); }, L.B, j0, nw, lane, b, ob);
-    if (mine) {
-      if (!ok) { b = search_cat(L, j); ob = cat_off(L, b); }
-      t = j - ob;
+    if (coop) ok = coop_lookup(W, lo, n_total, j, k, fk);
+    if (!mine) continue;
+    int64_t b, t, row = j;
+    if (pack) {
+      if (!ok) { k = search_boff(L.boff, L.T, j); fk = L.boff[k]; }
+      t = k;
+      const int64_t r = j - fk;
+      b = L.sorted ? L.sorted[r] : r;
+    } else {  // CAT / LEFT / RIGHT enumerate tokens batch-major
+      if (!ok) { k = search_cat(L, j); fk = cat_off(L, k); }
+      b = k;
+      t = j - fk;
       row = L.kind == RUA_CAT ? j : token_to_row(L, b, t, seq_len(L, b));
     }
+    if (bp) bp[j] = b;
+    if (tp) tp[j] = t;
+    if (flat) flat[j] = row;
   }
-  if (!mine) return;
-  if (bp) bp[j] = b;
-  if (tp) tp[j] = t;
-  if (flat) flat[j] = row;
 }
 
 // ------------------------------------------------------------------ masks
@@ -372,8 +386,8 @@ int rua_enum_rows(const rua_layout* lay, int64_t n_tokens, int64_t* batch_ptr, i
     return RUA_EINVAL;
   }
   if (n_tokens == 0) return 0;
-  hipLaunchKernelGGL(enum_rows_kernel, dim3(grid_for(n_tokens)), dim3(RUA_BLOCK), 0, (hipStream_t)stream, *lay,
-                     n_tokens, batch_ptr, token_ptr, flat);
+  hipLaunchKernelGGL(enum_rows_kernel, dim3(grid_for((n_tokens + ENUM_CHUNKS - 1) / ENUM_CHUNKS)), dim3(RUA_BLOCK), 0,
+                     (hipStream_t)stream, *lay, n_tokens, batch_ptr, token_ptr, flat);
   return (int)hipGetLastError();
 }
 
