@@ -65,7 +65,7 @@ typedef struct rua_layout {
                               e.g. a flat row gather `data[key]` against LEFT{B=1})      */
   const int64_t* tptr;     /* LIST: [M]                                     */
   /* PACK, optional: a (rank x time) tile table that lets narrow-row C/L/R <-> P transposes move
-   * multi-row runs on BOTH sides (rua_move_rows picks it up when rows are <= 128 bytes).        */
+   * multi-row runs on BOTH sides (rua_move_rows picks it up when rows are <= 64 bytes) .        */
   const int64_t* bsz;        /* device copy of batch_sizes [T]                                   */
   const int64_t* tile_start; /* [n_tchunks + 1]: tile_start[c] = sum_{c'<c} ceil(batch_sizes[16c']/16) */
   int64_t n_tchunks;         /* ceil(T / 16)                                                     */

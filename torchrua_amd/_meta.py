@@ -400,7 +400,7 @@ def lay_padded(kind: int, lens: Optional[Tensor], B: int, T_phys: int, T_log: in
 
 
 TILE_R, TILE_T = 16, 16     # (rank x time) tile of the narrow-row pack kernel
-NARROW_ROW_BYTES = 128
+NARROW_ROW_BYTES = 64      # rows up to this get the tile table (rua_move.hip: TILE_MAX_ROW_BYTES)
 
 
 class PackTiling:

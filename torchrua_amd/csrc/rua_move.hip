@@ -238,7 +238,7 @@ __global__ __launch_bounds__(BLOCK) void move_rows_kernel(rua_layout D, rua_layo
 // sub-tiles.  (At >= 1 KiB rows the same tiling changes nothing — a row already fills whole lines — so
 // wide rows keep the generic kernel.)  Phase 1 needs no search: rank r is live at time t iff r < bsz[t].
 constexpr int TR = 16, TT = 16;   // TR * TT == TILE_ROWS
-constexpr int64_t TILE_LDS_MAX_ROW_BYTES = 64;   // at or below: pack_tile_lds_kernel
+constexpr int64_t TILE_MAX_ROW_BYTES = 64;       // rows up to this take the tile kernel (pack_tile_lds_kernel)
 
 // phase 1 of both tile kernels (closed form, no search): thread i = (rank << 4) | time of the tile fills the
 // source / destination row of its token, or -1
@@ -276,52 +276,11 @@ __device__ __forceinline__ void tile_phase1(const rua_layout& Pk, const rua_layo
   s_st[i] = TO_PACK ? prow : orow;
 }
 
-template <int VEC, bool TO_PACK>
-__global__ __launch_bounds__(RUA_BLOCK) void pack_tile_kernel(rua_layout Pk, rua_layout Ot, char* __restrict__ dst,
-                                                              const char* __restrict__ src, int64_t row_bytes,
-                                                              int64_t lpr, int lp_log2, int cpr) {
-  using V = typename vec_of<VEC>::type;
-  __shared__ int64_t s_ld[TILE_ROWS];
-  __shared__ int64_t s_st[TILE_ROWS];
-
-  tile_phase1<TO_PACK>(Pk, Ot, s_ld, s_st);
-  __syncthreads();
-
-  // ---- phase 2: 4x4 sub-tiles (4 consecutive rows per wave on the time-contiguous side, the 4 waves
-  // adjacent on the rank-contiguous side)
-  const int lane = threadIdx.x & (RUA_WAVE - 1), wave = threadIdx.x >> 6;
-  const int rpw = RUA_WAVE >> lp_log2;
-  const int rsub = lane >> lp_log2;
-  const int64_t col0 = lane & ((1 << lp_log2) - 1);
-  constexpr int ENTRIES = TILE_ROWS / RUA_WAVES_PER_BLOCK;   // 64 rows per wave
-  for (int e0 = 0; e0 < ENTRIES; e0 += rpw * UNROLL) {
-    for (int c = 0; c < cpr; ++c) {
-      const int64_t col = col0 + (int64_t)c * RUA_WAVE;
-      const bool colok = col < lpr;
-      V val[UNROLL];
-      int64_t st[UNROLL];
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        const int e = e0 + u * rpw + rsub;           // this wave's e-th row: sub-tile e / 4, time step e % 4 in it
-        const int sub = e >> 2, u4 = e & 3;
-        const int i = ((((sub >> 2) << 2) + wave) << 4) + ((sub & 3) << 2) + u4;
-        st[u] = -1;
-        if (colok && e < ENTRIES) {
-          const int64_t ld = s_ld[i];
-          st[u] = s_st[i];
-          if (ld >= 0 && st[u] >= 0) val[u] = ld_row<V, false>(src + ld * row_bytes + col * VEC); else st[u] = -1;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u)
-        if (st[u] >= 0) st_row<V, false>(dst + st[u] * row_bytes + col * VEC, val[u]);
-    }
-  }
-}
-
-// Rows of at most 64 B: the same tile, staged through LDS (measured at 32-byte rows: pack 3.5 -> 4.0 TB/s, P.cat
-// 3.9 -> 4.3; at 128-byte rows the 32 KiB of LDS per tile costs more occupancy than the longer runs win: 5.3 -> 4.9,
-// so those keep the sub-tile walk above).
+// The tile goes through LDS: read in the source's contiguous order, written in the destination's (measured at 32-byte
+// rows: pack 3.5 -> 4.0 TB/s against a 4x4 sub-tile walk without staging).  Rows of 128 B and more take the generic
+// mover: since round 2 (16 KiB tiles, cooperative row resolution) it is the faster one there — 5.5 / 5.8 TB/s for
+// C->P / P->C at 128 B against 5.3 / 5.2 for the tile kernels; at 64 B the tiles win 4.8 to 3.2, at 32 B 3.9 to 1.6
+// (scripts/narrow_ab.py).
 template <int VEC, bool TO_PACK>
 __global__ __launch_bounds__(RUA_BLOCK) void pack_tile_lds_kernel(rua_layout Pk, rua_layout Ot, char* __restrict__ dst,
                                                               const char* __restrict__ src, int64_t row_bytes,
@@ -366,16 +325,10 @@ static int launch_pack_tiles(int vec, hipStream_t s, const rua_layout& Pk, const
                              const char* src, int64_t row_bytes) {
   if (Pk.n_tiles > 0x7fffffffLL) return RUA_ERANGE;
   const int64_t lpr = (row_bytes + vec - 1) / vec;
-  int lp_log2 = 0;
-  while ((1 << lp_log2) < lpr && lp_log2 < 6) ++lp_log2;
-  const int cpr = (int)((lpr + RUA_WAVE - 1) / RUA_WAVE);
   const dim3 g((unsigned)Pk.n_tiles), b(RUA_BLOCK);
   const size_t lds = (size_t)(TILE_ROWS * lpr + TILE_ROWS / 16) * vec;   // the staged tile + its padding slots
-#define RUA_LAUNCH(VEC)                                                                                         \
-  if (row_bytes <= TILE_LDS_MAX_ROW_BYTES)                                                                      \
-    hipLaunchKernelGGL((pack_tile_lds_kernel<VEC, TO_PACK>), g, b, lds, s, Pk, Ot, dst, src, row_bytes, lpr);    \
-  else                                                                                                          \
-    hipLaunchKernelGGL((pack_tile_kernel<VEC, TO_PACK>), g, b, 0, s, Pk, Ot, dst, src, row_bytes, lpr, lp_log2, cpr)
+#define RUA_LAUNCH(VEC) \
+  hipLaunchKernelGGL((pack_tile_lds_kernel<VEC, TO_PACK>), g, b, lds, s, Pk, Ot, dst, src, row_bytes, lpr)
   switch (vec) {
     case 16: RUA_LAUNCH(16); break;
     case 8:  RUA_LAUNCH(8); break;
@@ -488,7 +441,7 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
   }
   hipStream_t s = (hipStream_t)stream;
   // narrow rows between a PackedSequence and a batch-major layout: (rank x time) tiles
-  if (flags == 0 && tmap == RUA_T_SHIFT && tmap_arg == 0 && row_bytes <= 128) {
+  if (flags == 0 && tmap == RUA_T_SHIFT && tmap_arg == 0 && row_bytes <= TILE_MAX_ROW_BYTES) {
     const bool to_pack = dst->kind == RUA_PACK && (src->kind == RUA_CAT || src->kind == RUA_LEFT || src->kind == RUA_RIGHT);
     const bool from_pack = src->kind == RUA_PACK && dst->kind == RUA_CAT;   // padded destinations need the fill pass
     const rua_layout* pk = to_pack ? dst : src;
