@@ -243,24 +243,25 @@ constexpr int64_t TILE_MAX_ROW_BYTES = 64;       // rows up to this take the til
 // phase 1 of both tile kernels (closed form, no search): thread i = (rank << 4) | time of the tile fills the
 // source / destination row of its token, or -1
 template <bool TO_PACK>
-__device__ __forceinline__ void tile_phase1(const rua_layout& Pk, const rua_layout& Ot, int64_t* s_ld, int64_t* s_st) {
-  // which time chunk does this tile belong to?  largest c with tile_start[c] <= blockIdx.x.  Up to 64 chunks
+__device__ __forceinline__ void tile_phase1(const rua_layout& Pk, const rua_layout& Ot, int64_t* s_ld, int64_t* s_st,
+                                            int64_t tile) {
+  // which time chunk does this tile belong to?  largest c with tile_start[c] <= tile.  Up to 64 chunks
   // (T <= 1 024) every lane loads one entry and a ballot counts them: ONE load instead of a six-step chain of
   // dependent ones — an 8-KiB tile lives for ~8 us, most of it waiting on such chains.
   int64_t lo = 0, hi = Pk.n_tchunks;
   if (Pk.n_tchunks <= RUA_WAVE) {
     const int lane = threadIdx.x & (RUA_WAVE - 1);
     const int64_t v = lane < Pk.n_tchunks ? Pk.tile_start[lane] : 0x7fffffffffffffffLL;
-    lo = (int64_t)__popcll(__ballot(v <= (int64_t)blockIdx.x)) - 1;
+    lo = (int64_t)__popcll(__ballot(v <= tile)) - 1;
     if (lo < 0) lo = 0;
   } else {
     while (hi - lo > 1) {
       const int64_t mid = (lo + hi) >> 1;
-      if (Pk.tile_start[mid] <= (int64_t)blockIdx.x) lo = mid; else hi = mid;
+      if (Pk.tile_start[mid] <= tile) lo = mid; else hi = mid;
     }
   }
   const int64_t t0 = lo * TT;
-  const int64_t r0 = ((int64_t)blockIdx.x - Pk.tile_start[lo]) * TR;
+  const int64_t r0 = (tile - Pk.tile_start[lo]) * TR;
   const int i = threadIdx.x;
   const int64_t r = r0 + (i >> 4), t = t0 + (i & 15);
   int64_t prow = -1, orow = -1;
@@ -284,12 +285,17 @@ __device__ __forceinline__ void tile_phase1(const rua_layout& Pk, const rua_layo
 template <int VEC, bool TO_PACK>
 __global__ __launch_bounds__(RUA_BLOCK) void pack_tile_lds_kernel(rua_layout Pk, rua_layout Ot, char* __restrict__ dst,
                                                               const char* __restrict__ src, int64_t row_bytes,
-                                                              int64_t lpr) {
+                                                              int64_t lpr, int64_t tiles_per_xcd) {
   using V = typename vec_of<VEC>::type;
   __shared__ int64_t s_ld[TILE_ROWS];
   __shared__ int64_t s_st[TILE_ROWS];
 
-  tile_phase1<TO_PACK>(Pk, Ot, s_ld, s_st);
+  int64_t tile = blockIdx.x;                  // (block-uniform) one contiguous span of tiles per XCD, as in the row mover
+  if (tiles_per_xcd > 0) {
+    tile = (int64_t)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= tiles_per_xcd || tile >= Pk.n_tiles) return;
+  }
+  tile_phase1<TO_PACK>(Pk, Ot, s_ld, s_st, tile);
   __syncthreads();
 
   // ---- phase 2: the tile goes through LDS.  It is read in the SOURCE's contiguous order (consecutive lanes =
@@ -322,13 +328,15 @@ __global__ __launch_bounds__(RUA_BLOCK) void pack_tile_lds_kernel(rua_layout Pk,
 
 template <bool TO_PACK>
 static int launch_pack_tiles(int vec, hipStream_t s, const rua_layout& Pk, const rua_layout& Ot, char* dst,
-                             const char* src, int64_t row_bytes) {
-  if (Pk.n_tiles > 0x7fffffffLL) return RUA_ERANGE;
+                             const char* src, int64_t row_bytes, bool xcd_span) {
+  const int64_t per_xcd = xcd_span ? (Pk.n_tiles + 7) / 8 : 0;
+  const int64_t grid = xcd_span ? per_xcd * 8 : Pk.n_tiles;
+  if (grid > 0x7fffffffLL) return RUA_ERANGE;
   const int64_t lpr = (row_bytes + vec - 1) / vec;
-  const dim3 g((unsigned)Pk.n_tiles), b(RUA_BLOCK);
+  const dim3 g((unsigned)grid), b(RUA_BLOCK);
   const size_t lds = (size_t)(TILE_ROWS * lpr + TILE_ROWS / 16) * vec;   // the staged tile + its padding slots
 #define RUA_LAUNCH(VEC) \
-  hipLaunchKernelGGL((pack_tile_lds_kernel<VEC, TO_PACK>), g, b, lds, s, Pk, Ot, dst, src, row_bytes, lpr)
+  hipLaunchKernelGGL((pack_tile_lds_kernel<VEC, TO_PACK>), g, b, lds, s, Pk, Ot, dst, src, row_bytes, lpr, per_xcd)
   switch (vec) {
     case 16: RUA_LAUNCH(16); break;
     case 8:  RUA_LAUNCH(8); break;
@@ -441,13 +449,17 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
   }
   hipStream_t s = (hipStream_t)stream;
   // narrow rows between a PackedSequence and a batch-major layout: (rank x time) tiles
-  if (flags == 0 && tmap == RUA_T_SHIFT && tmap_arg == 0 && row_bytes <= TILE_MAX_ROW_BYTES) {
+  const int span_flags = RUA_MOVE_XCD_SPAN_ON | RUA_MOVE_XCD_SPAN_OFF;
+  if ((flags & ~span_flags) == 0 && tmap == RUA_T_SHIFT && tmap_arg == 0 && row_bytes <= TILE_MAX_ROW_BYTES) {
     const bool to_pack = dst->kind == RUA_PACK && (src->kind == RUA_CAT || src->kind == RUA_LEFT || src->kind == RUA_RIGHT);
     const bool from_pack = src->kind == RUA_PACK && dst->kind == RUA_CAT;   // padded destinations need the fill pass
     const rua_layout* pk = to_pack ? dst : src;
     if ((to_pack || from_pack) && pk->tile_start && pk->bsz && pk->n_tiles > 0 && pk->boff) {
-      return to_pack ? launch_pack_tiles<true>(vec, s, *dst, *src, (char*)dst_data, (const char*)src_data, row_bytes)
-                     : launch_pack_tiles<false>(vec, s, *src, *dst, (char*)dst_data, (const char*)src_data, row_bytes);
+      bool span = pk->n_tiles >= MOVE_SPAN_MIN_TILES;
+      if (flags & RUA_MOVE_XCD_SPAN_ON) span = true;
+      if (flags & RUA_MOVE_XCD_SPAN_OFF) span = false;
+      return to_pack ? launch_pack_tiles<true>(vec, s, *dst, *src, (char*)dst_data, (const char*)src_data, row_bytes, span)
+                     : launch_pack_tiles<false>(vec, s, *src, *dst, (char*)dst_data, (const char*)src_data, row_bytes, span);
     }
   }
   const bool big = (double)dst->n_rows * (double)row_bytes >= (double)(512ll << 20);
