@@ -145,6 +145,8 @@ int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32_t tmap, in
 /* ---- reductions ------------------------------------------------------------ */
 enum rua_dtype { RUA_F32 = 0, RUA_BF16 = 1, RUA_F16 = 2, RUA_F64 = 3 };
 #define RUA_TIES_FINAL 2   /* rua_segment_reduce_backward's include_self: see there */
+#define RUA_BWD_FILL_PADDING 0x100  /* OR-ed into that include_self: also write zeros into the rows of a padded
+                                      layout that hold no token (grad_in then needs no pre-zeroing)              */
 enum rua_op {
   RUA_SUM = 0, RUA_MEAN = 1, RUA_MAX = 2, RUA_MIN = 3, RUA_PROD = 4, RUA_LOGSUMEXP = 5
 };
@@ -202,7 +204,9 @@ int rua_pack_reduce(const rua_layout* src, const rua_layout* pack, const void* d
  * segment_reduce backward, which the reference inherits through autograd: reduce.py:34-61):
  *   SUM g | MEAN g/len | PROD g*prod(others) (zero factors handled like torch) | LOGSUMEXP g*exp(x-out) |
  *   MAX/MIN g/ties where x == out, else 0.
- * grad_in has the storage of `data`; rows of padded layouts that hold no token are NOT written.
+ * grad_in has the storage of `data`; rows of padded layouts that hold no token are NOT written unless
+ * RUA_BWD_FILL_PADDING is OR-ed into include_self (SUM / MEAN / LOGSUMEXP and MAX / MIN with RUA_TIES_FINAL then
+ * write them in the same pass: the backward runs one storage row at a time, laid out like rua_move_rows).
  * With `perm` it is the gradient w.r.t. the SOURCE rows of scatter_* (reduce.py:6-31); include_self != 0 then
  * counts the old destination row in MEAN's divisor (MAX/MIN: seed `ties` with the old row's tie, below).
  * split_rows / ws as in rua_segment_reduce.

@@ -78,7 +78,7 @@ for (B, lo, hi, H) in ((512, 8, 512, 512), (4096, 8, 512, 256), (8192, 8, 512, 5
     nb = N * H * e
     print(f'--- B={B} U({lo},{hi}) H={H}: payload {nb / 1e6:.0f} MB')
     for split in ('policy', 0, 32, 64, 128, 256):
-        M.reduce_split_rows = orig if split == 'policy' else (lambda lay, rb=0, s=split: s if lay.n_rows > s else 0)
+        M.reduce_split_rows = orig if split == 'policy' else (lambda lay, rb=0, team_ok=True, s=split: s if lay.n_rows > s else 0)
         run(f'  split={split}: segment_sum(c)', lambda: ta.segment_sum(c.data, c.token_sizes), nb)
         run(f'  split={split}: reduce_sum(p)', lambda: ta.reduce_sum(p), nb)
     M.reduce_split_rows = orig

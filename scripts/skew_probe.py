@@ -34,7 +34,7 @@ def t(name, fn):
 
 policy = M.reduce_split_rows
 for split in ('policy', 64, 256, 4096, 0):
-    M.reduce_split_rows = policy if split == 'policy' else (lambda lay, rb=0, s=split: s)
+    M.reduce_split_rows = policy if split == 'policy' else (lambda lay, rb=0, team_ok=True, s=split: s)
     tag = f'split {split}' if split else 'no split  '
     if split == 'policy':
         tag += f' (= {policy(M.lay_cat(c.token_sizes, lens.numel(), data.size(0)), H * 2)})'

@@ -35,7 +35,7 @@ for (B, lo, hi, H, tag) in ((4096, 8, 512, 256, 'cfg2'), (16384, 1, 64, 512, 'cf
     nb = data.numel() * 2 + B * H * 2
     row = []
     for split in (None, 0, 32, 64, 128, 256):
-        M.reduce_split_rows = orig if split is None else (lambda lay, rb=1024, s=split: s)
+        M.reduce_split_rows = orig if split is None else (lambda lay, rb=1024, team_ok=True, s=split: s)
         tc = timed(lambda: ta.segment_sum(c.data, c.token_sizes))
         tp = timed(lambda: ta.reduce_sum(p))
         tm = timed(lambda: ta.segment_max(c.data, c.token_sizes))

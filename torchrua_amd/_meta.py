@@ -593,7 +593,7 @@ SPLIT_FIXED_S = 30e-6        # what arming costs: one memset, a tail and a combi
 TEAM_MAX_UNITS = 16384       # rua_reduce_impl.h: units up to which a team of waves may share one unit
 
 
-def reduce_split_rows(lay: Lay, row_bytes: int = 1024) -> int:
+def reduce_split_rows(lay: Lay, row_bytes: int = 1024, team_ok: bool = True) -> int:
     """Rows per part for rua_segment_reduce, or 0 (= one wave streams each whole sequence).
 
     Splitting pays only when the longest sequence would show: one wave walks a sequence at ~WAVE_RATE, the balanced
@@ -603,7 +603,8 @@ def reduce_split_rows(lay: Lay, row_bytes: int = 1024) -> int:
     do not need it halves the rate.  The part size fills the chip (n_rows / 8192) when there are few units, and is
     raised to that threshold when there are plenty, so that only real outliers are cut.  When the host does not know
     the longest sequence (device-only lengths) the machinery is armed only where a tail could matter: long average
-    sequences or few of them."""
+    sequences or few of them.  team_ok=False: the caller's kernel has no wave teams (the backward walk, the fused
+    pack + reduce), so a unit streams at the single-wave rate."""
     n = lay.n_rows
     rb_unit = max(1, min(int(row_bytes), 1024))        # wider rows: 4 KiB per wave, 4x the loads in flight
     n_chunks = -(-int(row_bytes) // (1024 if row_bytes <= 1024 else 4096)) if row_bytes > 0 else 1
@@ -612,7 +613,7 @@ def reduce_split_rows(lay: Lay, row_bytes: int = 1024) -> int:
     # 2-4x as fast, and splitting — three launches and a pass over fp32 partials — is for real outliers only
     team = 1
     units = max(lay.B, 1) * n_chunks
-    if 0 < row_bytes <= 1024 and row_bytes % 16 == 0 and units <= TEAM_MAX_UNITS:
+    if team_ok and 0 < row_bytes <= 1024 and row_bytes % 16 == 0 and units <= TEAM_MAX_UNITS:
         lanes = -(-int(row_bytes) // 16)
         rows_per_group = max(1, 64 // (1 << max(0, (lanes - 1).bit_length()))) * 8
         groups = n // max(lay.B, 1) // rows_per_group

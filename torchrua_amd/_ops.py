@@ -155,9 +155,9 @@ def _bits(value: float, dtype: torch.dtype) -> int:
     return int.from_bytes(raw, 'little')
 
 
-def split_workspace(lay: M.Lay, H: int, dtype: torch.dtype, dev) -> Tuple[int, Optional[Tensor]]:
+def split_workspace(lay: M.Lay, H: int, dtype: torch.dtype, dev, team_ok: bool = True) -> Tuple[int, Optional[Tensor]]:
     """(split_rows, workspace) for the reducer's long-sequence splitting (0, None when it is off)."""
-    split = M.reduce_split_rows(lay, H * dtype.itemsize)
+    split = M.reduce_split_rows(lay, H * dtype.itemsize, team_ok)
     if not split:
         return 0, None
     nbytes = L.load().rua_reduce_ws_bytes(lay.n_rows, H, L.DTYPES[dtype], split)
@@ -230,15 +230,15 @@ class _Reduce(torch.autograd.Function):
         dev = L.require_device(data)
         lib = L.load()
         grad = grad.contiguous()
-        padded = lay.kind in (L.LEFT, L.RIGHT)
-        g = (torch.zeros if padded else torch.empty)(data.shape, dtype=data.dtype, device=dev)
+        g = torch.empty(data.shape, dtype=data.dtype, device=dev)   # padding rows: zeroed by the call (BWD_FILL_PADDING)
         H = 1
         for d in out.shape[1:]:
             H *= d
-        split, ws = split_workspace(lay, H, data.dtype, dev)
+        split, ws = split_workspace(lay, H, data.dtype, dev, team_ok=False)      # (the backward walk has no wave teams)
         ties = ctx.ties                        # max/min: counted by the forward -> apply only (TIES_FINAL)
         L.check(lib.rua_segment_reduce_backward(lay.ref(), None, L.ptr(data), L.ptr(out), L.ptr(grad), L.ptr(g), H,
-                                                L.DTYPES[data.dtype], op, L.TIES_FINAL if ties is not None else 0,
+                                                L.DTYPES[data.dtype], op,
+                                                (L.TIES_FINAL if ties is not None else 0) | L.BWD_FILL_PADDING,
                                                 split, L.ptr(ws), L.ptr(ties), None, L.stream_ptr(dev)),
                 'rua_segment_reduce_backward')
         return g, None, None, None, None

@@ -17,7 +17,7 @@ __global__ void extreme_init_entry_kernel(unsigned long long* ext, int want_max_
                     const rua_layout* CD, void* copy, void* ties, bool no_empty);                                  \
   int backward_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,           \
                       const void* out, const void* gout, void* gin, int64_t H, int extra_count, int64_t split,    \
-                      void* ws, void* ties, bool ties_final, const void* self_in);                                 \
+                      void* ws, void* ties, bool ties_final, const void* self_in, bool fill_padding);              \
   int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, void* ext,        \
                         int reset, const void* data, const int64_t* perm);                                       \
   int self_grad_##NAME(hipStream_t s, const int64_t* counts, int64_t S, int64_t H, const void* self_in,            \
@@ -44,12 +44,14 @@ int rua_segment_reduce_backward(const rua_layout* lay, const int64_t* perm, cons
   if (lay->B == 0 || H == 0 || lay->n_rows == 0) return 0;
   if (!data || !out || !grad_out || !grad_in) return RUA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  const bool fill = (include_self & RUA_BWD_FILL_PADDING) != 0;
+  include_self &= 0xff;
   const bool final = include_self == RUA_TIES_FINAL && ties != nullptr;   // the forward counted them (ties_out)
   switch (dtype) {
-    case RUA_F32: return backward_f32(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final, self_in);
-    case RUA_BF16: return backward_bf16(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final, self_in);
-    case RUA_F16: return backward_f16(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final, self_in);
-    case RUA_F64: return backward_f64(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final, self_in);
+    case RUA_F32: return backward_f32(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final, self_in, fill);
+    case RUA_BF16: return backward_bf16(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final, self_in, fill);
+    case RUA_F16: return backward_f16(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final, self_in, fill);
+    case RUA_F64: return backward_f64(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final, self_in, fill);
   }
   return RUA_EINVAL;
 }

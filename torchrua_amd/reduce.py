@@ -164,7 +164,7 @@ class _Scatter(torch.autograd.Function):
                 ties, mode, self_in = ctx.ties, K.TIES_FINAL, tensor_c
             elif op == K.PROD and inc:
                 self_in = tensor_c
-            split, ws = O.split_workspace(ctx.lay, H, source.dtype, dev)
+            split, ws = O.split_workspace(ctx.lay, H, source.dtype, dev, team_ok=False)
             K.check(lib.rua_segment_reduce_backward(ctx.lay.ref(), K.ptr(ctx.perm), K.ptr(source.contiguous()),
                                                     K.ptr(out), K.ptr(grad), K.ptr(g_src), H, dt, op, mode, split,
                                                     K.ptr(ws), K.ptr(ties), K.ptr(self_in), K.stream_ptr(dev)),
@@ -289,7 +289,7 @@ def pack_reduce(sequence: Z, op: str = 'sum', fused: bool = None):
     src = describe(sequence)
     out = torch.empty((B,) + hidden, dtype=data.dtype, device=dev)
     extreme, op_bits = O.extreme_scratch(dev, src) if code in (K.MAX, K.MIN, K.LOGSUMEXP) else (None, 0)
-    split, ws = O.split_workspace(src, H, data.dtype, dev)
+    split, ws = O.split_workspace(src, H, data.dtype, dev, team_ok=False)      # (the fused kernel has no wave teams)
     if O._kernel_hook:
         O._kernel_hook('pack_reduce', True)
     try:
