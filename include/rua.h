@@ -241,7 +241,8 @@ int rua_scatter_self_grad(const int64_t* counts, int64_t S, int64_t H, const voi
 /* After rua_segment_reduce / rua_pack_reduce with `extreme` (MAX/MIN/LOGSUMEXP): write the global extreme into the
  * rows of empty sequences, or NaN into every row when the NaN flag is up (the reference's initial=NaN behaviour).
  * With `data` (and `perm`) — the reduce's own inputs — this call ALSO takes the rare second walk for the global
- * extreme when a segment is empty (one launch with a grid barrier inside instead of a launch of its own): pass
+ * extreme when a segment is empty (one launch — the workgroup that finishes the walk last patches the rows — instead of a
+ * launch of its own): pass
  * RUA_OP_NO_EMPTY to the reduce so that it does not arm the walk itself.  data == NULL: the reduce did it, or
  * nothing is empty. */
 int rua_fill_empty(const rua_layout* lay, void* out, int64_t H, int32_t dtype, int32_t op,

@@ -259,8 +259,8 @@ def test_runs_of_empty_sequences_between_real_ones(hidden):
 
 def test_empty_segments_at_a_grid_that_hits_the_cap():
     """max / min / logsumexp with empty segments among 300 000: the one trailing launch walks the payload for the
-    global extreme, meets at its grid barrier (the grid is capped at 1 024 workgroups so that all are resident) and
-    patches the empty rows — against the oracle, twice in a row (the persistent scratch must come back zeroed)."""
+    global extreme with its (capped) grid, the workgroup that finishes last patches the empty rows — against the oracle,
+    twice in a row (the persistent scratch must come back zeroed)."""
     g = torch.Generator().manual_seed(12)
     lens = torch.randint(0, 4, (300_000,), generator=g)
     data = torch.randn(int(lens.sum()), 8, generator=g)

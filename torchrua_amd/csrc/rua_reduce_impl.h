@@ -1161,20 +1161,20 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_extreme_kernel(rua_layout L, con
 }
 
 // extreme scratch (67 words): [0..63] hashed slots (zero-neutral, see seg_extreme_kernel), [64] flags, [65] a ticket
-// counter, [66] the grid barrier of extreme_fill_kernel.
+// counter, [66] extreme_fill_kernel's "who finished the walk last" ticket.
 // `reset`: the scratch is the caller's persistent, zeroed buffer (RUA_OP_SCRATCH_CLEAN): the LAST workgroup to have
 // read it (ticket) puts it back to zero, so the next call needs no initialising launch either.
 template <typename T>
 __device__ __forceinline__ void fill_empty_body(const rua_layout& L, T* __restrict__ out, int64_t H,
                                                 int want_max_of_data, const unsigned long long* __restrict__ ext,
-                                                unsigned long long flags);
+                                                unsigned long long flags, int64_t first_block, int64_t n_blocks);
 
 template <typename T>
 __global__ __launch_bounds__(RUA_BLOCK) void fill_empty_kernel(rua_layout L, T* __restrict__ out, int64_t H,
                                                                int want_max_of_data,
                                                                unsigned long long* __restrict__ ext, int reset) {
   const unsigned long long flags = ext[EXTREME_SLOTS];
-  if (flags != 0ull) fill_empty_body<T>(L, out, H, want_max_of_data, ext, flags);   // rare: a NaN or an empty segment
+  if (flags != 0ull) fill_empty_body<T>(L, out, H, want_max_of_data, ext, flags, blockIdx.x, gridDim.x);   // rare: a NaN or an empty segment
   if (!reset) return;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1190,7 +1190,7 @@ __global__ __launch_bounds__(RUA_BLOCK) void fill_empty_kernel(rua_layout L, T* 
 template <typename T>
 __device__ __forceinline__ void fill_empty_body(const rua_layout& L, T* __restrict__ out, int64_t H,
                                                 int want_max_of_data, const unsigned long long* __restrict__ ext,
-                                                unsigned long long flags) {
+                                                unsigned long long flags, int64_t first_block, int64_t n_blocks) {
   using A = typename elem<T>::acc;
   // decode the tracked extreme: lane i reads slot i (past this CU's L1: other workgroups' atomics wrote it), 6-step butterfly
   const int lane = threadIdx.x & (RUA_WAVE - 1);
@@ -1210,7 +1210,7 @@ __device__ __forceinline__ void fill_empty_body(const rua_layout& L, T* __restri
   // only empty sequences (or everything, when a NaN poisoned `initial`) are written.  A lane inspects one sequence,
   // then the wave writes the marked rows together, lanes side by side along H (coalesced stores; the poisoned case
   // rewrites the whole [B, H] output).  Workgroups stride over the batch (the merged kernel's grid is capped).
-  for (int64_t base = (int64_t)blockIdx.x * RUA_BLOCK; base < L.B; base += (int64_t)gridDim.x * RUA_BLOCK) {
+  for (int64_t base = first_block * RUA_BLOCK; base < L.B; base += n_blocks * RUA_BLOCK) {
     const int64_t b0 = base + (int64_t)(threadIdx.x >> 6) * RUA_WAVE;
     const int64_t b = b0 + lane;
     const bool mine = b < L.B && (poison || seq_len(L, b) <= 0);
@@ -1226,10 +1226,11 @@ __device__ __forceinline__ void fill_empty_body(const rua_layout& L, T* __restri
 
 // rua_fill_empty with the payload at hand (the default from round 2): ONE trailing launch does what seg_extreme_kernel
 // + fill_empty_kernel did in two.  Common case: every workgroup reads the flag word and leaves.  Some segment empty
-// (and no NaN): phase A, the workgroups walk the payload together for its global extreme; a grid barrier — the grid
-// is capped at EXTREME_FILL_GRID workgroups so that all of them are resident, which a spinning barrier needs —;
-// phase B, they patch the empty segments.  scratch word [66] is the barrier counter.
-constexpr int64_t EXTREME_FILL_GRID = 1024;   // x 256 threads = 4 096 waves: half the chip's wave slots
+// (and no NaN): phase A, the workgroups walk the payload together for its global extreme; the workgroup that
+// finishes LAST (a ticket in scratch word [66]) then patches the empty segments by itself — no grid barrier: a
+// spinning barrier needs every workgroup resident at once, which concurrent launches on other streams could deny
+// (a hang is not a price for the rare path: one workgroup writes ~100 GB/s, 64 MB of empty rows in under a ms).
+constexpr int64_t EXTREME_FILL_GRID = 1024;   // workgroups of the (rare) walk; the common case only reads a flag
 template <typename T, int EPL, bool WANT_MAX>
 __global__ __launch_bounds__(RUA_BLOCK) void extreme_fill_kernel(rua_layout L, const int64_t* __restrict__ perm,
                                                                  const T* __restrict__ data, T* __restrict__ out,
@@ -1268,18 +1269,18 @@ __global__ __launch_bounds__(RUA_BLOCK) void extreme_fill_kernel(rua_layout L, c
           else atomicMax(&ext[slot], ~(unsigned long long)ordered_bits(e0));
         }
       }
+      __shared__ int s_last;
       __syncthreads();
       if (threadIdx.x == 0) {
         __threadfence();
-        atomicAdd(&ext[EXTREME_SLOTS + 2], 1ull);
-        while (__hip_atomic_load(&ext[EXTREME_SLOTS + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
-               (unsigned long long)gridDim.x)
-          __builtin_amdgcn_s_sleep(16);
+        s_last = atomicAdd(&ext[EXTREME_SLOTS + 2], 1ull) == (unsigned long long)gridDim.x - 1ull;
         __threadfence();
       }
       __syncthreads();
+      if (s_last) fill_empty_body<T>(L, out, H, WANT_MAX ? 1 : 0, ext, flags, 0, 1);   // alone, over the whole batch
+    } else {
+      fill_empty_body<T>(L, out, H, WANT_MAX ? 1 : 0, ext, flags, blockIdx.x, gridDim.x);   // NaN: no walk needed
     }
-    fill_empty_body<T>(L, out, H, WANT_MAX ? 1 : 0, ext, flags);
   }
   if (!reset) return;
   __syncthreads();
