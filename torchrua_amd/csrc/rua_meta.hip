@@ -255,7 +255,8 @@ __global__ __launch_bounds__(RUA_BLOCK) void enum_rows_kernel(rua_layout L, int6
     if (pack) {
       if (!ok) { k = search_boff(L.boff, L.T, j); fk = L.boff[k]; }
       t = k;
-      const int64_t r = j - fk;
+      int64_t r = j - fk;
+      if (r < 0 || r >= L.B) r = 0;            // a token count that does not match batch_sizes must not index out of range
       b = L.sorted ? L.sorted[r] : r;
     } else {  // CAT / LEFT / RIGHT enumerate tokens batch-major
       if (!ok) { k = search_cat(L, j); fk = cat_off(L, k); }
