@@ -132,7 +132,7 @@ def test_wrong_device_and_dtype_errors():
     with pytest.raises(ta.RuaError):
         ta.scatter_sum(torch.zeros(2, 5, device=DEV), torch.tensor([0, 1, 1, 0, 0]), c.data)   # index on the CPU
     with pytest.raises(ta.RuaError):
-        ta.scatter_max(torch.zeros(5, 2, device=DEV), torch.zeros(5, dtype=torch.long, device=DEV), c.data, dim=1)
+        ta.scatter_max(torch.zeros(5, 2, device=DEV), torch.zeros(5, dtype=torch.long, device=DEV), c.data, dim=2)   # no such dim
 
 
 def test_product_process_never_loads_the_oracle(tmp_path):

@@ -299,3 +299,38 @@ def test_pack_reduce_picks_the_two_kernel_form_for_few_sequences():
     torch.testing.assert_close(s_fused, s_auto, rtol=1e-5, atol=1e-4)
     ref = torch.stack([x.sum(0) for x in torch.split(data.double(), lens.tolist())])
     assert ((s_auto.double() - ref).abs() <= 1e-5 * torch.stack([x.abs().sum(0) for x in torch.split(data.double(), lens.tolist())])).all()
+
+
+@pytest.mark.parametrize('name', ['sum', 'mean', 'max', 'prod', 'logsumexp'])
+@pytest.mark.parametrize('dim', [1, -1, 2])
+def test_scatter_along_another_dim(name, dim):
+    """reduce.py:6-31 hand `dim` to torch.index_reduce / index_add; here any dim is brought to the front and back."""
+    g = torch.Generator().manual_seed(21)
+    t = torch.rand(3, 5, 4, generator=g) + 0.5
+    n_src = 7
+    shape = list(t.shape)
+    shape[dim] = n_src
+    src = torch.rand(shape, generator=g) + 0.5
+    idx = torch.randint(0, t.shape[dim], (n_src,), generator=g)
+    for inc in (False, True):
+        td, sd = t.to(DEV).requires_grad_(), src.to(DEV).requires_grad_()
+        out = getattr(ta, f'scatter_{name}')(td, idx.to(DEV), sd, include_self=inc, dim=dim)
+        tc, sc = t.clone().requires_grad_(), src.clone().requires_grad_()
+        if name == 'sum' and not inc:
+            ref = torch.zeros_like(tc).index_add(dim, idx, sc)
+        elif name == 'sum':
+            ref = tc.index_add(dim, idx, sc)
+        elif name == 'logsumexp':
+            d = dim % 3
+            ref = getattr(orc, 'scatter_logsumexp')(t.movedim(d, 0).contiguous().numpy(), idx.numpy(), src.movedim(d, 0).contiguous().numpy(), inc)
+            ref = torch.from_numpy(ref).movedim(0, d)
+        else:
+            ref = torch.index_reduce(tc, dim, idx, sc, {'mean': 'mean', 'max': 'amax', 'prod': 'prod'}[name], include_self=inc)
+        torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+        if name != 'logsumexp':
+            w = torch.randn(out.shape, generator=g)
+            (out * w.to(DEV)).sum().backward()
+            (ref * w).sum().backward()
+            torch.testing.assert_close(sd.grad.cpu(), sc.grad, rtol=1e-5, atol=1e-6)
+            if tc.grad is not None and td.grad is not None:
+                torch.testing.assert_close(td.grad.cpu(), tc.grad, rtol=1e-5, atol=1e-6)

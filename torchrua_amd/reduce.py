@@ -192,9 +192,17 @@ class _Scatter(torch.autograd.Function):
 
 
 def _scatter(tensor: T, index: T, source: T, op: int, include_self: bool, dim: int) -> T:
-    if dim != 0:
-        raise K.RuaError('scatter_* reduce along dim 0 (the only dim the reference uses)')
     K.require_device(tensor, index, source)
+    if dim != 0:
+        # the kernels reduce along the row dimension; any other `dim` (torch.index_reduce accepts one, the reference
+        # passes it through: reduce.py:6-31) is brought to the front and back — a strided view in, one contiguous
+        # copy inside, a view out; gradients follow the views
+        nd = tensor.dim()
+        if not -nd <= dim < nd or source.dim() != nd:
+            raise K.RuaError(f'scatter_*: dim {dim} out of range for a {nd}-d tensor')
+        d = dim % nd
+        out = _scatter(tensor.movedim(d, 0), index, source.movedim(d, 0), op, include_self, 0)
+        return out.movedim(0, d)
     if tensor.dtype not in K.DTYPES:
         raise K.RuaError(f'reductions support {list(K.DTYPES)}; got {tensor.dtype}')
     # what torch.index_add / index_reduce reject (reduce.py:6-31 inherit their checks): the kernel is launched with
