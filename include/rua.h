@@ -147,6 +147,11 @@ enum rua_dtype { RUA_F32 = 0, RUA_BF16 = 1, RUA_F16 = 2, RUA_F64 = 3 };
 #define RUA_TIES_FINAL 2   /* rua_segment_reduce_backward's include_self: see there */
 #define RUA_BWD_FILL_PADDING 0x100  /* OR-ed into that include_self: also write zeros into the rows of a padded
                                       layout that hold no token (grad_in then needs no pre-zeroing)              */
+#define RUA_BWD_TIES_POSITIVE 0x200 /* OR-ed into that include_self (MAX / MIN): tied extrema share a POSITIVE
+                                      gradient (g / ties each) and each take a non-positive one WHOLE — what
+                                      torch.segment_reduce's backward does (segment_max/min, reduce.py:34-41);
+                                      without it ties share g / ties whatever the sign (index_reduce's backward:
+                                      scatter_max/min, reduce.py:6-11)                                          */
 enum rua_op {
   RUA_SUM = 0, RUA_MEAN = 1, RUA_MAX = 2, RUA_MIN = 3, RUA_PROD = 4, RUA_LOGSUMEXP = 5
 };
@@ -203,7 +208,7 @@ int rua_pack_reduce(const rua_layout* src, const rua_layout* pack, const void* d
 /* Backward of rua_segment_reduce in one kernel (semantics of torch's
  * segment_reduce backward, which the reference inherits through autograd: reduce.py:34-61):
  *   SUM g | MEAN g/len | PROD g*prod(others) (zero factors handled like torch) | LOGSUMEXP g*exp(x-out) |
- *   MAX/MIN g/ties where x == out, else 0.
+ *   MAX/MIN g/ties where x == out, else 0 (RUA_BWD_TIES_POSITIVE: g itself when g <= 0 or NaN).
  * grad_in has the storage of `data`; rows of padded layouts that hold no token are NOT written unless
  * RUA_BWD_FILL_PADDING is OR-ed into include_self (SUM / MEAN / LOGSUMEXP and MAX / MIN with RUA_TIES_FINAL then
  * write them in the same pass: the backward runs one storage row at a time, laid out like rua_move_rows).

@@ -192,13 +192,16 @@ def test_infinities_nan_and_empty_segments_like_the_reference(lens, dtype):
 
 def test_max_min_backward_counts_come_from_the_forward():
     """The differentiable forward of max/min also counts the elements equal to the extreme (so the backward is one
-    walk): ties inside one chunk, across chunks and row groups, every layout, split sequences — against autograd through torch.segment_reduce on the CPU (positive cotangents: DESIGN §5)."""
+    walk): ties inside one chunk, across chunks and row groups, every layout, split sequences — against autograd through torch.segment_reduce on the CPU, the reference's own backend call
+    (reduce.py:34-41), with cotangents of BOTH signs: its backward lets ties share a positive gradient and hands each
+    of them a non-positive one whole."""
     g = torch.Generator().manual_seed(21)
     lens = [1, 300, 7, 64, 65, 5000, 2, 129]
     lt = torch.tensor(lens)
     for h, dtype in ((8, torch.float32), (24, torch.float32), (512, torch.float32), (130, torch.float64)):
         x = torch.randint(0, 3, (sum(lens), h), generator=g).to(dtype)
-        cot = (torch.rand(len(lens), h, generator=g) + 0.1).to(dtype)
+        cot = torch.randn(len(lens), h, generator=g).to(dtype)
+        cot[:, 0] = 0.0                                         # and a zero gradient
         for name in ('max', 'min'):
             r = x.clone().requires_grad_(True)
             ref = torch.segment_reduce(r, name, lengths=lt, unsafe=True)
@@ -211,6 +214,19 @@ def test_max_min_backward_counts_come_from_the_forward():
                 out.backward(cot.to(DEV))
                 torch.testing.assert_close(out.detach().cpu(), ref.detach())
                 torch.testing.assert_close(xs.grad.cpu(), r.grad, rtol=1e-6, atol=1e-7, msg=f'{name} {kind} h={h}')
+    # many short sequences with narrow rows (a PackedSequence then takes the adjacent-ranks kernel), signed cotangents
+    lt3 = torch.randint(1, 12, (3000,), generator=g)
+    x3 = torch.randint(0, 3, (int(lt3.sum()), 4), generator=g).float()
+    cot3 = torch.randn(3000, 4, generator=g)
+    for name in ('max', 'min'):
+        r = x3.clone().requires_grad_(True)
+        torch.segment_reduce(r, name, lengths=lt3, unsafe=True).backward(cot3)
+        for kind in 'CLPR':
+            xs = x3.clone().to(DEV).requires_grad_(True)
+            c = ta.with_host_sizes(xs, lt3)
+            z = {'C': lambda: c, 'L': c.left, 'P': c.pack, 'R': c.right}[kind]()
+            getattr(ta, f'reduce_{name}')(z).backward(cot3.to(DEV))
+            torch.testing.assert_close(xs.grad.cpu(), r.grad, rtol=1e-6, atol=1e-7, msg=f'narrow {name} {kind}')
     # a NaN result: its NaN elements are the hits and share the gradient (column 0; every sequence holds one there, so
     # the reference's NaN-poisoned `initial` changes nothing in that column)
     x = torch.tensor([[float('nan'), 1.0], [1.0, 2.0], [float('nan'), 3.0], [float('nan'), 4.0], [5.0, 0.0]])
@@ -362,14 +378,14 @@ def test_long_sequences_are_split(hidden, dtype):
         torch.testing.assert_close(x.grad, r.grad, rtol=1e-4, atol=1e-6, msg=f'backward {name}')
     # max/min with ties spread over several parts of a split sequence (phased backward: count, then apply)
     xt = torch.randint(0, 3, (sum(lens), hidden), generator=g).float()
-    for name, fn in (('max', torch.amax), ('min', torch.amin)):
+    for name in ('max', 'min'):
         x = xt.clone().to(DEV).requires_grad_(True)
         out = getattr(ta, f'segment_{name}')(x, known.token_sizes)
-        cot = torch.randn(out.shape, generator=g).to(DEV)
-        out.backward(cot)
-        r = xt.clone().to(DEV).requires_grad_(True)
-        torch.stack([fn(s_, 0) for s_ in torch.split(r, lens)]).backward(cot)     # amax/amin share among ties
-        torch.testing.assert_close(x.grad, r.grad, rtol=1e-5, atol=1e-7, msg=f'tied backward {name}')
+        cot = torch.randn(out.shape, generator=g)
+        out.backward(cot.to(DEV))
+        r = xt.clone().requires_grad_(True)                      # the reference's backend call, on the CPU
+        torch.segment_reduce(r, name, lengths=torch.tensor(lens), unsafe=True).backward(cot)
+        torch.testing.assert_close(x.grad.cpu(), r.grad, rtol=1e-5, atol=1e-7, msg=f'tied backward {name}')
     # prod with a single zero factor deep inside the longest sequence: its gradient is the product of the others
     xp = 1.0 + torch.randn(sum(lens), hidden, generator=g) * 1e-3
     xp[12345] = 0.0

@@ -20,6 +20,7 @@ CAT, LEFT, PACK, RIGHT, LIST = 0, 1, 2, 3, 4
 T_SHIFT, T_ROLL, T_REV_S, T_REV_D, T_ZERO = 0, 1, 2, 3, 4
 TIES_FINAL = 2      # rua_segment_reduce_backward include_self: `ties` came complete from the forward
 BWD_FILL_PADDING = 0x100   # ... OR-ed in: the call itself zeroes the padding rows of a padded layout
+BWD_TIES_POSITIVE = 0x200  # ... OR-ed in (max/min): torch.segment_reduce's tie rule — ties share g only where g > 0
 MOVE_SCATTER = 1
 OP_SCRATCH_CLEAN, OP_NO_EMPTY = 0x100, 0x200     # rua.h: bits OR-ed into `op` (persistent zeroed extreme scratch)
 # enum rua_dtype / rua_op

@@ -236,9 +236,11 @@ class _Reduce(torch.autograd.Function):
             H *= d
         split, ws = split_workspace(lay, H, data.dtype, dev, team_ok=False)      # (the backward walk has no wave teams)
         ties = ctx.ties                        # max/min: counted by the forward -> apply only (TIES_FINAL)
+        # segment_max/min are torch.segment_reduce in the reference (reduce.py:34-41), whose backward lets tied extrema
+        # share a positive gradient and hands each of them a non-positive one whole (BWD_TIES_POSITIVE)
         L.check(lib.rua_segment_reduce_backward(lay.ref(), None, L.ptr(data), L.ptr(out), L.ptr(grad), L.ptr(g), H,
                                                 L.DTYPES[data.dtype], op,
-                                                (L.TIES_FINAL if ties is not None else 0) | L.BWD_FILL_PADDING,
+                                                (L.TIES_FINAL if ties is not None else 0) | L.BWD_FILL_PADDING | L.BWD_TIES_POSITIVE,
                                                 split, L.ptr(ws), L.ptr(ties), None, L.stream_ptr(dev)),
                 'rua_segment_reduce_backward')
         return g, None, None, None, None

@@ -6,6 +6,7 @@
 
 namespace rua {
 constexpr int EXTREME_SLOTS_ENTRY = 64;
+constexpr int BWD_TIES_POSITIVE = 2;      // bit 1 of the kernels' extra_count (rua_reduce_impl.h)
 __global__ void extreme_init_entry_kernel(unsigned long long* ext, int want_max_of_data) {
   const int i = threadIdx.x;
   (void)want_max_of_data;                       // the slots are zero-neutral for the maximum and the minimum alike
@@ -45,13 +46,14 @@ int rua_segment_reduce_backward(const rua_layout* lay, const int64_t* perm, cons
   if (!data || !out || !grad_out || !grad_in) return RUA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const bool fill = (include_self & RUA_BWD_FILL_PADDING) != 0;
+  const int tie_rule = (include_self & RUA_BWD_TIES_POSITIVE) ? BWD_TIES_POSITIVE : 0;   // rides in extra_count
   include_self &= 0xff;
   const bool final = include_self == RUA_TIES_FINAL && ties != nullptr;   // the forward counted them (ties_out)
   switch (dtype) {
-    case RUA_F32: return backward_f32(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final, self_in, fill);
-    case RUA_BF16: return backward_bf16(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final, self_in, fill);
-    case RUA_F16: return backward_f16(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final, self_in, fill);
-    case RUA_F64: return backward_f64(op, s, *lay, perm, data, out, grad_out, grad_in, H, include_self == 1 ? 1 : 0, split_rows, ws, ties, final, self_in, fill);
+    case RUA_F32: return backward_f32(op, s, *lay, perm, data, out, grad_out, grad_in, H, (include_self == 1 ? 1 : 0) | tie_rule, split_rows, ws, ties, final, self_in, fill);
+    case RUA_BF16: return backward_bf16(op, s, *lay, perm, data, out, grad_out, grad_in, H, (include_self == 1 ? 1 : 0) | tie_rule, split_rows, ws, ties, final, self_in, fill);
+    case RUA_F16: return backward_f16(op, s, *lay, perm, data, out, grad_out, grad_in, H, (include_self == 1 ? 1 : 0) | tie_rule, split_rows, ws, ties, final, self_in, fill);
+    case RUA_F64: return backward_f64(op, s, *lay, perm, data, out, grad_out, grad_in, H, (include_self == 1 ? 1 : 0) | tie_rule, split_rows, ws, ties, final, self_in, fill);
   }
   return RUA_EINVAL;
 }

@@ -760,6 +760,19 @@ constexpr int UNROLL_B = 4;
 //              scatter_max/min with include_self); one walk writes the gradient.
 //   RANKS: as in the forward (make_unit) — the wave's row groups are adjacent ranks of a PackedSequence walking the
 //   same time steps; every group is its own sequence (per-lane len, no cross-group combine).
+// `extra_count` of the backward kernels: bit 0 = the old destination row of a scatter_* took part (MEAN's divisor,
+// PROD's factors); bit 1 = RUA_BWD_TIES_POSITIVE
+constexpr int BWD_SELF_COUNTS = 1, BWD_TIES_POSITIVE = 2;
+
+// the share of one of `c` tied extrema in the gradient g.  torch.segment_reduce's backward hands every tie the whole
+// g and then divides only the entries that are > 0 (SegmentReduce.cpp: `if (grad_input > 0) grad_input /= counter`),
+// so a negative or NaN g reaches every tie undivided; index_reduce's backward (scatter_max/min) divides always.
+template <typename A>
+__device__ __forceinline__ A tie_share(A g, A c, bool positive_only) {
+  if (positive_only && !(g > (A)0)) return g;
+  return g / (c > (A)0 ? c : (A)1);
+}
+
 template <typename T, int EPL, int OP, int TIES = 0, bool RANKS = false>
 __device__ __forceinline__ void backward_unit(const Unit<T, EPL>& U, int64_t t_lo, int64_t t_hi,
                                               const T* __restrict__ data, const T* __restrict__ out,
@@ -785,7 +798,7 @@ __device__ __forceinline__ void backward_unit(const Unit<T, EPL>& U, int64_t t_l
   }
   if (OP == RUA_MEAN) {
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) g[e] = g[e] / (A)(len + extra_count);   // +1: the old row took part (scatter_mean, include_self)
+    for (int e = 0; e < EPL; ++e) g[e] = g[e] / (A)(len + (extra_count & BWD_SELF_COUNTS));   // +1: the old row took part (scatter_mean, include_self)
   }
 
   // PROD with zeros: d/dx_i = g * prod_{j != i} x_j, which g*out/x cannot give when x_i == 0.  Whole-sequence
@@ -813,7 +826,7 @@ __device__ __forceinline__ void backward_unit(const Unit<T, EPL>& U, int64_t t_l
     for (int e = 0; e < EPL; ++e) {
       A c = ties[b * H + col + e];
       if (has_self && ((sv[e] == o[e]) || (sv[e] != sv[e] && o[e] != o[e]))) c += (A)1;
-      g[e] = g[e] / (c > (A)0 ? c : (A)1);
+      g[e] = tie_share(g[e], c, (extra_count & BWD_TIES_POSITIVE) != 0);
     }
   }
   A nz[EPL];      // PROD: product of the non-zero factors
@@ -883,10 +896,10 @@ __device__ __forceinline__ void backward_unit(const Unit<T, EPL>& U, int64_t t_l
       for (int e = 0; e < EPL; ++e) {
         if (OP == RUA_PROD) {
           zeros[e] = cnt[e];
-          if (has_self && extra_count) { if (sv[e] == (A)0) zeros[e] += (A)1; else nz[e] *= sv[e]; }
+          if (has_self && (extra_count & BWD_SELF_COUNTS)) { if (sv[e] == (A)0) zeros[e] += (A)1; else nz[e] *= sv[e]; }
         }
         else if (TIES == 1) { if (colok && rsub == 0 && cnt[e] > (A)0) atomicAdd(&ties[b * H + col + e], cnt[e]); }
-        else g[e] = g[e] / (cnt[e] > (A)0 ? cnt[e] : (A)1);   // MAX/MIN: ties share the gradient equally
+        else g[e] = tie_share(g[e], cnt[e], (extra_count & BWD_TIES_POSITIVE) != 0);   // MAX/MIN: ties share the gradient
       }
     }
   }
@@ -951,6 +964,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_ranks_kernel(rua_layout
                                                                       const T* __restrict__ out,
                                                                       const T* __restrict__ gout,
                                                                       T* __restrict__ gin, int64_t H, int lp_log2,
+                                                                      int tie_rule,
                                                                       typename elem<T>::acc* __restrict__ ties) {
   const int lane = threadIdx.x;
   const Unit<T, EPL> U = make_unit<T, EPL, false, 1, true>(L, L, nullptr, blockIdx.x, 0, H, lp_log2, lane);
@@ -961,7 +975,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_ranks_kernel(rua_layout
     t_hi = o > t_hi ? o : t_hi;
   }
   if (t_hi <= 0) return;
-  backward_unit<T, EPL, OP, TIES, true>(U, 0, t_hi, data, out, gout, gin, H, 0, lane, ties);
+  backward_unit<T, EPL, OP, TIES, true>(U, 0, t_hi, data, out, gout, gin, H, tie_rule, lane, ties);
 }
 
 // ---------------------------------------------------------------- backward, one storage row at a time
@@ -979,7 +993,7 @@ __global__ __launch_bounds__(RUA_BLOCK) void seg_backward_rows_kernel(rua_layout
                                                                       const T* __restrict__ out,
                                                                       const T* __restrict__ gout, T* __restrict__ gin,
                                                                       int64_t H, int lp_log2, int cpr, int tile_rows,
-                                                                      int64_t tiles_per_xcd,
+                                                                      int64_t tiles_per_xcd, int tie_rule,
                                                                       const typename elem<T>::acc* __restrict__ ties) {
   using A = typename elem<T>::acc;
   struct alignas(sizeof(T) * EPL) Pack { T v[EPL]; };
@@ -1101,8 +1115,7 @@ __global__ __launch_bounds__(RUA_BLOCK) void seg_backward_rows_kernel(rua_layout
               if (OP == RUA_LOGSUMEXP) gi = g * fexp(x - o);
               else {
                 const bool hit = (x == o) || (x != x && o != o);
-                const A cnt = pc.v[e];
-                gi = hit ? g / (cnt > (A)0 ? cnt : (A)1) : (A)0;
+                gi = hit ? tie_share(g, (A)pc.v[e], tie_rule != 0) : (A)0;
               }
             }
             res.v[e] = elem<T>::down(gi);
@@ -1624,7 +1637,8 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
   // (ops that read x: rows up to 1 KiB — one wave instruction per row; wider rows leave a wave one row of a 4-row
   // tile and the walk's 4.4 TB/s beats 3.5)
   const bool rows_width_ok = (op == RUA_SUM || op == RUA_MEAN) ? true : n_chunks == 1;
-  if (vec_ok && !perm && !self_in && !extra_count && rows_op && rows_width_ok && L.kind != RUA_PACK &&
+  const int tie_rule = extra_count & BWD_TIES_POSITIVE;
+  if (vec_ok && !perm && !self_in && !(extra_count & BWD_SELF_COUNTS) && rows_op && rows_width_ok && L.kind != RUA_PACK &&
       H * (int64_t)sizeof(T) >= 64) {
     const int64_t row_bytes = H * (int64_t)sizeof(T);
     int tile_rows = BROWS_MAX;
@@ -1639,7 +1653,7 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
     using A = typename elem<T>::acc;
 #define RUA_BROWS(OPV, NTV)                                                                                         \
   hipLaunchKernelGGL((seg_backward_rows_kernel<T, FULL, OPV, NTV>), gg, bb, 0, s, L, (const T*)data, (const T*)out,  \
-                     (const T*)gout, (T*)gin, H, lp_log2, (int)n_chunks, tile_rows, per_xcd, (const A*)ties)
+                     (const T*)gout, (T*)gin, H, lp_log2, (int)n_chunks, tile_rows, per_xcd, tie_rule, (const A*)ties)
 #define RUA_BROWS_OP(NTV)                                 \
   switch (op) {                                           \
     case RUA_SUM: RUA_BROWS(RUA_SUM, NTV); break;         \
@@ -1659,7 +1673,7 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
     if (e != hipSuccess) return (int)e;
   }
   if (L.kind == RUA_PACK && L.sorted && !perm && (!ties || ties_final) && lp_log2 < 6 && !(split > 0 && ws) &&
-      !extra_count && !self_in && (L.B >> (6 - lp_log2)) >= RANKS_MIN_WAVES) {
+      !(extra_count & BWD_SELF_COUNTS) && !self_in && (L.B >> (6 - lp_log2)) >= RANKS_MIN_WAVES) {
     // narrow rows of a PackedSequence: adjacent ranks share a wave instruction
     const int64_t rpw = RUA_WAVE >> lp_log2;
     const int64_t nblk = (L.B + rpw - 1) / rpw;
@@ -1667,7 +1681,7 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
     const dim3 gg((unsigned)nblk), bb(RUA_WAVE);
 #define RUA_BRANKS(EPLV, OPV, TV)                                                                                   \
   hipLaunchKernelGGL((seg_backward_ranks_kernel<T, EPLV, OPV, TV>), gg, bb, 0, s, L, (const T*)data,              \
-                     (const T*)out, (const T*)gout, (T*)gin, H, lp_log2, (typename elem<T>::acc*)ties)
+                     (const T*)out, (const T*)gout, (T*)gin, H, lp_log2, tie_rule, (typename elem<T>::acc*)ties)
 #define RUA_BRANKS_OP(EPLV)                                     \
   switch (op) {                                                 \
     case RUA_SUM: RUA_BRANKS(EPLV, RUA_SUM, 0); break;          \
