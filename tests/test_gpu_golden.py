@@ -211,7 +211,10 @@ def test_seg(case):
         if not out.data.is_contiguous():
             out = out._replace(data=out.data.contiguous())
         exact = name in ('max', 'min', 'head', 'last')
-        # padding slots of L/R results hold reference-internal garbage (zero-length runs): compare tokens
-        assert_same_seq(out, seq_from(f, n, ks), n, exact=exact, rtol=RTOL, atol=ATOL, valid_only=True)
+        # the padding slots of L/R results too: they hold what `fn` makes of a zero-length run (max/min/logsumexp: the
+        # minimum of the whole padded storage, segment.py:25,47 -> reduce.py:35), and that is part of what callers see.
+        # Only segment_last differs there: the reference's `last` of an empty run is `data[offset - 1]`, a row of
+        # a neighbouring run; here it is a row of zeros.
+        assert_same_seq(out, seq_from(f, n, ks), n, exact=exact, rtol=RTOL, atol=ATOL, valid_only=name == 'last')
         done += 1
     assert done >= 20

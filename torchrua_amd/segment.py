@@ -7,7 +7,8 @@ row matrix and run sizes that cover it.
 C : the runs of all sequences are already back to back — fn sees the payload as it is.
 L/R: the padded storage [B, T] is handed to fn unchanged (no copy), with the padding of every row declared as
      one more run (trailing for L, leading for R); the column of results that belongs to it is cut off again.
-     Its slots inside the result's own padding hold whatever fn makes of an empty run.
+     Its slots inside the result's own padding hold whatever fn makes of an empty run — the same values as in the
+     reference for every segment_* but segment_last.
 P : through C (two moves of the row mover), as the reference does.
 """
 from torchrua_amd.layout import C, L, P, R, Z
