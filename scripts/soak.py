@@ -27,7 +27,7 @@ while time.time() < t_end:
     if family == 'mixed':
         B = int(rng.choice([1, 2, 7, 63, 64, 65, 255, 257, 1000, 2049, 3000]))
         hi = int(rng.choice([1, 2, 5, 17, 63, 64, 65, 130, 300, 700]))
-        H = int(rng.choice([1, 2, 3, 4, 8, 16, 24, 31, 32, 64, 96, 128, 136, 256, 520, 1024]))
+        H = int(rng.choice([1, 2, 3, 4, 8, 16, 24, 31, 32, 64, 96, 100, 128, 136, 250, 256, 500, 520, 1024]))
     elif family == 'long':       # few sequences, some far beyond the reducer's part size: split / tail / combine
         B = int(rng.choice([1, 3, 11, 40]))
         hi = int(rng.choice([3000, 9000, 30000]))
@@ -79,9 +79,9 @@ while time.time() < t_end:
                 # reference calls, reduce.py:34-53); ties of max/min share the gradient in both
                 name = ['sum', 'mean', 'max', 'min'][int(rng.randint(0, 4))]
                 tied = (torch.randint(0, 3, (N, H), generator=g)).to(dtype)
-                # positive cotangents: torch's segment_reduce backward shares a gradient among tied extrema only when
-                # it is > 0 (its kernel tests `grad_input > 0` to find them; DESIGN.md §5, deviations)
-                cot = (torch.rand(B, H, generator=g) + 0.1).to(dtype)
+                # cotangents of both signs: torch's segment_reduce backward shares a gradient among tied extrema only
+                # when it is > 0 (its kernel tests `grad_input > 0` to find them) — RUA_BWD_TIES_POSITIVE does the same
+                cot = torch.randn(B, H, generator=g).to(dtype)
                 r = tied.clone().requires_grad_(True)
                 torch.segment_reduce(r, name, lengths=lens, unsafe=True).backward(cot)
                 for k in 'CLPR':
