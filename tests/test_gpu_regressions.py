@@ -334,3 +334,42 @@ def test_scatter_along_another_dim(name, dim):
             torch.testing.assert_close(sd.grad.cpu(), sc.grad, rtol=1e-5, atol=1e-6)
             if tc.grad is not None and td.grad is not None:
                 torch.testing.assert_close(td.grad.cpu(), tc.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_two_host_threads_share_one_stream():
+    """Two Python threads enqueueing on the same stream (ctypes drops the GIL around every launch): the reduce and its
+    trailing rua_fill_empty share one scratch and must stay back to back; pack() with device-only lengths must never be
+    handed a staging slot another thread is filling."""
+    import threading
+    g = torch.Generator().manual_seed(33)
+    cases = []
+    for k in range(2):
+        lens = torch.randint(0, 9, (1500 + 700 * k,), generator=g)          # a third of the segments empty-ish
+        lens[::3] = 0
+        data = torch.randn(int(lens.sum()), 16, generator=g)
+        pl = torch.randint(1, 40, (1200 + 900 * k,), generator=g)          # >= 1 024 lengths: the side-stream upload
+        pd = torch.randn(int(pl.sum()), 8, generator=g)
+        exp_max = orc.segment_max(data.numpy(), lens.numpy())
+        exp_pack = orc.to_pack(orc.C(pd.numpy(), pl.numpy()), host_sort(pl))
+        cases.append((data.to(DEV), lens.to(DEV), exp_max, pd.to(DEV), pl, exp_pack))
+    torch.cuda.synchronize()
+    errors = []
+
+    def work(k):
+        try:
+            data, lens, exp_max, pd, pl, exp_pack = cases[k]
+            for _ in range(150):
+                got = ta.segment_max(data, lens)
+                p = ta.C(pd, pl.to(DEV)).pack()                               # device-only lengths: read back, sort, upload
+                assert np.array_equal(got.cpu().numpy(), exp_max), 'segment_max with empty segments'
+                assert np.array_equal(p.data.cpu().numpy(), exp_pack.data), 'pack payload'
+                assert np.array_equal(p.sorted_indices.cpu().numpy(), exp_pack.sorted_indices), 'sorted_indices'
+        except BaseException as e:      # noqa: BLE001 - reported by the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

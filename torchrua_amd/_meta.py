@@ -8,6 +8,7 @@ touches payload bytes.
 """
 import ctypes
 import os
+import threading
 import time
 from typing import List, Optional, Tuple
 
@@ -467,13 +468,23 @@ class _StagingRing:
     def __init__(self):
         self.bufs = [None] * self.SLOTS
         self.events = [None] * self.SLOTS
+        self.busy = [False] * self.SLOTS     # reserved, not yet committed (a host thread is filling it)
         self.i = 0
         self.side = None      # the upload stream of this device
+        self.lock = threading.Lock()         # two host threads must never be handed the same slot
 
     def reserve(self, shape, dtype: torch.dtype) -> Tuple[int, Tensor]:
         """Claim the next slot and return (slot, pinned tensor of `shape`) for the caller to fill."""
-        i = self.i
-        self.i = (i + 1) % self.SLOTS
+        with self.lock:
+            i = self.i
+            for _ in range(self.SLOTS):
+                if not self.busy[i]:
+                    break
+                i = (i + 1) % self.SLOTS
+            else:
+                raise RuntimeError('torchrua_amd: every staging slot is being filled by another thread')
+            self.busy[i] = True
+            self.i = (i + 1) % self.SLOTS
         if self.events[i] is not None:
             self.events[i].synchronize()
             self.events[i] = None
@@ -489,6 +500,12 @@ class _StagingRing:
 
     def commit(self, i: int, staged: Tensor, dev: torch.device) -> Tensor:
         """Enqueue the H2D of a slot filled through reserve()."""
+        try:
+            return self._commit(i, staged, dev)
+        finally:
+            self.busy[i] = False
+
+    def _commit(self, i: int, staged: Tensor, dev: torch.device) -> Tensor:
         cur = torch.cuda.current_stream(dev)
         ev = torch.cuda.Event()
         if staged.numel() < self.SIDE_MIN_ELEMS or torch.cuda.is_current_stream_capturing():
@@ -526,7 +543,11 @@ class _StagingRing:
         # a plain memcpy on the calling thread: torch's copy_ hands a 512 KiB vector to its whole OpenMP team
         # (128 threads on the GPU box: 10-100x the serial time), and flipping torch.set_num_threads around it — what
         # round 1 did — is a process-global side effect
-        np.copyto(staged.numpy(), host.detach().numpy())
+        try:
+            np.copyto(staged.numpy(), host.detach().numpy())
+        except BaseException:
+            self.busy[i] = False
+            raise
         return self.commit(i, staged, dev)
 
 
@@ -555,7 +576,11 @@ def sorted_indices_to_device(host_lens_: Tensor, dev: torch.device) -> Tensor:
         return host_sort_desc(host_lens_).to(dev)
     ring = _ring(dev)
     i, staged = ring.reserve((n,), torch.long)
-    host_sort_desc(host_lens_, out=staged)
+    try:
+        host_sort_desc(host_lens_, out=staged)
+    except BaseException:
+        ring.busy[i] = False
+        raise
     return ring.commit(i, staged, dev)
 
 

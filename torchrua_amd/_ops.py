@@ -4,6 +4,7 @@ Backward of a move is the adjoint move (layouts swapped, token map inverted, zer
 nothing maps to) — the same kernel.  Backward of a segmented reduce is one fused kernel
 (rua_segment_reduce_backward), which also serves scatter_* through the bucket indirection.
 """
+import threading
 from typing import Callable, Optional, Sequence, Tuple
 
 import torch
@@ -129,6 +130,9 @@ class _ListGather(torch.autograd.Function):
 # persistent, zeroed scratch per (device, stream): the reduce needs no initialising launch (RUA_OP_SCRATCH_CLEAN) and
 # rua_fill_empty's last workgroup hands it back zeroed — stream order makes that safe for one stream, hence the key.
 _scratch = {}
+# the reduce and its trailing rua_fill_empty share the scratch and must reach the stream back to back: ctypes drops the
+# GIL around each call, so a second host thread enqueueing on the SAME stream could slip its own reduce in between
+_scratch_pair = threading.Lock()
 
 
 def extreme_scratch(dev, lay: M.Lay) -> Tuple[Tensor, int]:
@@ -186,6 +190,9 @@ def launch_reduce(lay: M.Lay, data: Tensor, op: int, out: Optional[Tensor] = Non
     split, ws = split_workspace(lay, H, data.dtype, dev)
     if _kernel_hook:
         _kernel_hook(name, True)
+    paired = extreme is not None
+    if paired:
+        _scratch_pair.acquire()
     try:
         # (the second walk for the global extreme, should a segment be empty, rides in rua_fill_empty's launch: the
         # reduce is told not to arm it, and fill_empty gets the payload unless the host knows nothing is empty)
@@ -203,6 +210,9 @@ def launch_reduce(lay: M.Lay, data: Tensor, op: int, out: Optional[Tensor] = Non
     except L.RuaError:
         forget_extreme_scratch(dev)        # a refused launch may have left the flags raised
         raise
+    finally:
+        if paired:
+            _scratch_pair.release()
     return out
 
 

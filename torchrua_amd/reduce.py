@@ -300,6 +300,9 @@ def pack_reduce(sequence: Z, op: str = 'sum', fused: bool = None):
     split, ws = O.split_workspace(src, H, data.dtype, dev, team_ok=False)      # (the fused kernel has no wave teams)
     if O._kernel_hook:
         O._kernel_hook('pack_reduce', True)
+    paired = extreme is not None          # as in _ops.launch_reduce: the two launches stay back to back on the stream
+    if paired:
+        O._scratch_pair.acquire()
     try:
         K.check(lib.rua_pack_reduce(src.ref(), dst.ref(), K.ptr(data), K.ptr(pdata), K.ptr(out), H, K.DTYPES[data.dtype],
                                     code | op_bits | (K.OP_NO_EMPTY if extreme is not None else 0),
@@ -315,4 +318,7 @@ def pack_reduce(sequence: Z, op: str = 'sum', fused: bool = None):
     except K.RuaError:
         O.forget_extreme_scratch(dev)
         raise
+    finally:
+        if paired:
+            O._scratch_pair.release()
     return p, out
