@@ -39,3 +39,4 @@ for _ in range(300):
 pr.disable()
 torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats('tottime').print_stats(32)
+pstats.Stats(pr).print_callers('__new__')
