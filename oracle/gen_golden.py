@@ -327,9 +327,57 @@ def extra():
     print('wrote', len(store), 'extra arrays;', os.path.getsize(os.path.join(OUT, 'extra.npz')), 'bytes')
 
 
+def foreign():
+    """tests/golden/foreign.npz: PackedSequences whose ties are NOT in torch.sort's order (the stable order, built by
+    hand) through the functions of a PackedSequence.  roll / rev end in `.pack()` in the reference (select/roll.py:26-30,
+    select/rev.py:33-34), so their results come back in the host sort's order whatever the input's was."""
+    global store
+    store = {}
+    rng = np.random.RandomState(31)
+    n_differ = 0
+    for name, lens, H in (('foreign.a', rng.randint(1, 5, 40), 3), ('foreign.b', rng.randint(1, 7, 300), 1),
+                          ('foreign.c', rng.randint(2, 4, 64), 40)):
+        g = torch.Generator().manual_seed(len(lens))
+        lens = torch.as_tensor(lens, dtype=torch.long)
+        data = torch.randn((int(lens.sum()), H), generator=g)
+        c = C(data, lens)
+        theirs = c.pack()
+        stable = torch.sort(lens, descending=True, stable=True)[1]
+        n_differ += int(not torch.equal(stable, theirs.sorted_indices))
+        off = torch.cumsum(lens, 0) - lens
+        rows = [int(off[b]) + t for t, n in enumerate(theirs.batch_sizes.tolist()) for b in stable[:n].tolist()]
+        mine = P(data=data[torch.tensor(rows)], batch_sizes=theirs.batch_sizes, sorted_indices=stable,
+                 unsorted_indices=ref.invert_permutation(stable))
+        assert torch.equal(mine.cat().data, data)
+        put(name, 'lens', lens)
+        put(name, 'data', data)
+        put_seq(name, 'pack', mine)
+        for s_ in (-3, -1, 0, 1, 2, 7):
+            put_seq(name, f'roll.{s_}', mine.roll(s_))
+        put_seq(name, 'rev', mine.rev())
+        put_seq(name, 'cat', mine.cat())
+        put_seq(name, 'left', mine.left(FILL))
+        put_seq(name, 'right', mine.right(FILL))
+        put(name, 'last', mine.last())
+        put_seq(name, 'head.1', mine.head(1))
+        put_seq(name, 'trunc.1.0', mine.trunc((1, 0))) if int(lens.min()) > 1 else None
+        put(name, 'segment_sum.via_cat', ref.segment_sum(*mine.cat()))
+    assert n_differ == 3, 'every case must differ from the host sort order'
+    np.savez_compressed(os.path.join(OUT, 'foreign.npz'), **store)
+    meta_path = os.path.join(OUT, 'META.json')
+    meta = json.load(open(meta_path))
+    meta['foreign_n_arrays'] = len(store)
+    with open(meta_path, 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print('wrote', len(store), 'foreign-order arrays;', os.path.getsize(os.path.join(OUT, 'foreign.npz')), 'bytes')
+
+
 if __name__ == '__main__':
-    if '--extra' in sys.argv:
+    if '--foreign' in sys.argv:
+        foreign()
+    elif '--extra' in sys.argv:
         extra()
     else:
         main()
         extra()
+        foreign()

@@ -22,7 +22,7 @@ def golden():
     global _small
     if _small is None:
         out = {}
-        for fname in ('small.npz', 'extra.npz'):      # round 1 / round 2 (oracle/gen_golden.py: main / extra)
+        for fname in ('small.npz', 'extra.npz', 'foreign.npz'):   # oracle/gen_golden.py: main / extra / foreign
             z = np.load(os.path.join(GOLDEN, fname))
             for key in z.files:
                 case, name = key.split('/', 1)

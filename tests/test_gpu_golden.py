@@ -218,3 +218,37 @@ def test_seg(case):
         assert_same_seq(out, seq_from(f, n, ks), n, exact=exact, rtol=RTOL, atol=ATOL, valid_only=name == 'last')
         done += 1
     assert done >= 20
+
+
+@pytest.mark.parametrize('case', cases('foreign.'))
+def test_packed_sequences_in_another_tie_order(case):
+    """tests/golden/foreign.npz (from the reference itself): a PackedSequence built by hand with its ties in the
+    STABLE order.  roll / rev end in `.pack()` in the reference (select/roll.py:26-30, select/rev.py:33-34), so their
+    results — payload AND sorted / unsorted indices — carry the host sort's order; cat / left / right / last / head /
+    trunc read whatever order the input has.  Gradients flow back through the re-ordering move."""
+    f = golden()[case]
+    p = dev_seq(seq_from(f, 'pack', 'P'))
+    for n in sorted({n.rsplit('.', 1)[0] for n in f if n.startswith('roll.') and n.endswith('.data')}):
+        assert_same_seq(p.roll(int(n.split('.')[1])), seq_from(f, n, 'P'), n)
+    assert_same_seq(p.rev(), seq_from(f, 'rev', 'P'), 'rev')
+    assert_same_seq(p.cat(), seq_from(f, 'cat', 'C'), 'cat')
+    assert_same_seq(p.left(-1.5), seq_from(f, 'left', 'L'), 'left')
+    assert_same_seq(p.right(-1.5), seq_from(f, 'right', 'R'), 'right')
+    np.testing.assert_array_equal(to_np(p.last()), f['last'])
+    assert_same_seq(p.head(1), seq_from(f, 'head.1', 'P'), 'head')
+    if 'trunc.1.0.data' in f:
+        assert_same_seq(p.trunc((1, 0)), seq_from(f, 'trunc.1.0', 'P'), 'trunc')
+    np.testing.assert_allclose(to_np(ta.reduce_sum(p)), f['segment_sum.via_cat'], rtol=1e-5, atol=1e-5)
+    # a second roll of the same object takes the same path (the order is only ever checked, never cached as "fine")
+    assert_same_seq(p.roll(2), seq_from(f, 'roll.2', 'P'), 'roll again')
+    # the result IS in the reference's order: rolling it back passes its metadata through and restores the payload
+    back = p.roll(2).roll(-2)
+    assert torch.equal(back.cat().data, p.cat().data)
+    x = p.data.detach().clone().requires_grad_(True)
+    w = torch.randn_like(x)
+    q = ta.P(x, p.batch_sizes, p.sorted_indices, p.unsorted_indices)
+    (q.roll(1).cat().data * w).sum().backward()
+    # d/dx of sum(w * roll(x)) in C order = w rolled back, brought into the order of x
+    cw = ta.C(w, q.cat().token_sizes).roll(-1)
+    got_c = ta.P(x.grad, p.batch_sizes, p.sorted_indices, p.unsorted_indices).cat().data
+    assert torch.equal(got_c, cw.data), 'gradient through the re-ordering roll'

@@ -95,7 +95,26 @@ def _pack_meta(token_sizes: Tensor, dev: torch.device):
     # garbage made at every step drives Python into full collections — 38 ms each with torch's heap to scan)
     meta = (sorted_indices, unsorted, batch_sizes, bsz_dev, boff)
     M._memo_put(token_sizes, key, (meta, tuple(M._version(t) for t in meta)))
+    M._memo_put(sorted_indices, 'reference_order', True)        # (pack_reference_order below)
     return (lens,) + meta
+
+
+def pack_reference_order(p: P):
+    """The metadata `P.roll` / `P.rev` return in the reference: both end in `.pack()` (select/roll.py:26-30,
+    select/rev.py:33-34), i.e. in a fresh host sort of the lengths (core/view.py:48), whatever order `p` itself is in.
+    None when p's own order already is that one — always for a PackedSequence made by this library, and for
+    torch's pack_sequence(enforce_sorted=False), which makes the same call; a hand-made PackedSequence whose ties sit
+    in another order (a stable sort, say) is checked ONCE (a read-back of its lengths, as the reference pays on every
+    call) and, if it differs, gets (lens, sorted, unsorted, batch_sizes, bsz_dev, boff) in the reference's order."""
+    given = p.sorted_indices
+    if given is None or M._memo_get(given, 'reference_order'):
+        return None
+    dev = K.require_device(p.data)
+    meta = _pack_meta(M.pack_lens(p), dev)
+    if torch.equal(meta[1], given):
+        M._memo_put(given, 'reference_order', True)
+        return None
+    return meta
 
 
 def _pack_view(self: Union[C, L, R], **kwargs) -> P:

@@ -11,7 +11,7 @@ from torch import Tensor
 from torchrua_amd import _lib as K
 from torchrua_amd import _meta as M
 from torchrua_amd import _ops as O
-from torchrua_amd.core import _hidden
+from torchrua_amd.core import _hidden, pack_reference_order
 from torchrua_amd.layout import C, L, P, R, Z, describe, lens_of
 
 
@@ -84,6 +84,14 @@ def _same_layout_move(self: Z, tmap: int, arg: int, name: str, pad_row: int = -1
         plan = O.MovePlan(dst, src, (b, t) + _hidden(self), tmap, arg, fill=0, pad_row=pad_row, name=name)
     else:
         lay = describe(self)
+        order = pack_reference_order(self) if isinstance(self, P) else None
+        if order is not None:
+            # a PackedSequence whose ties are not in the reference's order: the result is (see pack_reference_order)
+            lens, sorted_indices, unsorted, batch_sizes, bsz_dev, boff = order
+            shell = P(data=self.data, batch_sizes=batch_sizes, sorted_indices=sorted_indices, unsorted_indices=unsorted)
+            M.adopt_pack(shell, lens, boff, bsz_dev)
+            dst = M.lay_pack(shell, lens=lens, boff=boff, n_rows=int(self.data.size(0)))
+            return shell._replace(data=O.move(self.data, O.MovePlan(dst, lay, self.data.shape, tmap, arg, name=name)))
         plan = O.MovePlan(lay, lay, self.data.shape, tmap, arg, name=name)
     return self._replace(data=O.move(self.data, plan))
 
@@ -95,7 +103,8 @@ def _cat_roll(self: C, shifts: int) -> C:
 
 def _pack_roll(self: P, shifts: int) -> P:
     """select/roll.py:26-30 (3 index-tensor conversions + 1 gather in the reference) as one closed-form
-    gather: out[boff[t] + r] = in[boff[(t - s) mod len] + r]; batch_sizes / sorted / unsorted pass through."""
+    gather: out[boff[t] + r] = in[boff[(t - s) mod len] + r]; batch_sizes / sorted / unsorted pass through when they
+    are what the reference's closing `.pack()` would compute again (core.pack_reference_order), else they are that."""
     return _same_layout_move(self, K.T_ROLL, int(shifts), 'roll')
 
 
