@@ -373,3 +373,44 @@ def test_two_host_threads_share_one_stream():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_placement_of_large_outputs_changes_nothing_but_the_block(monkeypatch):
+    """torchrua_amd/_placement.py at a tiny threshold: outputs are bit-identical with it on and off, launches get
+    timed without a synchronisation, an offer that is known to be slow is held in favour of another block, and the
+    cache grows by at most EXPLORE - 2 blocks."""
+    from torchrua_amd import _placement as P
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()          # start from an allocator without cached blocks, like a fresh process
+    P.forget()
+    monkeypatch.setattr(P, 'ENABLED', True)
+    monkeypatch.setattr(P, 'MIN_BYTES', 1 << 20)
+    for k in P.stats:
+        P.stats[k] = 0
+    g = torch.Generator().manual_seed(2)
+    lens = torch.randint(1, 50, (700,), generator=g)
+    data = torch.randn(int(lens.sum()), 128, generator=g).to(DEV)          # 8.7 MB payload
+    want = orc.to_pack(orc.C(data.cpu().numpy(), lens.numpy()), host_sort(lens))
+    keep = None
+    for i in range(12):
+        p = ta.with_host_sizes(data, lens).pack()
+        torch.cuda.synchronize()                                          # (so that the timings are in for the next choice)
+        assert np.array_equal(p.data.cpu().numpy(), want.data)
+        assert torch.equal(ta.reduce_sum(p), ta.segment_sum(data, lens.to(DEV)))
+        keep = p                                                          # the previous output stays alive for one step
+    assert P.stats['timed'] >= 8 and P.stats['explored'] >= 1
+    key = next(iter(P._tried))
+    assert 2 <= len(P._tried[key]) <= P.EXPLORE + 1
+    # a block known to be slow is passed over: mark every block but one as slow and ask again
+    blocks = sorted(P._tried[key])
+    for b in blocks:
+        P._times[(key, b)] = (1.0 if b == blocks[-1] else 5.0, 5)
+    P._best[key] = 1.0
+    del keep, p
+    got = [P._base(ta.with_host_sizes(data, lens).pack().data) for _ in range(4)]
+    assert all(b == blocks[-1] for b in got), (got, blocks)
+    # off: plain torch.empty
+    monkeypatch.setattr(P, 'ENABLED', False)
+    p = ta.with_host_sizes(data, lens).pack()
+    assert np.array_equal(p.data.cpu().numpy(), want.data)
+    P.forget()

@@ -22,6 +22,7 @@ TIES_FINAL = 2      # rua_segment_reduce_backward include_self: `ties` came comp
 BWD_FILL_PADDING = 0x100   # ... OR-ed in: the call itself zeroes the padding rows of a padded layout
 BWD_TIES_POSITIVE = 0x200  # ... OR-ed in (max/min): torch.segment_reduce's tie rule — ties share g only where g > 0
 MOVE_SCATTER = 1
+MOVE_NT_ON, MOVE_NT_OFF = 2, 4       # rua.h: force / forbid non-temporal payload accesses
 OP_SCRATCH_CLEAN, OP_NO_EMPTY = 0x100, 0x200     # rua.h: bits OR-ed into `op` (persistent zeroed extreme scratch)
 # enum rua_dtype / rua_op
 F32, BF16, F16, F64 = 0, 1, 2, 3

@@ -13,6 +13,7 @@ from torch.autograd.function import once_differentiable
 
 from torchrua_amd import _lib as L
 from torchrua_amd import _meta as M
+from torchrua_amd import _placement
 
 # optional hook bench.py installs to bracket named kernels with HIP events on the launch stream
 _kernel_hook: Optional[Callable[[str, bool], None]] = None
@@ -63,8 +64,15 @@ def launch_move(plan: MovePlan, src_data: Tensor, out: Optional[Tensor] = None) 
     dev = L.require_device(src_data)
     lib = L.load()
     src_data = src_data.contiguous()
+    placed = None
     if out is None:
-        out = torch.empty(plan.out_shape, dtype=src_data.dtype, device=dev)
+        nbytes = src_data.element_size()
+        for d in plan.out_shape:
+            nbytes *= d
+        # large outputs go where this source is known to move fast; the launch below is timed for it
+        placed = _placement.key_for(plan.name, nbytes, src_data) if nbytes >= _placement.MIN_BYTES else None
+        out = (torch.empty(plan.out_shape, dtype=src_data.dtype, device=dev) if placed is None
+               else _placement.empty_for(plan.out_shape, src_data.dtype, dev, placed))
     elif not out.is_contiguous() or out.dtype != src_data.dtype:
         raise L.RuaError('move target must be contiguous and of the payload dtype')
     # rows are equally wide on both sides; size them on the side the layout `dst` enumerates
@@ -73,8 +81,13 @@ def launch_move(plan: MovePlan, src_data: Tensor, out: Optional[Tensor] = None) 
     fill = _fill16(plan.fill, src_data.dtype)
     if _kernel_hook:
         _kernel_hook(plan.name, True)
+    if placed is not None:
+        stream = torch.cuda.current_stream(dev)
+        placed = _placement.begin(placed, out, stream)
     L.check(lib.rua_move_rows(plan.dst.ref(), plan.src.ref(), plan.tmap, plan.arg, L.ptr(out), L.ptr(src_data), rb,
                               fill, plan.pad_row, plan.flags, L.stream_ptr(dev)), 'rua_move_rows')
+    if placed is not None:
+        _placement.end(placed, stream)
     if _kernel_hook:
         _kernel_hook(plan.name, False)
     return out
