@@ -290,7 +290,10 @@ def pack_reduce(sequence: Z, op: str = 'sum', fused: bool = None):
     lens, sorted_indices, unsorted, batch_sizes, bsz_dev, boff = _pack_meta(sequence.token_sizes, dev)
     n = int(data.size(0)) if isinstance(sequence, C) else M.total_len(sequence.token_sizes)
     B = lens.numel()
-    pdata = torch.empty((n,) + hidden, dtype=data.dtype, device=dev)
+    nbytes = n * H * data.element_size()
+    placed = O._placement.key_for('pack_reduce', nbytes, data) if nbytes >= O._placement.MIN_BYTES else None
+    pdata = (torch.empty((n,) + hidden, dtype=data.dtype, device=dev) if placed is None
+             else O._placement.empty_for((n,) + hidden, data.dtype, dev, placed))
     p = P(data=pdata, batch_sizes=batch_sizes, sorted_indices=sorted_indices, unsorted_indices=unsorted)
     M.adopt_pack(p, lens, boff, bsz_dev)
     dst = M.lay_pack(p, lens=lens, boff=boff, T=batch_sizes.numel(), n_rows=n)
@@ -304,10 +307,15 @@ def pack_reduce(sequence: Z, op: str = 'sum', fused: bool = None):
     if paired:
         O._scratch_pair.acquire()
     try:
+        if placed is not None:
+            stream = torch.cuda.current_stream(dev)
+            placed = O._placement.begin(placed, pdata, stream)
         K.check(lib.rua_pack_reduce(src.ref(), dst.ref(), K.ptr(data), K.ptr(pdata), K.ptr(out), H, K.DTYPES[data.dtype],
                                     code | op_bits | (K.OP_NO_EMPTY if extreme is not None else 0),
                                     O._bits(O._EMPTY[code], data.dtype), K.ptr(extreme), split, K.ptr(ws),
                                     K.stream_ptr(dev)), 'rua_pack_reduce')
+        if placed is not None:
+            O._placement.end(placed, stream)
         if O._kernel_hook:
             O._kernel_hook('pack_reduce', False)
         if extreme is not None:
