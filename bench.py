@@ -241,7 +241,7 @@ def main():
     # which cached blocks this source moves into fastest (torchrua_amd/_placement.py) — a few steps
     # with a synchronisation each so that the timings are in before the next choice
     from torchrua_amd import _placement
-    settle_steps = 10 if _placement.ENABLED else 0
+    settle_steps = 12 if _placement.ENABLED else 0
     for _ in range(settle_steps):
         p, out = step()
         sync()
@@ -289,7 +289,7 @@ def main():
         # extension, reported beside the graded pipeline: pack + reduce fused into one pass (same outputs)
         p_ref = p
         del p
-        for _ in range(2):      # allocator warm-up for the fused variant's buffers
+        for _ in range(10 if _placement.ENABLED else 2):      # allocator warm-up for the fused variant's buffers
             pf, of = ta.pack_reduce(ta.with_host_sizes(data, lens_host), 'sum', fused=True)
         sync()
         timer.enabled = True

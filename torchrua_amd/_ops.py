@@ -209,10 +209,17 @@ def launch_reduce(lay: M.Lay, data: Tensor, op: int, out: Optional[Tensor] = Non
     try:
         # (the second walk for the global extreme, should a segment be empty, rides in rua_fill_empty's launch: the
         # reduce is told not to arm it, and fill_empty gets the payload unless the host knows nothing is empty)
+        # (a reduce that reads a block the mover placed tells the placement what that block costs its reader)
+        reader = None
+        if perm is None and data.numel() * data.element_size() >= _placement.MIN_BYTES:
+            stream = torch.cuda.current_stream(dev)
+            reader = _placement.reader_begin(f'reduce{op}', data, stream)
         L.check(lib.rua_segment_reduce(lay.ref(), L.ptr(perm), L.ptr(data), L.ptr(out), H, L.DTYPES[data.dtype],
                                        op | op_bits | (L.OP_NO_EMPTY if extreme is not None else 0), include_self,
                                        _bits(_EMPTY[op], data.dtype), L.ptr(extreme), split, L.ptr(ws), L.ptr(ties_out),
                                        L.stream_ptr(dev)), 'rua_segment_reduce')
+        if reader is not None:
+            _placement.end(reader, stream)
         if _kernel_hook:
             _kernel_hook(name, False)
         if extreme is not None:

@@ -15,9 +15,9 @@ This module lets the mover learn which blocks are good for which source, from it
     TOLERANCE, the offer is held and another block is asked for (a held block is alive, so the allocator has to
     come up with a different one — only cached blocks are asked for here); the rejected offers go straight back to
     the caching allocator;
-  * a block nobody has timed yet is simply used, and until EXPLORE different blocks have been tried for a source an
-    offer that HAS been tried is held in favour of one that has not (two equally slow blocks would otherwise look
-    fine for ever) — a cached one, or, while the card has ample room, a fresh one: that is the exploration, and it is
+  * a block nobody has timed yet is simply used, and until EXPLORE different blocks have each been moved into
+    MIN_SAMPLES times for a source, an offer whose cost is already known is held in favour of one whose cost is not
+    (two equally slow blocks would otherwise look fine for ever) — a cached one, or, while the card has ample room, a fresh one: that is the exploration, and it is
     what may grow the cache by EXPLORE - 2 blocks.
 
 A caching allocator recycles a handful of blocks, so after the first steps every pair is known and the choice is a
@@ -37,7 +37,8 @@ from torch import Tensor
 
 ENABLED = os.environ.get('RUA_PLACEMENT', '1') != '0'
 MIN_BYTES = int(os.environ.get('RUA_PLACEMENT_MIN_BYTES', 2 << 30))
-TOLERANCE = 0.03           # a block within this of the best time for its source is taken as it comes
+TOLERANCE = 0.015          # a block within this of the best cost for its source is taken as it comes (launches between
+                           # one pair of blocks repeat to ~0.3 %)
 MAX_HELD = 3               # offers in hand at most while choosing
 EXPLORE = 4                # distinct blocks to try for a source before trusting the best time seen
 MIN_SAMPLES = 2            # a block is only called slow after this many launches (the first one into fresh memory
@@ -48,11 +49,13 @@ _lock = threading.Lock()
 
 Key = Tuple[str, int, int, int]                      # (move name, output bytes, source bytes, source storage)
 _times: Dict[Tuple[Key, int], Tuple[float, int]] = {}   # (key, output storage) -> (fastest ms, launches timed)
-_best: Dict[Key, float] = {}
 _pending: List[Tuple[Key, int, torch.cuda.Event, torch.cuda.Event]] = []
 _tried: Dict[Key, set] = {}                         # output blocks launched into, per key (timed or still pending)
 _blocks: Dict[Tuple[int, int], set] = {}            # (device, bytes) -> storage addresses met for outputs of this size
 _frozen: Dict[Tuple[int, int], bool] = {}           # (device, bytes) -> holding switched off (see _may_ask_again)
+_launched: Dict[Tuple[Key, int], int] = {}          # (key, output storage) -> launches into it so far
+_readers: Dict[Tuple[str, int], Dict[int, float]] = {}   # (reader kernel, bytes) -> {block: fastest ms}: what the NEXT
+                                                    # kernel pays to read a block this module placed
 stats = {'timed': 0, 'explored': 0, 'rejected': 0, 'taken_good': 0, 'taken_untimed': 0, 'settled': 0}
 
 
@@ -64,9 +67,10 @@ def _harvest() -> None:
     """File the launches that have finished; never waits."""
     if len(_times) > TABLE_MAX:
         _times.clear()
-        _best.clear()
         _tried.clear()
         _blocks.clear()
+        _readers.clear()
+        _launched.clear()
     keep = []
     for item in list(_pending):
         key, ob, e0, e1 = item
@@ -74,22 +78,39 @@ def _harvest() -> None:
             keep.append(item)
             continue
         ms = e0.elapsed_time(e1)
+        if key[0].startswith('read:'):
+            table = _readers.setdefault((key[0], key[1]), {})
+            table[ob] = min(ms, table.get(ob, float('inf')))
+            stats['timed'] += 1
+            continue
         old = _times.get((key, ob))
         _times[(key, ob)] = (ms, 1) if old is None else (min(ms, old[0]), old[1] + 1)
-        # the first launch into a block does not set the bar (fresh memory is slow once)
-        if old is not None or key not in _best:
-            _best[key] = min(_best.get(key, float('inf')), _times[(key, ob)][0])
         stats['timed'] += 1
     _pending[:] = keep[-PENDING_MAX:]
 
 
+def _read_penalty(ob: int, nbytes: int) -> float:
+    """ms a block costs its readers over the best block of its size, as far as readers have been timed on both."""
+    worst = 0.0
+    for (_name, n), table in _readers.items():
+        if n == nbytes and ob in table and len(table) > 1:
+            worst = max(worst, table[ob] - min(table.values()))
+    return worst
+
+
 def _verdict(key: Key, ob: int) -> Optional[float]:
-    """The block's time for this source when it is KNOWN to be slow, else None (good, or not timed enough)."""
+    """The block's cost for this source — its move time plus what its readers pay — when it is KNOWN to be worse than
+    the best block tried by more than TOLERANCE, else None (good, or not timed enough)."""
     hit = _times.get((key, ob))
-    best = _best.get(key)
-    if hit is None or best is None or hit[1] < MIN_SAMPLES:
+    if hit is None or hit[1] < MIN_SAMPLES:
         return None
-    return hit[0] if hit[0] > best * (1.0 + TOLERANCE) else None
+    best = float('inf')
+    for b in _tried.get(key, ()):
+        t = _times.get((key, b))
+        if t is not None and (t[1] >= MIN_SAMPLES or b == ob):
+            best = min(best, t[0] + _read_penalty(b, key[1]))
+    cost = hit[0] + _read_penalty(ob, key[1])
+    return cost if cost > best * (1.0 + TOLERANCE) else None
 
 
 def _may_ask_again(key: Key, n_held: int, dev: torch.device, exploring: bool) -> bool:
@@ -101,10 +122,10 @@ def _may_ask_again(key: Key, n_held: int, dev: torch.device, exploring: bool) ->
     cached and grew), holding is switched off for this size — growth by one block, once."""
     size = (dev.index, key[1])
     if exploring:
-        if len(_tried.get(key, ())) >= EXPLORE:
-            return False
         if len(_blocks.get(size, ())) >= n_held + 2:
             return True                              # probably cached
+        if len(_tried.get(key, ())) >= EXPLORE:
+            return False
         free, _total = torch.cuda.mem_get_info(dev)  # (waits for the device: at most EXPLORE times per source)
         return free >= 3 * key[1]
     return not _frozen.get(size, False) and len(_blocks.get(size, ())) >= n_held + 2
@@ -136,15 +157,20 @@ def _empty_for(shape, dtype: torch.dtype, dev: torch.device, key: Key) -> Tensor
     _harvest()
     out = torch.empty(shape, dtype=dtype, device=dev)
     tried = _tried.setdefault(key, set())
-    exploring = len(tried) < EXPLORE
+
+    def fresh(t: Tensor) -> bool:          # not moved into MIN_SAMPLES times yet: its cost is not known
+        return _launched.get((key, _base(t)), 0) < MIN_SAMPLES
+
+    exploring = len(tried) < EXPLORE or any(_launched.get((key, b), 0) < MIN_SAMPLES for b in tried)
     _met(key, out, dev, True)
-    if exploring and _base(out) in tried:
-        # exploration: prefer a block this source has not been moved into yet
+    if exploring and not fresh(out):
+        # exploration: prefer a block whose cost for this source is not known yet — one never moved into, or moved
+        # into once (the first launch into fresh memory also pays for its page tables and does not count)
         spare = [out]
         while len(spare) < MAX_HELD and _may_ask_again(key, len(spare), dev, True):
             nxt = torch.empty(shape, dtype=dtype, device=dev)
             _met(key, nxt, dev, True)
-            if _base(nxt) not in tried:
+            if fresh(nxt):
                 stats['explored'] += 1
                 return nxt
             spare.append(nxt)
@@ -175,6 +201,7 @@ def begin(key: Key, out: Tensor, stream: torch.cuda.Stream):
     e0.record(stream)
     with _lock:
         _tried.setdefault(key, set()).add(_base(out))
+        _launched[(key, _base(out))] = _launched.get((key, _base(out)), 0) + 1
     return key, _base(out), e0
 
 
@@ -186,12 +213,30 @@ def end(token, stream: torch.cuda.Stream) -> None:
         _pending.append((key, ob, e0, e1))
 
 
+def reader_begin(name: str, data: Tensor, stream: torch.cuda.Stream):
+    """Bracket a kernel that READS a block this module placed (the reduce over a PackedSequence that pack() just made):
+    its time goes into the block's cost the next time the mover chooses."""
+    if not ENABLED:
+        return None
+    nbytes = data.numel() * data.element_size()
+    if nbytes < MIN_BYTES or torch.cuda.is_current_stream_capturing():
+        return None
+    known = _blocks.get((data.device.index, nbytes))
+    ob = _base(data)
+    if not known or ob not in known:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    return ('read:' + name, nbytes, 0, 0), ob, e0
+
+
 def forget() -> None:
     """Drop everything learned (after torch.cuda.empty_cache(): a storage address may come back on other memory)."""
     _times.clear()
-    _best.clear()
     _pending.clear()
     _tried.clear()
     _blocks.clear()
     _frozen.clear()
+    _readers.clear()
+    _launched.clear()
 
