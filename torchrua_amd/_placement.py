@@ -17,8 +17,8 @@ This module lets the mover learn which blocks are good for which source, from it
     the caching allocator;
   * a block nobody has timed yet is simply used, and until EXPLORE different blocks have each been moved into
     MIN_SAMPLES times for a source, an offer whose cost is already known is held in favour of one whose cost is not
-    (two equally slow blocks would otherwise look fine for ever) — a cached one, or, while the card has ample room, a fresh one: that is the exploration, and it is
-    what may grow the cache by EXPLORE - 2 blocks.
+    (two equally slow blocks would otherwise look fine for ever) — a cached one, or, while the card has ample room,
+    a fresh one: that is the exploration, and it is what may grow the cache by EXPLORE - 2 blocks.
 
 A caching allocator recycles a handful of blocks, so after the first steps every pair is known and the choice is a
 dictionary lookup plus, at worst, a couple of cached alloc / free pairs per call.  No synchronisation, no extra GPU
@@ -54,6 +54,7 @@ _tried: Dict[Key, set] = {}                         # output blocks launched int
 _blocks: Dict[Tuple[int, int], set] = {}            # (device, bytes) -> storage addresses met for outputs of this size
 _frozen: Dict[Tuple[int, int], bool] = {}           # (device, bytes) -> holding switched off (see _may_ask_again)
 _launched: Dict[Tuple[Key, int], int] = {}          # (key, output storage) -> launches into it so far
+_no_room: Dict[Tuple[int, int], bool] = {}          # (device, bytes) -> the card had no room for a fresh block
 _readers: Dict[Tuple[str, int], Dict[int, float]] = {}   # (reader kernel, bytes) -> {block: fastest ms}: what the NEXT
                                                     # kernel pays to read a block this module placed
 stats = {'timed': 0, 'explored': 0, 'rejected': 0, 'taken_good': 0, 'taken_untimed': 0, 'settled': 0}
@@ -124,10 +125,13 @@ def _may_ask_again(key: Key, n_held: int, dev: torch.device, exploring: bool) ->
     if exploring:
         if len(_blocks.get(size, ())) >= n_held + 2:
             return True                              # probably cached
-        if len(_tried.get(key, ())) >= EXPLORE:
+        if len(_tried.get(key, ())) >= EXPLORE or _no_room.get(size, False):
             return False
-        free, _total = torch.cuda.mem_get_info(dev)  # (waits for the device: at most EXPLORE times per source)
-        return free >= 3 * key[1]
+        free, _total = torch.cuda.mem_get_info(dev)  # (waits for the device: at most EXPLORE times per source,
+        if free < 3 * key[1]:                        #  and never again for this size once the answer was no)
+            _no_room[size] = True
+            return False
+        return True
     return not _frozen.get(size, False) and len(_blocks.get(size, ())) >= n_held + 2
 
 
@@ -239,4 +243,5 @@ def forget() -> None:
     _frozen.clear()
     _readers.clear()
     _launched.clear()
+    _no_room.clear()
 
