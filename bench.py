@@ -241,7 +241,7 @@ def main():
     # which cached blocks this source moves into fastest (torchrua_amd/_placement.py) — a few steps
     # with a synchronisation each so that the timings are in before the next choice
     from torchrua_amd import _placement
-    settle_steps = 12 if _placement.ENABLED else 0
+    settle_steps = 3 * _placement.EXPLORE if _placement.ENABLED else 0      # every block tried is moved into twice
     for _ in range(settle_steps):
         p, out = step()
         sync()

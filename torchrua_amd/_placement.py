@@ -39,8 +39,9 @@ ENABLED = os.environ.get('RUA_PLACEMENT', '1') != '0'
 MIN_BYTES = int(os.environ.get('RUA_PLACEMENT_MIN_BYTES', 2 << 30))
 TOLERANCE = 0.015          # a block within this of the best cost for its source is taken as it comes (launches between
                            # one pair of blocks repeat to ~0.3 %)
-MAX_HELD = 3               # offers in hand at most while choosing
-EXPLORE = 4                # distinct blocks to try for a source before trusting the best time seen
+EXPLORE = int(os.environ.get('RUA_PLACEMENT_EXPLORE', 4))   # distinct blocks to try for a source before trusting the best seen
+MAX_HELD = EXPLORE + 1     # offers in hand at most while choosing: enough to see every block that was tried, so that
+                           # settling for the best one on offer really is the best one free
 MIN_SAMPLES = 2            # a block is only called slow after this many launches (the first one into fresh memory
                            # also pays for its page tables)
 PENDING_MAX = 256
