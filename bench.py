@@ -10,6 +10,9 @@ One step = one pass of the hot path over one batch already resident in HBM:
     out = reduce_sum(p)                 # segmented reduce over the PackedSequence -> [B, H]
     (N > 1: one RCCL all-gather of `out`; sequences are sharded, payload never crosses xGMI)
 Nothing is cached between steps: every step uploads the lengths again, re-sorts, re-scans, re-moves.
+Before the W warm-up steps, and outside every clock, a few more untimed steps let the allocator settle: the library
+learns from its own launches which of torch's cached blocks this source moves into fastest (torchrua_amd/_placement.py,
+DESIGN.md §4.1a) — the timed steps then run exactly what any long-running caller of the library runs.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the pack row mover:
 algorithmic bytes 2*N*H*e + 8*(3B+T)), timed with HIP events on the launch stream
