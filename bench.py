@@ -10,9 +10,8 @@ One step = one pass of the hot path over one batch already resident in HBM:
     out = reduce_sum(p)                 # segmented reduce over the PackedSequence -> [B, H]
     (N > 1: one RCCL all-gather of `out`; sequences are sharded, payload never crosses xGMI)
 Nothing is cached between steps: every step uploads the lengths again, re-sorts, re-scans, re-moves.
-Before the W warm-up steps, and outside every clock, a few more untimed steps let the allocator settle: the library
-learns from its own launches which of torch's cached blocks this source moves into fastest (torchrua_amd/_placement.py,
-DESIGN.md §4.1a) — the timed steps then run exactly what any long-running caller of the library runs.
+The library runs with its defaults: output placement (torchrua_amd/_placement.py) is opt-in and OFF
+here unless RUA_PLACEMENT=1 is exported; the line says which (`placement.enabled`).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the pack row mover:
 algorithmic bytes 2*N*H*e + 8*(3B+T)), timed with HIP events on the launch stream
@@ -112,6 +111,57 @@ def cpu_baseline(args):
     return {'value': round(n * args.hidden / t / 1e6, 1), 'unit': 'M elements/s', 'cores': cores, 'kind': 'port',
             'sample': f'{B} sequences len~U({args.lo},{args.hi}) hidden={args.hidden} bf16 ({n} rows), '
                       f'pack -> cat -> segment_sum, median of 3, {t:.2f} s each'}
+
+
+def parity_leg(ta, data, lens_host, out_bf16, n_sample=256):
+    """Untimed: what the kernels' floating point actually achieves at this shape, against the oracle (checker only).
+    A strided sample of `n_sample` sequences of the batch is copied out; the oracle folds it the reference's way
+    (torch.segment_reduce's sequential fp32 fold over x.float(), reduce.py:44-61) and exactly (fp64).  Reported:
+      * the graded bf16 output of the pipeline against the oracle's fp32 sums rounded to bf16, in bf16 ulps;
+      * the kernels on the same rows as fp32 payload against the oracle: |got - ref| / sum|x| per element for the sums
+        (the scale rounding errors of a sum live on) and plain relative error for logsumexp; max must be exact;
+      * the reference's OWN sequential fp32 fold against fp64 in the same measure, for scale.
+    north_star's bar is 1e-5 relative."""
+    import numpy as np
+
+    from oracle import rua_oracle as orc
+    B = lens_host.numel()
+    pick = torch.arange(0, B, max(1, B // n_sample))[:n_sample]
+    off = torch.cumsum(lens_host, 0) - lens_host
+    rows = torch.cat([torch.arange(int(off[b]), int(off[b] + lens_host[b])) for b in pick.tolist()])
+    lens_s = lens_host[pick].contiguous()
+    x_dev = data[rows.to(data.device)]                              # [n_s, H] bf16 on the device
+    x32 = x_dev.float()
+    x_np = x32.cpu().numpy()
+    lens_np = lens_s.numpy()
+    ref32 = {'sum': orc.segment_sum(x_np, lens_np), 'max': orc.segment_max(x_np, lens_np),
+             'logsumexp': orc.segment_logsumexp(x_np, lens_np)}
+    x64 = x_np.astype(np.float64)
+    ref64_sum = orc.segment_sum(x64, lens_np)
+    ref64_lse = orc.segment_logsumexp(x64, lens_np)
+    sum_abs = orc.segment_sum(np.abs(x64), lens_np)
+    lens_dev = lens_s.to(data.device)
+    got = {'sum': ta.segment_sum(x32, lens_dev).cpu().numpy(), 'max': ta.segment_max(x32, lens_dev).cpu().numpy(),
+           'logsumexp': ta.segment_logsumexp(x32, lens_dev).cpu().numpy()}
+    # the graded output: rows of the pipeline's [B, H] bf16 sums for the sampled sequences
+    mine_bf16 = out_bf16[pick.to(out_bf16.device)].view(torch.int16).cpu().numpy().astype(np.int32)
+    want_bf16 = torch.from_numpy(ref64_sum).to(torch.bfloat16).view(torch.int16).numpy().astype(np.int32)
+
+    def ordered(bits):          # sign-magnitude -> monotone integers, so that a difference counts ulps
+        return np.where(bits < 0, -(bits & 0x7fff), bits)
+    ulps = np.abs(ordered(mine_bf16) - ordered(want_bf16))
+    return {
+        'sample': f'{pick.numel()} sequences (every {max(1, B // n_sample)}th) of the batch, {rows.numel()} rows',
+        'pipeline_bf16_sum_vs_exact_rounded_to_bf16_max_ulps': int(ulps.max()),
+        'pipeline_bf16_sum_frac_bit_identical': round(float((ulps == 0).mean()), 4),
+        'sum_f32_vs_reference_fold_over_sum_abs': float(np.max(np.abs(got['sum'] - ref32['sum']) / sum_abs)),
+        'sum_f32_vs_fp64_over_sum_abs': float(np.max(np.abs(got['sum'] - ref64_sum) / sum_abs)),
+        'reference_fold_f32_vs_fp64_over_sum_abs': float(np.max(np.abs(ref32['sum'] - ref64_sum) / sum_abs)),
+        'sum_f32_vs_reference_fold_max_rel': float(np.max(np.abs(got['sum'] - ref32['sum']) / np.maximum(np.abs(ref32['sum']), 1e-30))),
+        'max_exact': bool(np.array_equal(got['max'], ref32['max'])),
+        'logsumexp_f32_vs_reference_max_rel': float(np.max(np.abs(got['logsumexp'] - ref32['logsumexp']) / np.maximum(np.abs(ref32['logsumexp']), 1e-30))),
+        'logsumexp_f32_vs_fp64_max_rel': float(np.max(np.abs(got['logsumexp'] - ref64_lse) / np.maximum(np.abs(ref64_lse), 1e-30))),
+        'bar': '1e-5 relative (BASELINE.json north_star); integer outputs bit-exact (checked by tests, not here)'}
 
 
 def self_launch(args):
@@ -240,14 +290,7 @@ def main():
             torch.cuda.synchronize(dev)
 
     p = out = None
-    # allocator warm-up, before the W warm-up steps and outside every clock: the library learns, from its own launches,
-    # which cached blocks this source moves into fastest (torchrua_amd/_placement.py) — a few steps
-    # with a synchronisation each so that the timings are in before the next choice
     from torchrua_amd import _placement
-    settle_steps = 3 * _placement.EXPLORE if _placement.ENABLED else 0      # every block tried is moved into twice
-    for _ in range(settle_steps):
-        p, out = step()
-        sync()
     for _ in range(max(args.warmup, 2)):   # at least 2: the loop keeps the previous PackedSequence alive, so the
                                            # allocator needs two steps to own both 17 GB buffers
         p, out = step()      # keep the previous result alive exactly like the timed loop does, so the caching
@@ -268,6 +311,7 @@ def main():
                   file=sys.stderr)
     timer.enabled = False
 
+    out_graded = out        # the timed pipeline's [B, H] sums (parity_leg looks at a sample of them)
     # sanity inside the bench: the last step's output is a real PackedSequence and a [B, H] sum
     assert p.data.shape == data.shape and p.batch_sizes.numel() == T and out.shape[-1] == H
     assert out.shape[0] == B * world
@@ -292,7 +336,7 @@ def main():
         # extension, reported beside the graded pipeline: pack + reduce fused into one pass (same outputs)
         p_ref = p
         del p
-        for _ in range(10 if _placement.ENABLED else 2):      # allocator warm-up for the fused variant's buffers
+        for _ in range(2):      # allocator warm-up for the fused variant's buffers
             pf, of = ta.pack_reduce(ta.with_host_sizes(data, lens_host), 'sum', fused=True)
         sync()
         timer.enabled = True
@@ -368,10 +412,9 @@ def main():
             'reduce_kernel': {'kernel': 'seg_reduce_kernel<bf16,8,SUM,NT> (over P)', 'avg_ms': round(red_ms, 4),
                               'achieved': round(reduce_bytes / (red_ms * 1e-3) / 1e9, 1), 'unit': 'GB/s',
                               'frac': round(reduce_bytes / (red_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-            'placement': {'enabled': bool(_placement.ENABLED), 'settle_steps_before_warmup': settle_steps,
-                          'stats': dict(_placement.stats),
-                          'note': 'large outputs go into the cached block this source is known to move into fastest '
-                                  '(learned from the launches themselves; RUA_PLACEMENT=0 switches it off)'},
+            'placement': {'enabled': bool(_placement.ENABLED), 'stats': dict(_placement.stats),
+                          'note': 'opt-in (RUA_PLACEMENT=1): choose among CACHED output blocks by their measured move '
+                                  'time; off by default, never allocates on its own'},
             'pipeline': {'algorithmic_bytes': pack_bytes + reduce_bytes,
                          'kernel_ms': round(move_ms + red_ms, 4),
                          'frac_of_hbm_peak_kernels': round((pack_bytes + reduce_bytes) / ((move_ms + red_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -379,6 +422,7 @@ def main():
         }
         line.update(extra)
         if world == 1 and not args.no_cpu_baseline:
+            line['parity'] = parity_leg(ta, data, lens_host, out_graded)
             line['cpu_baseline'] = cpu_baseline(args)
             line['cpu_baseline_torch'] = cpu_baseline_torch(args)
         print(json.dumps(line), flush=True)

@@ -81,3 +81,29 @@ def test_bench_self_launch_needs_the_gpus_it_was_asked_for():
                          capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert out.returncode != 0 and '--gpus 16' in out.stderr
     assert not [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+
+
+@pytest.mark.gpu
+def test_bench_legs_are_sane_at_the_north_star_shape():
+    """keys are not enough — a 150 ms fused leg around a 6 ms kernel passed the key check.  At the
+    north-star shape (the driver's own command line, fewer steps) every leg's wall clock per step must stay within
+    1.25x of the kernels it enqueues, the reference-signature leg (blocking read-back per step) within 1.4x, and the
+    achieved float error must be on the line."""
+    import torch
+    if torch.cuda.mem_get_info()[0] < 80 << 30:
+        pytest.skip('needs ~75 GB of free HBM')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '6', '--warmup', '3', '--cpu-sample', '256'],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT,
+                         env={k: v for k, v in os.environ.items() if k != 'RUA_PLACEMENT'})
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][0])
+    assert 'north-star shape' in d['config']['workload'] and d['placement']['enabled'] is False
+    kernels = d['pipeline']['kernel_ms']
+    assert kernels > 0 and d['ms_per_step'] <= 1.25 * kernels, (d['ms_per_step'], kernels)
+    f = d['fused_pack_reduce']
+    assert f['kernel_ms'] > 0 and f['ms_per_step'] <= 1.25 * f['kernel_ms'], f
+    assert d['device_lens']['ms_per_step'] <= 1.4 * kernels, (d['device_lens'], kernels)
+    assert d['roofline']['frac'] >= 0.6 and d['pipeline']['frac_of_hbm_peak_wall'] >= 0.6
+    par = d['parity']
+    assert par['max_exact'] is True and par['sum_f32_vs_fp64_over_sum_abs'] <= 1e-5
+    assert par['logsumexp_f32_vs_reference_max_rel'] <= 1e-5 and par['pipeline_bf16_sum_vs_exact_rounded_to_bf16_max_ulps'] <= 1

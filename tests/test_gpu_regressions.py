@@ -2,6 +2,8 @@
 widths on both sides of the 128-byte kernel switch, scatter_* argument validation (what torch.index_add /
 index_reduce reject), the hot path under torch.inference_mode(), scatter_prod's gradient where `tensor` is 0,
 and the privacy of the host length mirror."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -375,11 +377,13 @@ def test_two_host_threads_share_one_stream():
     assert not errors, errors
 
 
-def test_placement_of_large_outputs_changes_nothing_but_the_block(monkeypatch):
-    """torchrua_amd/_placement.py at a tiny threshold: outputs are bit-identical with it on and off, launches get
-    timed without a synchronisation, an offer that is known to be slow is held in favour of another block, and the
-    cache grows by at most EXPLORE - 2 blocks."""
+def test_placement_is_opt_in_and_only_chooses_among_cached_blocks(monkeypatch):
+    """torchrua_amd/_placement.py: off by default; switched on at a tiny threshold the
+    outputs are bit-identical, launches get timed without a synchronisation, an offer known to be slow is held in
+    favour of a block KNOWN to sit in the cache, and the allocator never grows on its behalf (reserved bytes constant
+    once the caller's own warm() has run)."""
     from torchrua_amd import _placement as P
+    assert os.environ.get('RUA_PLACEMENT', '0') == '1' or not P.ENABLED          # default: off
     torch.cuda.synchronize()
     torch.cuda.empty_cache()          # start from an allocator without cached blocks, like a fresh process
     P.forget()
@@ -390,31 +394,41 @@ def test_placement_of_large_outputs_changes_nothing_but_the_block(monkeypatch):
     g = torch.Generator().manual_seed(2)
     lens = torch.randint(1, 50, (700,), generator=g)
     data = torch.randn(int(lens.sum()), 128, generator=g).to(DEV)          # 8.7 MB payload
+    nbytes = data.numel() * data.element_size()
     want = orc.to_pack(orc.C(data.cpu().numpy(), lens.numpy()), host_sort(lens))
     keep = None
-    for i in range(12):
+    for i in range(6):                # nothing cached beyond what the loop itself frees: plain behaviour, timed launches
         p = ta.with_host_sizes(data, lens).pack()
         torch.cuda.synchronize()                                          # (so that the timings are in for the next choice)
         assert np.array_equal(p.data.cpu().numpy(), want.data)
         assert torch.equal(ta.reduce_sum(p), ta.segment_sum(data, lens.to(DEV)))
         keep = p                                                          # the previous output stays alive for one step
-    assert P.stats['timed'] >= 8 and P.stats['explored'] >= 1
+    assert P.stats['timed'] >= 4 and P.stats['rejected'] == 0
+    # the caller opts into more blocks to choose from
+    assert P.warm(nbytes, DEV, blocks=3) == 3
+    reserved = torch.cuda.memory_reserved()
     key = next(iter(P._tried))
-    assert 2 <= len(P._tried[key]) <= P.EXPLORE + 2
-    # a block known to be slow is passed over: see which block the allocator offers first, call it slow, ask again
-    blocks = sorted(P._tried[key])
+    size = (DEV.index if DEV.index is not None else torch.cuda.current_device(), nbytes)
     del keep, p
-    first = P._base(ta.with_host_sizes(data, lens).pack().data)
+    first = P._base(ta.with_host_sizes(data, lens).pack().data)          # the block the allocator offers first
     torch.cuda.synchronize()
-    for b in set(blocks) | {first}:
+    assert len(P._blocks[size]) >= 3
+    for b in P._blocks[size]:                                            # call that one slow, every other one fast
         P._tried[key].add(b)
-        P._launched[(key, b)] = 5
         P._times[(key, b)] = (5.0 if b == first else 1.0, 5)
-    P._frozen.clear()
     monkeypatch.setattr(P, '_harvest', lambda: None)          # (real timings would overwrite the made-up ones)
     got = [P._base(ta.with_host_sizes(data, lens).pack().data) for _ in range(4)]
     assert first not in got, (first, got)
-    assert P.stats['rejected'] >= 1
+    assert P.stats['rejected'] >= 1 and not P._frozen
+    assert torch.cuda.memory_reserved() == reserved                      # never grew
+    # every cached block slow too: nothing better is known to be cached -> the first offer is taken, nothing is held
+    for b in P._blocks[size]:
+        P._times[(key, b)] = (5.0, 5)
+    P._times[(key, sorted(P._blocks[size])[0])] = (1.0, 5)
+    alive = [torch.empty(nbytes, dtype=torch.uint8, device=DEV) for _ in range(8)]   # ... and the fast one is in use
+    p = ta.with_host_sizes(data, lens).pack()
+    assert np.array_equal(p.data.cpu().numpy(), want.data)
+    del alive
     # off: plain torch.empty
     monkeypatch.setattr(P, 'ENABLED', False)
     p = ta.with_host_sizes(data, lens).pack()

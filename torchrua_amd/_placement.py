@@ -1,32 +1,28 @@
-"""Where a LARGE output of the row mover is put.
+"""Where a LARGE output of the row mover is put — OPT-IN, off by default.
 
 On the MI355X the time of a multi-GB move depends on WHICH allocations it runs between: the buffers of a process fall
-into a few classes (profiles/r02_placement.txt; they look like the ranks of the HBM3E stacks, but physical addresses
-are not visible from user space), and a move whose source and destination sit in the same class is ~6 % slower than
-one between classes — the same kernel, the same bytes (north-star pack: 6.05 vs 5.65 ms).  torch's caching allocator
-hands out whichever cached block fits, so a pipeline that alternates between two output blocks runs at the mix.
+into a few classes (profiles/r02_placement.txt), and a move whose source and destination sit in the same class is ~6 %
+slower than one between classes — the same kernel, the same bytes (north-star pack: 6.05 vs 5.65 ms).  torch's caching
+allocator hands out whichever cached block fits, so a pipeline that alternates between two output blocks runs at the mix.
 
-This module lets the mover learn which blocks are good for which source, from its own launches:
+When switched on (RUA_PLACEMENT=1, or `enable()`), the mover learns from its own launches which CACHED block is good
+for which source and prefers it.  Round 2 shipped this on by default and let it allocate while it explored; on a fresh
+box that stalled a caller for 0.7 s on a new shape.  The rules now:
 
-  * every launch into a large output (>= MIN_BYTES) is bracketed by two events on its stream; finished pairs are read
-    back later, without ever waiting, and the time is filed under (what moved, source block, output block) — blocks
-    are known by their storage address;
-  * when torch offers a block whose time for this source is known to be worse than the best one seen by more than
-    TOLERANCE, the offer is held and another block is asked for (a held block is alive, so the allocator has to
-    come up with a different one — only cached blocks are asked for here); the rejected offers go straight back to
-    the caching allocator;
-  * a block nobody has timed yet is simply used, and until EXPLORE different blocks have each been moved into
-    MIN_SAMPLES times for a source, an offer whose cost is already known is held in favour of one whose cost is not
-    (two equally slow blocks would otherwise look fine for ever) — a cached one, or, while the card has ample room,
-    a fresh one: that is the exploration, and it is what may grow the cache by EXPLORE - 2 blocks.
+  * it never asks the device for anything: no hipMalloc on its behalf, no `mem_get_info`, no `memory_stats` (all three
+    wait for the device).  It only asks torch's caching allocator for another block while it holds an offer, and only
+    when it KNOWS another block of exactly this size is sitting in the cache — a block it handed out earlier whose
+    storage has since died (weak references to the storages it handed out; no allocator query);
+  * should the allocator nevertheless answer with a block never met before (the cache was flushed behind its back, the
+    block went to another stream's pool), choosing is switched off for that size for good: growth by one block, once;
+  * while choosing it holds at most MAX_EXTRA_BLOCKS offers beyond the one it returns (default 1) and every extra
+    `torch.empty` is wrapped: an OutOfMemoryError returns the first offer and freezes the size;
+  * a caller who WANTS more blocks to choose from says so: `warm(nbytes, device, blocks)` puts that many blocks of the
+    size into the cache, up front, at the caller's expense.  bench.py does not.
 
-A caching allocator recycles a handful of blocks, so after the first steps every pair is known and the choice is a
-dictionary lookup plus, at worst, a couple of cached alloc / free pairs per call.  No synchronisation, no extra GPU
-work; the price is up to EXPLORE - 2 more cached blocks of the output's size, some of which end up parked in the
-allocator's cache because they are slow for this source.
-
-RUA_PLACEMENT=0 switches it off; RUA_PLACEMENT_MIN_BYTES moves the threshold (default 2 GiB).  Nothing here changes
-a result: only which block the output lives in.
+Every launch into a large output (>= MIN_BYTES) is bracketed by two events on its stream; finished pairs are read back
+later, without ever waiting, and the time is filed under (what moved, source block, output block).  Nothing here
+changes a result: only which cached block the output lives in.
 """
 import os
 import threading
@@ -34,14 +30,13 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 from torch import Tensor
+from torch.multiprocessing.reductions import StorageWeakRef
 
-ENABLED = os.environ.get('RUA_PLACEMENT', '1') != '0'
+ENABLED = os.environ.get('RUA_PLACEMENT', '0') == '1'
 MIN_BYTES = int(os.environ.get('RUA_PLACEMENT_MIN_BYTES', 2 << 30))
 TOLERANCE = 0.015          # a block within this of the best cost for its source is taken as it comes (launches between
                            # one pair of blocks repeat to ~0.3 %)
-EXPLORE = int(os.environ.get('RUA_PLACEMENT_EXPLORE', 4))   # distinct blocks to try for a source before trusting the best seen
-MAX_HELD = EXPLORE + 1     # offers in hand at most while choosing: enough to see every block that was tried, so that
-                           # settling for the best one on offer really is the best one free
+MAX_EXTRA_BLOCKS = int(os.environ.get('RUA_PLACEMENT_MAX_EXTRA', 1))   # offers held beyond the one returned
 MIN_SAMPLES = 2            # a block is only called slow after this many launches (the first one into fresh memory
                            # also pays for its page tables)
 PENDING_MAX = 256
@@ -49,16 +44,19 @@ TABLE_MAX = 4096           # (source, output) pairs remembered; beyond that ever
 _lock = threading.Lock()
 
 Key = Tuple[str, int, int, int]                      # (move name, output bytes, source bytes, source storage)
+Size = Tuple[int, int]                               # (device index, bytes)
 _times: Dict[Tuple[Key, int], Tuple[float, int]] = {}   # (key, output storage) -> (fastest ms, launches timed)
 _pending: List[Tuple[Key, int, torch.cuda.Event, torch.cuda.Event]] = []
-_tried: Dict[Key, set] = {}                         # output blocks launched into, per key (timed or still pending)
-_blocks: Dict[Tuple[int, int], set] = {}            # (device, bytes) -> storage addresses met for outputs of this size
-_frozen: Dict[Tuple[int, int], bool] = {}           # (device, bytes) -> holding switched off (see _may_ask_again)
-_launched: Dict[Tuple[Key, int], int] = {}          # (key, output storage) -> launches into it so far
-_no_room: Dict[Tuple[int, int], bool] = {}          # (device, bytes) -> the card had no room for a fresh block
-_readers: Dict[Tuple[str, int], Dict[int, float]] = {}   # (reader kernel, bytes) -> {block: fastest ms}: what the NEXT
-                                                    # kernel pays to read a block this module placed
-stats = {'timed': 0, 'explored': 0, 'rejected': 0, 'taken_good': 0, 'taken_untimed': 0, 'settled': 0}
+_tried: Dict[Key, set] = {}                          # output blocks launched into, per key (timed or still pending)
+_blocks: Dict[Size, Dict[int, Optional[StorageWeakRef]]] = {}   # blocks met, with the storage last handed out on each
+_frozen: Dict[Size, bool] = {}                       # choosing switched off for this size
+_readers: Dict[Tuple[str, int], Dict[int, float]] = {}   # (reader kernel, bytes) -> {block: fastest ms}
+stats = {'timed': 0, 'rejected': 0, 'taken_good': 0, 'taken_untimed': 0, 'settled': 0, 'frozen': 0, 'oom': 0}
+
+
+def enable(on: bool = True) -> None:
+    global ENABLED
+    ENABLED = bool(on)
 
 
 def _base(t: Tensor) -> int:
@@ -70,9 +68,7 @@ def _harvest() -> None:
     if len(_times) > TABLE_MAX:
         _times.clear()
         _tried.clear()
-        _blocks.clear()
         _readers.clear()
-        _launched.clear()
     keep = []
     for item in list(_pending):
         key, ob, e0, e1 = item
@@ -80,14 +76,13 @@ def _harvest() -> None:
             keep.append(item)
             continue
         ms = e0.elapsed_time(e1)
+        stats['timed'] += 1
         if key[0].startswith('read:'):
             table = _readers.setdefault((key[0], key[1]), {})
             table[ob] = min(ms, table.get(ob, float('inf')))
-            stats['timed'] += 1
             continue
         old = _times.get((key, ob))
         _times[(key, ob)] = (ms, 1) if old is None else (min(ms, old[0]), old[1] + 1)
-        stats['timed'] += 1
     _pending[:] = keep[-PENDING_MAX:]
 
 
@@ -100,49 +95,39 @@ def _read_penalty(ob: int, nbytes: int) -> float:
     return worst
 
 
-def _verdict(key: Key, ob: int) -> Optional[float]:
-    """The block's cost for this source — its move time plus what its readers pay — when it is KNOWN to be worse than
-    the best block tried by more than TOLERANCE, else None (good, or not timed enough)."""
+def _cost(key: Key, ob: int) -> Optional[float]:
     hit = _times.get((key, ob))
     if hit is None or hit[1] < MIN_SAMPLES:
         return None
-    best = float('inf')
-    for b in _tried.get(key, ()):
-        t = _times.get((key, b))
-        if t is not None and (t[1] >= MIN_SAMPLES or b == ob):
-            best = min(best, t[0] + _read_penalty(b, key[1]))
-    cost = hit[0] + _read_penalty(ob, key[1])
+    return hit[0] + _read_penalty(ob, key[1])
+
+
+def _verdict(key: Key, ob: int) -> Optional[float]:
+    """The block's cost for this source when it is KNOWN to be worse than the best block tried by more than
+    TOLERANCE, else None (good, or not timed enough)."""
+    cost = _cost(key, ob)
+    if cost is None:
+        return None
+    best = min((c for c in (_cost(key, b) for b in _tried.get(key, ())) if c is not None), default=cost)
     return cost if cost > best * (1.0 + TOLERANCE) else None
 
 
-def _may_ask_again(key: Key, n_held: int, dev: torch.device, exploring: bool) -> bool:
-    """May another block be asked for while `n_held` offers are held?  The allocator is not asked what it has cached
-    (torch.cuda.memory_stats / hipMemGetInfo turned out to wait for the device: 1.6 ms of GPU idle per step when they
-    sat on the steady path); the module keeps its own list of the blocks of this size it has met.  Outside exploration
-    another block is asked for only when that list is long enough to leave one after the held offers and one output
-    still alive from the previous call; should the allocator answer with a block never met before (it had nothing
-    cached and grew), holding is switched off for this size — growth by one block, once."""
-    size = (dev.index, key[1])
-    if exploring:
-        if len(_blocks.get(size, ())) >= n_held + 2:
-            return True                              # probably cached
-        if len(_tried.get(key, ())) >= EXPLORE or _no_room.get(size, False):
-            return False
-        free, _total = torch.cuda.mem_get_info(dev)  # (waits for the device: at most EXPLORE times per source,
-        if free < 3 * key[1]:                        #  and never again for this size once the answer was no)
-            _no_room[size] = True
-            return False
-        return True
-    return not _frozen.get(size, False) and len(_blocks.get(size, ())) >= n_held + 2
+def _hand_out(size: Size, t: Tensor) -> Tensor:
+    _blocks.setdefault(size, {})[_base(t)] = StorageWeakRef(t.untyped_storage())
+    return t
 
 
-def _met(key: Key, t: Tensor, dev: torch.device, exploring: bool) -> None:
-    size = (dev.index, key[1])
-    known = _blocks.setdefault(size, set())
-    if _base(t) not in known:
-        if known and not exploring and len(known) >= 2:
-            _frozen[size] = True                     # the allocator grew to serve a held offer: stop holding
-        known.add(_base(t))
+def _cached_better(key: Key, size: Size, held: List[Tensor], than: float) -> bool:
+    """Is a block of this size known to sit in the allocator's cache (handed out earlier, its storage dead since) that
+    is not known to cost `than` or more for this source?  Pure bookkeeping: the allocator is not asked."""
+    mine = {_base(t) for t in held}
+    for addr, ref in _blocks.get(size, {}).items():
+        if addr in mine or ref is None or not ref.expired():
+            continue
+        cost = _cost(key, addr)
+        if cost is None or cost < than:
+            return True
+    return False
 
 
 def key_for(name: str, out_bytes: int, src: Tensor) -> Optional[Key]:
@@ -152,53 +137,64 @@ def key_for(name: str, out_bytes: int, src: Tensor) -> Optional[Key]:
 
 
 def empty_for(shape, dtype: torch.dtype, dev: torch.device, key: Key) -> Tensor:
-    """torch.empty(shape) for an output the mover is about to fill — in a block that is not known to be slow for this
-    source, if one can be had."""
+    """torch.empty(shape) for an output the mover is about to fill — in a cached block that is not known to be slow
+    for this source, if the cache is known to hold one."""
     with _lock:
         return _empty_for(shape, dtype, dev, key)
 
 
 def _empty_for(shape, dtype: torch.dtype, dev: torch.device, key: Key) -> Tensor:
     _harvest()
+    size: Size = (dev.index, key[1])
     out = torch.empty(shape, dtype=dtype, device=dev)
-    tried = _tried.setdefault(key, set())
-
-    def fresh(t: Tensor) -> bool:          # not moved into MIN_SAMPLES times yet: its cost is not known
-        return _launched.get((key, _base(t)), 0) < MIN_SAMPLES
-
-    exploring = len(tried) < EXPLORE or any(_launched.get((key, b), 0) < MIN_SAMPLES for b in tried)
-    _met(key, out, dev, True)
-    if exploring and not fresh(out):
-        # exploration: prefer a block whose cost for this source is not known yet — one never moved into, or moved
-        # into once (the first launch into fresh memory also pays for its page tables and does not count)
-        spare = [out]
-        while len(spare) < MAX_HELD and _may_ask_again(key, len(spare), dev, True):
-            nxt = torch.empty(shape, dtype=dtype, device=dev)
-            _met(key, nxt, dev, True)
-            if fresh(nxt):
-                stats['explored'] += 1
-                return nxt
-            spare.append(nxt)
-        out = spare[0]
-        del spare
     slow = _verdict(key, _base(out))
-    if slow is None:
+    if slow is None or _frozen.get(size, False):
         stats['taken_good' if (key, _base(out)) in _times else 'taken_untimed'] += 1
-        return out
+        return _hand_out(size, out)
     held: List[Tuple[float, Tensor]] = [(slow, out)]
-    while len(held) < MAX_HELD and _may_ask_again(key, len(held), dev, False):
-        out = torch.empty(shape, dtype=dtype, device=dev)      # the held offers are alive: this is another block
-        _met(key, out, dev, False)
-        slow = _verdict(key, _base(out))
-        if slow is None:
+    while len(held) <= MAX_EXTRA_BLOCKS and _cached_better(key, size, [t for _, t in held], min(c for c, _ in held)):
+        try:
+            nxt = torch.empty(shape, dtype=dtype, device=dev)      # the held offers are alive: this is another block
+        except torch.OutOfMemoryError:
+            _frozen[size] = True
+            stats['oom'] += 1
+            break
+        if _base(nxt) not in _blocks.get(size, {}):
+            # the allocator grew (or re-carved its cache) to serve this: stop choosing for this size
+            _frozen[size] = True
+            stats['frozen'] += 1
+            _hand_out(size, held[0][1])       # (the first offer goes back to the cache; remember it is there)
+            return _hand_out(size, nxt)
+        cost = _verdict(key, _base(nxt))
+        if cost is None:
             stats['rejected'] += len(held)
-            stats['taken_good' if (key, _base(out)) in _times else 'taken_untimed'] += 1
-            return out
-        held.append((slow, out))
+            stats['taken_good' if (key, _base(nxt)) in _times else 'taken_untimed'] += 1
+            for _, t in held:
+                _hand_out(size, t)            # dies on return: back in the cache
+            return _hand_out(size, nxt)
+        held.append((cost, nxt))
     held.sort(key=lambda x: x[0])
     stats['rejected'] += len(held) - 1
     stats['settled'] += 1
-    return held[0][1]
+    for _, t in held[1:]:
+        _hand_out(size, t)
+    return _hand_out(size, held[0][1])
+
+
+def warm(nbytes: int, device=None, blocks: int = 3) -> int:
+    """Opt-in, at the caller's expense: put `blocks` blocks of `nbytes` into torch's allocator cache so that
+    empty_for has something to choose from.  Returns how many it got (an OutOfMemoryError ends it early)."""
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    got: List[Tensor] = []
+    with _lock:
+        for _ in range(max(0, blocks)):
+            try:
+                got.append(torch.empty(nbytes, dtype=torch.uint8, device=dev))
+            except torch.OutOfMemoryError:
+                break
+        for t in got:
+            _hand_out((dev.index, nbytes), t)
+    return len(got)
 
 
 def begin(key: Key, out: Tensor, stream: torch.cuda.Stream):
@@ -206,7 +202,6 @@ def begin(key: Key, out: Tensor, stream: torch.cuda.Stream):
     e0.record(stream)
     with _lock:
         _tried.setdefault(key, set()).add(_base(out))
-        _launched[(key, _base(out))] = _launched.get((key, _base(out)), 0) + 1
     return key, _base(out), e0
 
 
@@ -236,13 +231,11 @@ def reader_begin(name: str, data: Tensor, stream: torch.cuda.Stream):
 
 
 def forget() -> None:
-    """Drop everything learned (after torch.cuda.empty_cache(): a storage address may come back on other memory)."""
-    _times.clear()
-    _pending.clear()
-    _tried.clear()
-    _blocks.clear()
-    _frozen.clear()
-    _readers.clear()
-    _launched.clear()
-    _no_room.clear()
-
+    """Drop everything learned (call after torch.cuda.empty_cache(): a storage address may come back on other memory)."""
+    with _lock:
+        _times.clear()
+        _pending.clear()
+        _tried.clear()
+        _blocks.clear()
+        _frozen.clear()
+        _readers.clear()
