@@ -157,7 +157,8 @@ def parity_leg(ta, data, lens_host, out_bf16, n_sample=256):
         'sum_f32_vs_reference_fold_over_sum_abs': float(np.max(np.abs(got['sum'] - ref32['sum']) / sum_abs)),
         'sum_f32_vs_fp64_over_sum_abs': float(np.max(np.abs(got['sum'] - ref64_sum) / sum_abs)),
         'reference_fold_f32_vs_fp64_over_sum_abs': float(np.max(np.abs(ref32['sum'] - ref64_sum) / sum_abs)),
-        'sum_f32_vs_reference_fold_max_rel': float(np.max(np.abs(got['sum'] - ref32['sum']) / np.maximum(np.abs(ref32['sum']), 1e-30))),
+        'sum_f32_vs_fp64_max_rel': float(np.max(np.abs(got['sum'] - ref64_sum) / np.maximum(np.abs(ref64_sum), 1e-30))),
+        'reference_fold_f32_vs_fp64_max_rel': float(np.max(np.abs(ref32['sum'] - ref64_sum) / np.maximum(np.abs(ref64_sum), 1e-30))),
         'max_exact': bool(np.array_equal(got['max'], ref32['max'])),
         'logsumexp_f32_vs_reference_max_rel': float(np.max(np.abs(got['logsumexp'] - ref32['logsumexp']) / np.maximum(np.abs(ref32['logsumexp']), 1e-30))),
         'logsumexp_f32_vs_fp64_max_rel': float(np.max(np.abs(got['logsumexp'] - ref64_lse) / np.maximum(np.abs(ref64_lse), 1e-30))),

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RUA_ABI_VERSION 2
+#define RUA_ABI_VERSION 3
 
 /* argument errors (negative so they cannot collide with hipError_t) */
 #define RUA_EINVAL   (-1)  /* bad enum / null pointer / negative size      */
@@ -62,7 +62,9 @@ typedef struct rua_layout {
   const int64_t* sorted;   /* PACK: sorted_indices [B]                      */
   const int64_t* unsorted; /* PACK: unsorted_indices [B]                    */
   const int64_t* bptr;     /* LIST: [M]; NULL = all zeros (tptr then indexes ONE sequence,
-                              e.g. a flat row gather `data[key]` against LEFT{B=1})      */
+                              e.g. a flat row gather `data[key]` against LEFT{B=1}; a negative
+                              entry of such a flat list wraps by the source's n_rows, like
+                              torch's own indexing in core/get.py:29, core/set.py:30)   */
   const int64_t* tptr;     /* LIST: [M]                                     */
   /* PACK, optional: a (rank x time) tile table that lets narrow-row C/L/R <-> P transposes move
    * multi-row runs on BOTH sides (rua_move_rows picks it up when rows are <= 64 bytes) .        */
@@ -189,6 +191,10 @@ enum rua_op {
 #define RUA_OP_SCRATCH_CLEAN 0x100
 #define RUA_OP_NO_EMPTY      0x200
 int64_t rua_reduce_ws_bytes(int64_t n_rows, int64_t H, int32_t dtype, int64_t split_rows);
+/* Waves (1, 2 or 4) that share one sequence in rua_segment_reduce for a 16-byte-aligned payload of `row_bytes`-wide
+ * rows, B sequences, n_rows rows in all — the launcher's own rule, exported so that a host planner pricing
+ * `split_rows` (a unit streams team-times as fast) cannot drift from it. */
+int rua_reduce_team_waves(int64_t n_rows, int64_t B, int64_t row_bytes);
 int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* data, void* out,
                        int64_t H, int32_t dtype, int32_t op, int32_t include_self,
                        uint64_t empty_bits, void* extreme, int64_t split_rows, void* ws, void* ties_out,

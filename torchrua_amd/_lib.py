@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must be imported first: maps the HIP runtime our li
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RUA_LIB_PATH') or os.path.join(_HERE, 'librua_hip.so')   # env: developer A/B of builds
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 # enum rua_kind
 CAT, LEFT, PACK, RIGHT, LIST = 0, 1, 2, 3, 4
 # enum rua_tmap
@@ -60,6 +60,7 @@ SYMBOLS = {
     'rua_move_rows': (c_int, [POINTER(RuaLayout), POINTER(RuaLayout), c_int32, c_int64, c_void_p, c_void_p,
                               c_int64, c_void_p, c_int64, c_int32, c_void_p]),
     'rua_reduce_ws_bytes': (c_int64, [c_int64, c_int64, c_int32, c_int64]),
+    'rua_reduce_team_waves': (c_int, [c_int64, c_int64, c_int64]),
     'rua_segment_reduce': (c_int, [POINTER(RuaLayout), c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                                    c_int32, c_uint64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     'rua_pack_reduce': (c_int, [POINTER(RuaLayout), POINTER(RuaLayout), c_void_p, c_void_p, c_void_p, c_int64, c_int32,

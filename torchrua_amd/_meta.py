@@ -98,12 +98,6 @@ def host_lens(token_sizes: Tensor) -> Tensor:
     hit = _memo_get(token_sizes, 'host')
     if hit is not None:
         return hit
-    alias = _memo_get(token_sizes, 'host_alias')
-    if alias is not None:
-        # the caller's own host tensor (with_host_sizes does not copy it): valid while nobody wrote into it
-        if _version(alias[0]) == alias[1]:
-            return alias[0]
-        token_sizes.__dict__['_rua_memo'].pop('host_alias', None)
     return _memo_put(token_sizes, 'host', _read_back(token_sizes))
 
 
@@ -121,13 +115,21 @@ def _read_back(t: Tensor) -> Tensor:
     return out
 
 
-def attach_host(token_sizes: Tensor, host: Tensor, alias: bool = False) -> None:
-    """Record the host copy of a device length vector.  alias=True: `host` belongs to the caller and is only
-    borrowed, guarded by its version counter (a later in-place write sends host_lens() back to the device copy)."""
-    if alias:
-        _memo_put(token_sizes, 'host_alias', (host, _version(host)))
-    else:
-        _memo_put(token_sizes, 'host', host)
+def attach_host(token_sizes: Tensor, host: Tensor) -> None:
+    """Record the host copy of a device length vector.  `host` must be the library's own (nobody else writes it)."""
+    _memo_put(token_sizes, 'host', host)
+
+
+def private_host_copy(host: Tensor) -> Tensor:
+    """A copy of the caller's host lengths that the library owns (a loader that refills its buffer through
+    numpy / data_ptr does not bump `_version`, so a borrowed mirror can go stale silently).  It comes from torch's
+    PINNED caching host allocator: freeing it is a free-list push, not an munmap (a fresh pageable 512 KiB block per
+    step stalled the GPU queues on this platform — see _read_back), and the upload reads straight from it, so the
+    copy replaces the one into a staging slot instead of adding to it."""
+    src = _as_lens(host.detach())
+    out = torch.empty(src.shape, dtype=torch.long, pin_memory=True)
+    np.copyto(out.numpy(), src.numpy())
+    return out
 
 
 def max_len(token_sizes: Tensor) -> int:
@@ -144,7 +146,7 @@ def known_no_empty(token_sizes: Optional[Tensor]) -> bool:
         return False
     hit = _memo_get(token_sizes, 'min')
     if hit is None:
-        if token_sizes.is_cuda and _memo_get(token_sizes, 'host') is None and _memo_get(token_sizes, 'host_alias') is None:
+        if token_sizes.is_cuda and _memo_get(token_sizes, 'host') is None:
             return False
         h = host_lens(token_sizes)
         hit = _memo_put(token_sizes, 'min', int(h.detach().numpy().min()) if h.numel() else 1)
@@ -231,7 +233,7 @@ def adopt_pack(p, lens: Tensor, boff: Tensor, bsz_dev: Tensor) -> None:
     # plain-data memos: `lens` itself memoises this very batch_sizes (core._pack_meta), and batch_sizes pointing
     # back at it would close a reference cycle per pack() — cyclic garbage that forces full GC passes.
     alias = lens.detach()
-    for key in ('host', 'host_alias', 'max', 'sum', 'off'):
+    for key in ('host', 'max', 'sum', 'off'):
         hit = _memo_get(lens, key)
         if hit is not None:
             _memo_put(alias, key, hit)
@@ -266,6 +268,10 @@ def _selftest_inputs():
     yield torch.cat([up[:n // 2], up[:n // 2].flip(0)])          # organ pipe
     yield (up * 7919) % 13                                       # few distinct values, periodic
     yield torch.cat([torch.zeros(n // 2, dtype=torch.long), torch.ones(n // 2, dtype=torch.long)])
+    # a median-of-3 killer (McIlroy's adversary run against this very introsort: scripts/exp/sort_killer.cpp), 20 000
+    # elements with ties: the only kind of input that exhausts the depth budget and reaches the heap-sort branch
+    killer = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'selftest_sort_killer.npy')
+    yield torch.from_numpy(np.load(killer).astype(np.int64))
 
 
 def _host_sort_decide() -> int:
@@ -273,7 +279,8 @@ def _host_sort_decide() -> int:
 
     RUA_HOST_SORT=torch keeps the reference's own call; RUA_HOST_SORT=<n> fixes the thread count.  Otherwise the
     library's reproduction of that sort (rua_host.cpp) is used IF it returns exactly torch.sort's permutation on a
-    battery of inputs (tie-heavy, sorted, reversed, constant, organ-pipe, sizes around the 16-element leaf) —
+    battery of inputs (tie-heavy, sorted, reversed, constant, organ-pipe, sizes around the 16-element leaf, a median-of-3 killer
+    that drives it into the heap-sort branch) —
     a mismatch (another C++ runtime behind torch, say) silently keeps the reference's call.  The thread count is the
     fastest of {1, 2, 4, 8} on a 64 Ki-element sample, so a host that serialises threads is not made slower."""
     env = os.environ.get('RUA_HOST_SORT', '').strip().lower()
@@ -339,8 +346,7 @@ def known_max_len(token_sizes: Optional[Tensor]) -> Optional[int]:
     hit = _memo_get(token_sizes, 'max')
     if hit is not None:
         return hit
-    if not token_sizes.is_cuda or _memo_get(token_sizes, 'host') is not None or \
-            _memo_get(token_sizes, 'host_alias') is not None:
+    if not token_sizes.is_cuda or _memo_get(token_sizes, 'host') is not None:
         return max_len(token_sizes)
     return None
 
@@ -506,6 +512,12 @@ class _StagingRing:
             self.busy[i] = False
 
     def _commit(self, i: int, staged: Tensor, dev: torch.device) -> Tensor:
+        out, ev = self.h2d(staged, dev)
+        self.events[i] = ev
+        return out
+
+    def h2d(self, staged: Tensor, dev: torch.device):
+        """Enqueue the H2D of a PINNED host tensor; returns (device tensor, event that follows the copy)."""
         cur = torch.cuda.current_stream(dev)
         ev = torch.cuda.Event()
         if staged.numel() < self.SIDE_MIN_ELEMS or torch.cuda.is_current_stream_capturing():
@@ -535,8 +547,7 @@ class _StagingRing:
                 torch.cuda.set_stream(cur)
             cur.wait_event(ev)
             out.record_stream(cur)
-        self.events[i] = ev
-        return out
+        return out, ev
 
     def upload(self, host: Tensor, dev: torch.device) -> Tensor:
         i, staged = self.reserve(host.shape, host.dtype)
@@ -567,6 +578,14 @@ def to_device_async(host: Tensor, dev: torch.device) -> Tensor:
     if dev.type != 'cuda' or host.numel() == 0 or not host.is_contiguous():
         return host.to(dev)
     return _ring(dev).upload(host, dev)
+
+
+def pinned_to_device_async(pinned: Tensor, dev: torch.device) -> Tensor:
+    """H2D of a pinned host tensor the caller keeps alive (torch's host allocator does not hand a pinned block out
+    again while a copy from it is pending), on the upload stream."""
+    if pinned.numel() == 0:
+        return pinned.to(dev)
+    return _ring(dev).h2d(pinned, dev)[0]
 
 
 def sorted_indices_to_device(host_lens_: Tensor, dev: torch.device) -> Tensor:
@@ -615,7 +634,6 @@ ENOUGH_UNITS = 4096          # (sequence, column chunk) units that keep every SI
 WAVE_RATE = 4e9              # bytes/s ONE wave streams (8 KiB in flight / ~2 us; profiles/r01_skew.txt)
 STREAM_RATE = 5e12           # bytes/s the whole chip reads through the reducer
 SPLIT_FIXED_S = 30e-6        # what arming costs: one memset, a tail and a combine launch
-TEAM_MAX_UNITS = 16384       # rua_reduce_impl.h: units up to which a team of waves may share one unit
 
 
 def reduce_split_rows(lay: Lay, row_bytes: int = 1024, team_ok: bool = True) -> int:
@@ -637,12 +655,8 @@ def reduce_split_rows(lay: Lay, row_bytes: int = 1024, team_ok: bool = True) -> 
     # rows up to 1 KiB on the vector path, at most 16 384 units, >= 4 row groups per wave): a unit then streams
     # 2-4x as fast, and splitting — three launches and a pass over fp32 partials — is for real outliers only
     team = 1
-    units = max(lay.B, 1) * n_chunks
-    if team_ok and 0 < row_bytes <= 1024 and row_bytes % 16 == 0 and units <= TEAM_MAX_UNITS:
-        lanes = -(-int(row_bytes) // 16)
-        rows_per_group = max(1, 64 // (1 << max(0, (lanes - 1).bit_length()))) * 8
-        groups = n // max(lay.B, 1) // rows_per_group
-        team = 4 if groups >= 16 else 2 if groups >= 8 else 1
+    if team_ok and 0 < row_bytes <= 1024 and row_bytes % 16 == 0:
+        team = L.load().rua_reduce_team_waves(n, max(lay.B, 1), int(row_bytes))      # the launcher's own rule
     wave_rate = WAVE_RATE * team
     ideal_rows = int(0.75 * n * row_bytes / STREAM_RATE * wave_rate / rb_unit)   # rows a unit walks in 3/4 of the balanced time
     fixed_rows = int(SPLIT_FIXED_S * wave_rate / rb_unit)

@@ -150,11 +150,13 @@ _scratch_pair = threading.Lock()
 
 def extreme_scratch(dev, lay: M.Lay) -> Tuple[Tensor, int]:
     key = (dev.index, torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if dev.index is None else dev.index))
+    if torch.cuda.is_current_stream_capturing():
+        # inside a graph capture ALWAYS a buffer of the capture's own (zeroed by the legacy initialising launch), even
+        # when this stream already has a persistent one: a graph that baked the shared scratch in could be replayed on
+        # another stream while eager max / min runs on this one, and the two would race on its flag and ticket words
+        return torch.empty(67, dtype=torch.long, device=dev), (L.OP_NO_EMPTY if lay.no_empty else 0)
     buf = _scratch.get(key)
     if buf is None:
-        if torch.cuda.is_current_stream_capturing():
-            # first use inside a graph capture: a buffer of the capture's own (zeroed by the legacy initialising launch)
-            return torch.empty(67, dtype=torch.long, device=dev), (L.OP_NO_EMPTY if lay.no_empty else 0)
         buf = _scratch[key] = torch.zeros(67, dtype=torch.long, device=dev)
     return buf, L.OP_SCRATCH_CLEAN | (L.OP_NO_EMPTY if lay.no_empty else 0)
 

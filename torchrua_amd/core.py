@@ -209,6 +209,10 @@ R.right = _to_self
 
 
 # ------------------------------------------------------------------ core/get.py / core/set.py
+_tensor_getitem = Tensor.__getitem__       # torch's own, whatever patch_tensor_indexing() does later
+_tensor_setitem = Tensor.__setitem__
+
+
 def _is_ptr_pair(key) -> bool:
     return isinstance(key, tuple) and len(key) == 2 and isinstance(key[0], Tensor) and isinstance(key[1], Tensor)
 
@@ -238,7 +242,7 @@ def _gather_flat(raw: Tensor, index: Tensor) -> Tensor:
     """raw[index] for a row index of any shape (core/get.py:29,42,61,74) via the mover."""
     rows = _row_index(index, int(raw.size(0)))
     if rows is None:
-        return raw[index]   # multi-dimensional masks etc.: not a row-index gather
+        return _tensor_getitem(raw, index)   # multi-dimensional masks etc.: not a row-index gather
     index = rows
     flat = index.reshape(-1)
     shape = tuple(index.shape) + tuple(raw.shape[1:])
@@ -248,19 +252,34 @@ def _gather_flat(raw: Tensor, index: Tensor) -> Tensor:
     return O.launch_move(plan, raw)
 
 
+def _needs_autograd(raw: Tensor, value) -> bool:
+    """Would torch record this in-place write?  (the mover writes into raw.detach(); a gradient to `value`
+    or through a non-leaf `raw` would be dropped, a leaf that requires grad would be overwritten without torch's
+    error.)  Such writes take torch's own setitem — what the reference does (core/set.py:10-18)."""
+    return torch.is_grad_enabled() and (raw.requires_grad or (isinstance(value, Tensor) and value.requires_grad))
+
+
+def _written(raw: Tensor) -> None:
+    """The mover wrote into raw's storage behind autograd's back: bump the version counter, so that autograd's
+    saved-tensor check and this library's own version-keyed memos see the write."""
+    if not raw.is_inference():
+        torch.autograd.graph.increment_version(raw)
+
+
 def _scatter_flat(raw: Tensor, index: Tensor, value) -> None:
     """raw[index] = value (core/set.py:30,45,67,82) via the mover in scatter mode."""
     rows = _row_index(index, int(raw.size(0)))
-    if rows is None or not raw.is_contiguous():
-        raw[index] = value
+    if rows is None or not raw.is_contiguous() or _needs_autograd(raw, value):
+        _tensor_setitem(raw, index, value)
         return
     index = rows
     flat = index.reshape(-1)
     value = torch.as_tensor(value, dtype=raw.dtype, device=raw.device)
-    value = value.expand(tuple(index.shape) + tuple(raw.shape[1:])).contiguous()
+    value = value.detach().expand(tuple(index.shape) + tuple(raw.shape[1:])).contiguous()
     plan = O.MovePlan(M.lay_list(None, flat), M.lay_flat(int(raw.size(0))), raw.shape, flags=K.MOVE_SCATTER,
                       name='scatter_flat')
     O.launch_move(plan, value, out=raw.detach())
+    _written(raw)
 
 
 def _getitem(cls):
@@ -293,11 +312,16 @@ def _setitem(cls):
             if not self.data.is_contiguous():
                 raise K.RuaError('__setitem__ needs contiguous storage')
             hidden = _hidden(self)
+            if _needs_autograd(self.data, value):
+                # autograd has to see the write: torch's own setitem on the flat rows the kernels compute
+                _tensor_setitem(self.raw(), _flat_rows(self, (bp, tp)), value)
+                return None
             value = torch.as_tensor(value, dtype=self.data.dtype, device=self.data.device)
-            value = value.expand((bp.numel(),) + hidden).contiguous()
+            value = value.detach().expand((bp.numel(),) + hidden).contiguous()
             plan = O.MovePlan(M.lay_list(bp, tp), describe(self), self.data.shape, flags=K.MOVE_SCATTER,
                               name='setitem')
             O.launch_move(plan, value, out=self.data.detach())
+            _written(self.data)
             return None
         if isinstance(key, Tensor):
             _scatter_flat(self.raw(), key, value)
@@ -309,10 +333,6 @@ def _setitem(cls):
 for _cls in (C, L, P, R):
     _cls.__getitem__ = _getitem(_cls)
     _cls.__setitem__ = _setitem(_cls)
-
-
-_tensor_getitem = Tensor.__getitem__
-_tensor_setitem = Tensor.__setitem__
 
 
 def patch_tensor_indexing() -> None:
@@ -363,12 +383,11 @@ R.new = staticmethod(lambda tensors, fill_value=0: _new_cat(tensors).right(fill_
 
 
 def with_host_sizes(data: Tensor, token_sizes_host: Tensor) -> C:
-    """C(data, token_sizes) from lengths that live on the host (what C.new does for a list)."""
-    host = token_sizes_host.to(dtype=torch.long, device='cpu')
-    dev_sizes = M.to_device_async(host, data.device)
-    # The mirror outlives this call.  When `host` is the caller's own tensor it is borrowed, not copied, and guarded
-    # by its version counter: a loader that reuses its length buffer (an in-place write) invalidates the mirror and
-    # later pack()/size() calls read the lengths back from the device copy instead.  (A private copy per call would
-    # be a fresh 512 KiB host allocation per step at the north-star size; see _meta._read_back for what that costs.)
-    M.attach_host(dev_sizes, host, alias=host is token_sizes_host)
+    """C(data, token_sizes) from lengths that live on the host (what C.new does for a list).  The library keeps its
+    OWN pinned copy as the host mirror — the caller may refill its buffer at once, by any means — and uploads from that
+    copy, so the privacy costs no extra pass (see _meta.private_host_copy)."""
+    K.require_device(data)
+    mirror = M.private_host_copy(token_sizes_host)
+    dev_sizes = M.pinned_to_device_async(mirror, data.device)
+    M.attach_host(dev_sizes, mirror)
     return C(data=data, token_sizes=dev_sizes)

@@ -11,6 +11,19 @@
 
 namespace rua {
 
+// The reducer's wave-team rule (seg_reduce_team_kernel), in ONE place: the launcher (rua_reduce_impl.h) and the host
+// planner that prices long-sequence splitting (rua_reduce_team_waves -> _meta.reduce_split_rows) both call it.
+// Vector path only (16-byte lanes, rows up to 1 KiB): a team of 2 or 4 waves shares a unit when an average unit holds
+// at least 4 row groups per wave and there are at most `REDUCE_TEAM_MAX_UNITS` units.
+constexpr int REDUCE_UNROLL_T = 8;                      // rows in flight per wave (RUA_UNROLL_T overrides it in A/B builds)
+constexpr int64_t REDUCE_TEAM_MAX_UNITS = 16384;        // beyond this one wave per unit keeps the chip balanced by itself
+inline int reduce_team_waves(int64_t n_rows, int64_t B, int lp_log2, int64_t units, int unroll_t = REDUCE_UNROLL_T) {
+  if (units <= 0 || units > REDUCE_TEAM_MAX_UNITS) return 1;
+  const int64_t rows_per_group = (int64_t)(RUA_WAVE >> lp_log2) * unroll_t;
+  const int64_t groups = n_rows / (B > 0 ? B : 1) / rows_per_group;       // row groups of an average unit
+  return groups >= 4 * 4 ? 4 : groups >= 4 * 2 ? 2 : 1;
+}
+
 __device__ __forceinline__ int64_t seq_len(const rua_layout& L, int64_t b) {
   return (L.lens ? L.lens[b] : 0) + L.len_add;
 }

@@ -181,7 +181,10 @@ __global__ __launch_bounds__(BLOCK) void move_rows_kernel(rua_layout D, rua_layo
         if (token) {
           // caller-supplied (batch_ptr, token_ptr) pairs are range-checked: a bad pair yields the fill /
           // is skipped instead of faulting the GPU (the reference raises an IndexError there)
-          if (D.kind == RUA_LIST && (b < 0 || b >= S.B)) { b = 0; t = -1; }
+          if (D.kind == RUA_LIST) {
+            if (!D.bptr) { if (t < 0) t += S.n_rows; }        // a flat row list wraps negatives like torch's indexing
+            else if (b < 0 || b >= S.B) { b = 0; t = -1; }
+          }
           const int64_t slen = seq_len(S, b);
           const int64_t dlen = D.kind == RUA_LIST ? slen : seq_len(D, b);
           const int64_t ts = apply_tmap(tmap, targ, t, slen, dlen);

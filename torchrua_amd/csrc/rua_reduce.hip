@@ -31,6 +31,15 @@ using namespace rua;
 
 extern "C" {
 
+int rua_reduce_team_waves(int64_t n_rows, int64_t B, int64_t row_bytes) {
+  // what dispatch_reduce_main decides for a 16-byte-aligned payload whose rows are a multiple of 16 bytes
+  if (row_bytes <= 0 || row_bytes % 16 != 0 || row_bytes > 16 * RUA_WAVE) return 1;
+  const int64_t lpr = row_bytes / 16;
+  int lp_log2 = 0;
+  while ((1 << lp_log2) < lpr && lp_log2 < 6) ++lp_log2;
+  return reduce_team_waves(n_rows, B, lp_log2, B);      // one column chunk per row: units = sequences
+}
+
 int rua_segment_reduce_backward(const rua_layout* lay, const int64_t* perm, const void* data, const void* out,
                                 const void* grad_out, void* grad_in, int64_t H, int32_t dtype, int32_t op,
                                 int32_t include_self, int64_t split_rows, void* ws, void* ties,

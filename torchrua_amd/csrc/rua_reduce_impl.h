@@ -566,7 +566,6 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
 // at any moment the team reads one contiguous run — the partials meet in LDS and wave 0 merges them in wave order
 // (a fixed association: bitwise reproducible).  TEAM = blockDim.x / 64 (2 or 4).
 constexpr int TEAM_MAX = 4;
-constexpr int64_t TEAM_MAX_UNITS = 16384;   // beyond this one wave per unit keeps the chip balanced by itself
 template <typename T, int EPL, int OP, bool NT>
 __global__ __launch_bounds__(RUA_WAVE * TEAM_MAX) void seg_reduce_team_kernel(
     rua_layout L, const int64_t* __restrict__ perm, const T* __restrict__ data, T* __restrict__ out, int64_t H,
@@ -1480,10 +1479,8 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
     return (int)hipGetLastError();
   }
   // few-but-long units: a team of waves per unit (seg_reduce_team_kernel) — vector path, rows up to 1 KiB, no split
-  if (vec_ok && !wide && !copy && !(split > 0 && ws) && blocks > 0 && blocks <= TEAM_MAX_UNITS) {
-    const int64_t rows_per_group = (int64_t)(RUA_WAVE >> lp_log2) * UNROLL_T;
-    const int64_t groups = L.n_rows / (L.B > 0 ? L.B : 1) / rows_per_group;       // row groups of an average unit
-    const int team = groups >= 4 * 4 ? 4 : groups >= 4 * 2 ? 2 : 1;
+  if (vec_ok && !wide && !copy && !(split > 0 && ws)) {
+    const int team = reduce_team_waves(L.n_rows, L.B, lp_log2, blocks, UNROLL_T);   // (rua_dev.h: the one rule)
     if (team > 1) {
       T ev;
       __builtin_memcpy(&ev, &empty_bits, sizeof(T));
