@@ -7,6 +7,8 @@ never reference source.  Run here (the reference never travels to the GPU box):
 Outputs:
     tests/golden/small.npz     every hot-path function on tiny + seeded random cases
     tests/golden/sha.json      SHA-256 of the reference's outputs on reduced BASELINE.json configs
+    tests/golden/r3.npz        (--round3) compose, Z- / tensor-keyed indexing, split, and gradients of every op under
+                               one fixed cotangent, from the reference's CPU autograd
 """
 import hashlib
 import json
@@ -372,8 +374,323 @@ def foreign():
     print('wrote', len(store), 'foreign-order arrays;', os.path.getsize(os.path.join(OUT, 'foreign.npz')), 'bytes')
 
 
+# ------------------------------------------------------------------------------------------------- round 3
+def cot_like(t, salt=0):
+    """The fixed cotangent of every gradient fixture: a closed form of the element's position, so that the tests rebuild
+    it from the output's shape alone (tests/helpers.py: cotangent)."""
+    n = t.numel()
+    a = ((np.arange(n, dtype=np.float64) + 1.0 + salt) * 0.6180339887498949) % 1.0 - 0.5
+    return torch.from_numpy(a.astype(np.float32)).reshape(t.shape).to(t.dtype)
+
+
+def token_mask(z):
+    """[B, T, 1...] 0/1 mask of the token slots of a padded container's storage (None for C / P)."""
+    if isinstance(z, (C, P)):
+        return None
+    t_phys = z.data.size(1)
+    pos = torch.arange(t_phys)[None, :]
+    lens = z.token_sizes[:, None]
+    if isinstance(z, L):
+        m = pos < lens
+    else:
+        t_log = int(z.token_sizes.max())
+        m = (pos >= t_log - lens) & (pos < t_log)
+    return m.reshape(m.shape + (1,) * (z.data.dim() - 2)).to(z.data.dtype)
+
+
+def grad_wrt(out_data, inputs, mask=None, salt=0):
+    cot = cot_like(out_data, salt)
+    if mask is not None:
+        cot = cot * mask
+    return torch.autograd.grad(out_data, inputs, cot, allow_unused=True)
+
+
+def as_kind(c, k, fill=FILL):
+    return {'C': c.cat, 'L': lambda: c.left(fill), 'P': c.pack, 'R': lambda: c.right(fill)}[k]()
+
+
+def grad_layout_case(case, lens, H, seed):
+    """d(out)/d(data) for every cast, select and getitem of the hot path, from the reference's CPU autograd under the
+    fixed cotangent (the reference's contract is assert_grad_close on each: tests/test_layout.py:28-88,
+    tests/test_select.py:27-111).  Cotangents on the padding slots of L / R outputs are zeroed (what the reference puts
+    there is an artefact of its construction — copies of storage row 0 for roll, live tokens for trunc)."""
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.as_tensor(lens, dtype=torch.long)
+    N = int(lens.sum())
+    data = torch.randn((N, H), generator=g)
+    put(case, 'lens', lens)
+    put(case, 'data', data)
+    T, m = int(lens.max()), int(lens.min())
+    M = max(2, N)                      # keys with repeats
+    bsel = torch.randint(0, lens.numel(), (M,), generator=g)
+    tsel = (torch.rand(M, generator=g) * lens[bsel]).long()
+    put(case, 'key.batch', bsel)
+    put(case, 'key.token', tsel)
+    for k in 'CLPR':
+        def fresh():
+            x = data.clone().requires_grad_(True)
+            return x, as_kind(C(x, lens), k)
+        for dst in 'CLPR':
+            x, z = fresh()
+            out = as_kind(z, dst)
+            put(case, f'grad.cast.{k}.{dst}', grad_wrt(out.data, x)[0])
+        x, z = fresh()
+        put(case, f'grad.last.{k}', grad_wrt(z.last(), x)[0])
+        for n in sorted({1, m}):
+            x, z = fresh()
+            out = z.head(n)
+            put(case, f'grad.head.{k}.{n}', grad_wrt(out.data, x, token_mask(out))[0])
+        for s_ in sorted({-1, 2, T + 1}):
+            x, z = fresh()
+            out = z.roll(s_)
+            put(case, f'grad.roll.{k}.{s_}', grad_wrt(out.data, x, token_mask(out))[0])
+        x, z = fresh()
+        out = z.rev()
+        put(case, f'grad.rev.{k}', grad_wrt(out.data, x, token_mask(out))[0])
+        for a, b in sorted({(0, 0), (m - 1, 0), ((m - 1) // 2, (m - 1) - (m - 1) // 2)}):
+            x, z = fresh()
+            out = z.trunc((a, b))
+            put(case, f'grad.trunc.{k}.{a}.{b}', grad_wrt(out.data, x, token_mask(out))[0])
+        x, z = fresh()
+        put(case, f'grad.getitem.{k}', grad_wrt(z[bsel, tsel], x)[0])
+
+
+def grad_reduce_case(case, lens, H, seed, ties=False):
+    """Gradients of segment_* and scatter_* (tests/test_reduce.py:37...360): w.r.t. the rows, and for scatter_* also
+    w.r.t. `tensor`.  ties=True draws the values from {0, 1, 2}: tied extrema (torch.segment_reduce shares a positive
+    gradient among them; index_reduce always shares), zeros inside products."""
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.as_tensor(lens, dtype=torch.long)
+    N, S = int(lens.sum()), lens.numel()
+    if ties:
+        data = torch.randint(0, 3, (N, H), generator=g).float()
+        tensor = torch.randint(0, 3, (S, H), generator=g).float()
+    else:
+        data = torch.randn((N, H), generator=g)
+        tensor = torch.randn((S, H), generator=g)
+    put(case, 'lens', lens)
+    put(case, 'data', data)
+    for name in ('max', 'min', 'sum', 'mean', 'prod', 'logsumexp', 'head', 'last'):
+        if (lens == 0).any() and name in ('head', 'last'):
+            continue
+        x = data.clone().requires_grad_(True)
+        try:
+            out = getattr(ref, f'segment_{name}')(x, lens)
+            put(case, f'grad.segment_{name}', grad_wrt(out, x)[0])
+        except RuntimeError as e:
+            skipped.append(f'{case}/grad.segment_{name}: {type(e).__name__}')
+    index = torch.repeat_interleave(torch.arange(S), lens)
+    perm = torch.randperm(N, generator=g)
+    put(case, 'scatter.index', index[perm])
+    put(case, 'scatter.perm', perm)
+    put(case, 'scatter.tensor', tensor)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for name in ('max', 'min', 'sum', 'mean', 'prod', 'logsumexp'):
+            for inc in (False, True):
+                src = data[perm].clone().requires_grad_(True)
+                ten = tensor.clone().requires_grad_(True)
+                try:
+                    out = getattr(ref, f'scatter_{name}')(ten, index[perm], src, include_self=inc)
+                    gt, gs = grad_wrt(out, (ten, src))
+                except RuntimeError as e:
+                    skipped.append(f'{case}/grad.scatter_{name}.{int(inc)}: {type(e).__name__}: {str(e)[:80]}')
+                    continue
+                put(case, f'scatter_{name}.{int(inc)}', out)
+                put(case, f'grad.scatter_{name}.{int(inc)}.source', gs)
+                put(case, f'grad.scatter_{name}.{int(inc)}.tensor', torch.zeros_like(ten) if gt is None else gt)
+
+
+def grad_seg_case(case, lens, H, seed):
+    """Gradients through X.seg(duration, fn) (tests/test_segment.py:92), w.r.t. the concatenated inputs."""
+    g = torch.Generator().manual_seed(seed)
+    lens = [int(x) for x in lens]
+    data = torch.randn((sum(lens), H), generator=g)
+    durations = [torch.unique(torch.randint(n, (n,), generator=g), return_counts=True)[1] for n in lens]
+    put(case, 'lens', np.asarray(lens, dtype=np.int64))
+    put(case, 'data', data)
+    put(case, 'dur.lens', np.asarray([d.numel() for d in durations], dtype=np.int64))
+    put(case, 'dur.data', torch.cat(durations))
+    for name in ('max', 'sum', 'mean', 'logsumexp', 'min', 'prod'):
+        fn = getattr(ref, f'segment_{name}')
+        for ks, kd in (('C', 'C'), ('L', 'L'), ('P', 'P'), ('R', 'R'), ('C', 'P'), ('P', 'L'), ('L', 'R'), ('R', 'C')):
+            x = data.clone().requires_grad_(True)
+            inputs = list(torch.split(x, lens))
+            out = KINDS[ks].new(inputs).seg(KINDS[kd].new(durations), fn)
+            put_seq(case, f'seg.{name}.{ks}.{kd}', out)
+            put(case, f'grad.seg.{name}.{ks}.{kd}', grad_wrt(out.data, x, token_mask(out))[0])
+
+
+def zkey_case(case, lens, H, dtype, seed):
+    """container[Z], tensor[Z], container[tensor] and their setitem twins (core/get.py:11-18,22-23,38-39,54-55,70-71;
+    core/set.py:10-18 ...): a key container of every kind, holding flat row numbers of the indexed storage."""
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.as_tensor(lens, dtype=torch.long)
+    N = int(lens.sum())
+    shape = (N,) if H == 0 else (N, H)
+    data = torch.randint(-1000, 1000, shape, generator=g) if dtype == torch.long else torch.randn(shape, generator=g).to(dtype)
+    fill = FILL if dtype != torch.long else -7
+    put(case, 'lens', lens)
+    put(case, 'data', data)
+    c = C(data, lens)
+    seqs = {k: as_kind(c, k, fill) for k in 'CLPR'}
+    put(case, 'sorted_indices', seqs['P'].sorted_indices)
+    klens = torch.randint(1, 5, (6,), generator=g)
+    K = int(klens.sum())
+    put(case, 'key.lens', klens)
+    for k, z in seqs.items():
+        rows = z.raw().size(0)
+        krows = torch.randint(0, rows, (K,), generator=g)                  # with repeats: a gather may name a row twice
+        uniq = torch.randperm(rows, generator=g)[:K]                       # setitem: every row named once
+        kshape = (K,) + tuple(data.shape[1:])
+        value = (torch.randn(kshape, generator=g).to(dtype) if dtype != torch.long
+                 else torch.randint(-50, 50, kshape, generator=g))
+        put(case, f'key.{k}.rows', krows)
+        put(case, f'key.{k}.uniq', uniq)
+        put(case, f'key.{k}.value', value)
+        for kz in 'CLPR':
+            key = as_kind(C(krows, klens), kz, 0)                          # padded keys: padding slots name row 0
+            put_seq(case, f'getitem_z.{k}.{kz}', z[key])
+            if k == 'C':
+                put_seq(case, f'tensor_getitem.{kz}', data[key])
+            ukey = as_kind(C(uniq, klens), kz, 0)
+            z2 = z._replace(data=z.data.clone())
+            if kz in 'CP':
+                vz = as_kind(C(value, klens), kz)                          # the value in the key's own order
+                z2[ukey] = vz.data
+            else:
+                z2[ukey] = 3                                               # padded key: its padding slots write too
+            put(case, f'setitem_z.{k}.{kz}', z2.data)
+            if k == 'C':
+                t2 = data.clone()
+                t2[ukey] = (as_kind(C(value, klens), kz).data if kz in 'CP' else 3)
+                put(case, f'tensor_setitem.{kz}', t2)
+        put(case, f'getitem_t.{k}.1d', z[krows])
+        put(case, f'getitem_t.{k}.2d', z[krows[:K // 2 * 2].view(2, -1)])
+        z3 = z._replace(data=z.data.clone())
+        z3[uniq] = value
+        put(case, f'setitem_t.{k}', z3.data)
+
+
+def split_case(case, lens, H, seed):
+    """X.split() / X.tolist() (detach.py:9-51; tests/test_detach.py:17-27) for the four layouts, and L / R whose storage
+    is wider than the longest sequence (T_phys > T_log), where the reference's own split raises."""
+    g = torch.Generator().manual_seed(seed)
+    lens = [int(x) for x in lens]
+    inputs = [torch.randn((n, H), generator=g) for n in lens]
+    put(case, 'lens', np.asarray(lens, dtype=np.int64))
+    put(case, 'data', torch.cat(inputs))
+    for k in 'CLPR':
+        z = KINDS[k].new(inputs)
+        parts = z.split()
+        put(case, f'split.{k}.sizes', np.asarray([p_.size(0) for p_ in parts], dtype=np.int64))
+        put(case, f'split.{k}.cat', torch.cat(list(parts)))
+        if k != 'P':                                       # P.tolist raises in the reference (no .detach on a PackedSequence)
+            flat = [v for seq in z.tolist() for row in seq for v in row]
+            put(case, f'tolist.{k}.flat', np.asarray(flat, dtype=np.float64))
+    T = max(lens)
+    for k in 'LR':
+        z = KINDS[k].new(inputs)
+        pad = torch.full((len(lens), 3, H), 9.0)
+        wide = z._replace(data=torch.cat([z.data, pad], dim=1))       # T_phys = T_log + 3
+        put(case, f'wide.{k}.data', wide.data)
+        try:
+            parts = wide.split()
+            put(case, f'wide.{k}.split.cat', torch.cat(list(parts)))
+        except RuntimeError as e:
+            skipped.append(f'{case}/wide.{k}.split: {type(e).__name__}: {str(e)[:90]}')
+        put_seq(case, f'wide.{k}.cat', wide.cat())                      # what the sequences are (core/cast.py:8-10)
+
+
+def compose_case(case, spec, H, seed, grads=True):
+    """compose(list of containers) -> ONE PackedSequence (compose.py:9-33; tests/test_compose.py:17-46).
+    spec: [(kind, lens), ...]."""
+    g = torch.Generator().manual_seed(seed)
+    put(case, 'n', np.asarray(len(spec), dtype=np.int64))
+    datas = []
+    for i, (k, lens) in enumerate(spec):
+        lens = [int(x) for x in lens]
+        d = torch.randn((sum(lens), H), generator=g)
+        datas.append(d)
+        put(case, f'in{i}.kind', np.frombuffer(k.encode(), dtype=np.uint8))
+        put(case, f'in{i}.lens', np.asarray(lens, dtype=np.int64))
+        put(case, f'in{i}.data', d)
+    xs = [d.clone().requires_grad_(True) for d in datas]
+    seqs = [KINDS[k].new(list(torch.split(x, [int(v) for v in lens]))) for (k, lens), x in zip(spec, xs)]
+    out = ref.compose(seqs)
+    put_seq(case, 'out', out)
+    if grads:
+        for i, gi in enumerate(grad_wrt(out.data, xs)):
+            put(case, f'grad.in{i}', gi)
+
+
+def reference_fold_error(case_from, store_from, keep_f64=True):
+    """how far the reference's OWN fp32 results are from an fp64 evaluation of the same inputs, for the
+    long-sequence reduce fixtures — the stored number behind the bound tests/test_gpu_golden.py uses there."""
+    z = np.load(os.path.join(OUT, store_from))
+    data = torch.from_numpy(z[f'{case_from}/data'])
+    lens = torch.from_numpy(z[f'{case_from}/lens'])
+    sabs = ref.segment_sum(data.double().abs(), lens)
+    case = f'referr.{case_from}'
+    if keep_f64:
+        put(case, 'sum_abs', sabs)
+    for name in ('sum', 'mean', 'prod', 'logsumexp'):
+        fn = getattr(ref, f'segment_{name}')
+        r32, r64 = fn(data, lens).double(), fn(data.double(), lens)
+        if keep_f64:
+            put(case, f'{name}.f64', r64)
+        err = (r32 - r64).abs()
+        put(case, f'{name}.max_rel', np.float64((err / r64.abs().clamp_min(1e-300)).max()))
+        put(case, f'{name}.max_over_sum_abs', np.float64((err / sabs.clamp_min(1e-300)).max()))
+
+
+def round3():
+    """tests/golden/r3.npz (the earlier files stay byte-for-byte): what VERDICT r2 found unpinned — compose, Z-keyed
+    and tensor-keyed indexing, split, and GRADIENTS of every op under one fixed cotangent."""
+    global store
+    store = {}
+    rng = np.random.RandomState(33)
+    grad_layout_case('grad.layout.a', rng.randint(1, 6, 9), 3, seed=500)
+    grad_layout_case('grad.layout.ties19', rng.randint(1, 4, 19), 2, seed=501)
+    grad_layout_case('grad.layout.long', rng.randint(2, 30, 18), 3, seed=502)
+    grad_reduce_case('grad.reduce.a', rng.randint(1, 7, 11), 4, seed=510)
+    grad_reduce_case('grad.reduce.ties', rng.randint(1, 6, 13), 3, seed=511, ties=True)
+    grad_reduce_case('grad.reduce.long', rng.randint(100, 300, 5), 2, seed=512)
+    zl = rng.randint(0, 4, 12)
+    zl[0] = 2
+    grad_reduce_case('grad.reduce.zero_len', zl, 3, seed=513)
+    grad_seg_case('grad.seg.a', rng.randint(1, 9, 7), 3, seed=520)
+    grad_seg_case('grad.seg.b', rng.randint(2, 20, 18), 2, seed=521)
+    zkey_case('zkey.f32', rng.randint(1, 6, 17), 3, torch.float32, seed=530)
+    zkey_case('zkey.vec', rng.randint(1, 9, 8), 0, torch.float32, seed=531)
+    zkey_case('zkey.bf16', rng.randint(1, 12, 14), 16, torch.bfloat16, seed=532)
+    zkey_case('zkey.i64', rng.randint(1, 5, 9), 2, torch.long, seed=533)
+    split_case('split.a', rng.randint(1, 9, 7), 3, seed=540)
+    split_case('split.b17', rng.randint(1, 4, 17), 1, seed=541)
+    compose_case('compose.two', [('C', [3, 1]), ('P', [2, 2, 4])], 3, seed=550)
+    compose_case('compose.mixed', [('L', rng.randint(1, 5, 4)), ('P', rng.randint(1, 5, 7)), ('C', rng.randint(1, 5, 4)),
+                                   ('R', rng.randint(1, 5, 7)), ('C', rng.randint(1, 5, 1))], 2, seed=551)
+    compose_case('compose.ties', [(k, rng.randint(1, 4, n)) for k, n in zip('CLPRCLPRCLPRCLPRCLPR', [3] * 20)], 1, seed=552)
+    compose_case('compose.one', [('R', rng.randint(1, 6, 19))], 4, seed=553)
+    reference_fold_error('reduce.long', 'extra.npz')
+    reference_fold_error('reduce.h512', 'extra.npz', keep_f64=False)
+    np.savez_compressed(os.path.join(OUT, 'r3.npz'), **store)
+    meta_path = os.path.join(OUT, 'META.json')
+    meta = json.load(open(meta_path))
+    meta['r3_n_arrays'] = len(store)
+    meta['r3_reference_raised'] = list(skipped)
+    with open(meta_path, 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print('wrote', len(store), 'round-3 arrays;', os.path.getsize(os.path.join(OUT, 'r3.npz')), 'bytes')
+    for line in skipped:
+        print('  reference raised:', line)
+
+
 if __name__ == '__main__':
-    if '--foreign' in sys.argv:
+    if '--round3' in sys.argv:
+        round3()
+    elif '--foreign' in sys.argv:
         foreign()
     elif '--extra' in sys.argv:
         extra()
@@ -381,3 +698,4 @@ if __name__ == '__main__':
         main()
         extra()
         foreign()
+        round3()

@@ -94,7 +94,7 @@ def _scatter(dst, idx, src):
     idx = _i64(idx)
     idx = np.where(idx < 0, idx + dst.shape[0], idx)
     assert idx.size == 0 or (idx.min() >= 0 and idx.max() < dst.shape[0]), 'index out of range'
-    src = np.ascontiguousarray(src, dtype=dst.dtype)
+    src = np.ascontiguousarray(np.broadcast_to(np.asarray(src, dtype=dst.dtype), idx.shape + dst.shape[1:]))   # index_put_ broadcasts the value
     rb = int(np.prod(dst.shape[1:], dtype=np.int64)) * dst.itemsize
     if idx.size and rb:
         lib().orc_scatter_rows(_p(dst), _p(idx), ctypes.c_int64(idx.size), ctypes.c_int64(rb), _p(src))
@@ -531,6 +531,41 @@ def new(kind: str, arrays, fill=0, sorted_indices=None) -> Seq:
     data = np.concatenate(arrays, axis=0)
     c = C(data, [a.shape[0] for a in arrays])
     return to_kind(c, kind, fill, sorted_indices)
+
+
+# --------------------------------------------------------------------------- compose.py, detach.py
+def compose(seqs, sort_desc) -> Seq:
+    """compose.py:9-33, step by step.  `sort_desc(lens)` = the reference's host call
+    torch.sort(lens, descending=True)[1] (core/view.py:48), which both of compose's pack() calls make."""
+    offset, data, indices, token_sizes = 0, [], [], []
+    for s in seqs:                                             # compose.py:12-19
+        data.append(raw(s))
+        flat = to_cat(idx(s))                                  # sequence.idx().cat()
+        indices.append(flat.data + offset)
+        token_sizes.append(flat.token_sizes)
+        offset += data[-1].shape[0]
+    ts = new('C', token_sizes)                                 # compose.py:21  C.new(token_sizes)
+    order = to_pack(idx(ts), sort_desc(ts.token_sizes)).data   # compose.py:22  unsorted_indices, _, _, _ = ....idx().pack()
+    ind = to_pack(C(np.concatenate(indices), ts.data), sort_desc(ts.data))          # compose.py:24
+    unsorted = ind.unsorted_indices[order]                     # compose.py:25
+    ind = replace(ind, sorted_indices=invert_permutation(unsorted), unsorted_indices=unsorted)   # compose.py:26-31
+    return ind.with_data(_gather(np.concatenate(data, axis=0), ind.data))           # compose.py:33  tensor[Z], get.py:11-13
+
+
+def split(s: Seq):
+    """detach.py: C/P 9-17 (split of the cat form), L 22-28, R 33-40 (split of the flattened padded storage into
+    (tokens, padding) pairs; raises, like torch.split, when the storage is wider than the longest sequence)."""
+    if s.kind in 'CP':
+        c = to_cat(s)
+        return np.split(c.data, np.cumsum(c.token_sizes)[:-1])
+    t = size(s)[1]
+    pair = [s.token_sizes, t - s.token_sizes] if s.kind == 'L' else [t - s.token_sizes, s.token_sizes]
+    sizes = np.stack(pair, axis=-1).reshape(-1)
+    flat = raw(s)
+    if int(sizes.sum()) != flat.shape[0]:
+        raise RuntimeError(f'split_with_sizes expects split_sizes to sum exactly to {flat.shape[0]}')
+    parts = np.split(flat, np.cumsum(sizes)[:-1])
+    return parts[0::2] if s.kind == 'L' else parts[1::2]
 
 
 def stable_descending_order(lens):

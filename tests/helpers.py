@@ -22,13 +22,20 @@ def golden():
     global _small
     if _small is None:
         out = {}
-        for fname in ('small.npz', 'extra.npz', 'foreign.npz'):   # oracle/gen_golden.py: main / extra / foreign
+        for fname in ('small.npz', 'extra.npz', 'foreign.npz', 'r3.npz'):   # oracle/gen_golden.py: main / extra / foreign / round3
             z = np.load(os.path.join(GOLDEN, fname))
             for key in z.files:
                 case, name = key.split('/', 1)
                 out.setdefault(case, {})[name] = z[key]
         _small = out
     return _small
+
+
+def cotangent(shape, salt=0) -> np.ndarray:
+    """The fixed cotangent of the gradient fixtures (oracle/gen_golden.py: cot_like), rebuilt from the shape."""
+    n = int(np.prod(shape, dtype=np.int64))
+    a = ((np.arange(n, dtype=np.float64) + 1.0 + salt) * 0.6180339887498949) % 1.0 - 0.5
+    return a.astype(np.float32).reshape(shape)
 
 
 def golden_sha():

@@ -1,0 +1,87 @@
+"""Pins the oracle's restatements of compose, split and Z- / tensor-keyed indexing against the reference's own outputs
+(tests/golden/r3.npz, oracle/gen_golden.py --round3).  CPU only.  (The gradient fixtures of r3.npz have no oracle
+counterpart: the GPU tests compare the kernels' backward with them directly.)"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_seq_equal, cases, golden, orc
+
+KINDS = 'CLPR'
+
+
+def _sort_desc(lens):
+    """The reference's host call (core/view.py:48)."""
+    return torch.sort(torch.from_numpy(np.ascontiguousarray(lens)), descending=True)[1].numpy()
+
+
+def _fill_for(f):
+    if f['data'].dtype == np.uint16:
+        return np.array([0xBFC0], dtype=np.uint16)        # bf16 bits of -1.5
+    return -7 if f['data'].dtype.kind == 'i' else -1.5
+
+
+def _as_kind(c, k, fill, srt):
+    return orc.to_kind(c, k, fill, srt)
+
+
+@pytest.mark.parametrize('case', cases('zkey.'))
+def test_z_and_tensor_keys(case):
+    f = golden()[case]
+    fill = _fill_for(f)
+    c = orc.C(f['data'], f['lens'])
+    seqs = {k: _as_kind(c, k, fill, f['sorted_indices']) for k in KINDS}
+    klens = f['key.lens']
+    ksrt = _sort_desc(klens)
+    for k, z in seqs.items():
+        krows, uniq, value = f[f'key.{k}.rows'], f[f'key.{k}.uniq'], f[f'key.{k}.value']
+        for kz in KINDS:
+            key = _as_kind(orc.C(krows, klens), kz, 0, ksrt)
+            assert_seq_equal(orc.getitem(z, key), f, f'getitem_z.{k}.{kz}', kz)
+            ukey = _as_kind(orc.C(uniq, klens), kz, 0, ksrt)
+            z2 = z.with_data(z.data.copy())
+            if kz in 'CP':
+                orc.setitem(z2, ukey, _as_kind(orc.C(value, klens), kz, 0, ksrt).data)
+            else:
+                orc.setitem(z2, ukey, np.asarray(3).astype(z.data.dtype) if z.data.dtype != np.uint16
+                            else np.array(0x4040, dtype=np.uint16))          # bf16 bits of 3.0
+            np.testing.assert_array_equal(z2.data, f[f'setitem_z.{k}.{kz}'], err_msg=f'setitem_z.{k}.{kz}')
+            if k == 'C':
+                assert_seq_equal(orc.getitem(orc.C(f['data'], f['lens']), key), f, f'tensor_getitem.{kz}', kz)
+                np.testing.assert_array_equal(z2.data, f[f'tensor_setitem.{kz}'])
+        np.testing.assert_array_equal(orc.getitem(z, krows), f[f'getitem_t.{k}.1d'])
+        two = krows[:krows.size // 2 * 2].reshape(2, -1)
+        np.testing.assert_array_equal(orc.getitem(z, two), f[f'getitem_t.{k}.2d'])
+        z3 = z.with_data(z.data.copy())
+        orc.setitem(z3, uniq, value)
+        np.testing.assert_array_equal(z3.data, f[f'setitem_t.{k}'])
+
+
+@pytest.mark.parametrize('case', cases('split.'))
+def test_split(case):
+    f = golden()[case]
+    lens = f['lens']
+    arrays = np.split(f['data'], np.cumsum(lens)[:-1])
+    srt = _sort_desc(lens)
+    for k in KINDS:
+        z = orc.new(k, arrays, 0, srt)
+        parts = orc.split(z)
+        np.testing.assert_array_equal(np.asarray([p.shape[0] for p in parts]), f[f'split.{k}.sizes'])
+        np.testing.assert_array_equal(np.concatenate(parts), f[f'split.{k}.cat'])
+    for k in 'LR':                       # storage wider than the longest sequence: the reference's split raises
+        wide = orc.Seq(k, f[f'wide.{k}.data'], token_sizes=lens)
+        with pytest.raises(RuntimeError):
+            orc.split(wide)
+        assert_seq_equal(orc.to_cat(wide), f, f'wide.{k}.cat', 'C')
+
+
+@pytest.mark.parametrize('case', cases('compose.'))
+def test_compose(case):
+    f = golden()[case]
+    seqs = []
+    for i in range(int(f['n'])):
+        kind = bytes(f[f'in{i}.kind']).decode()
+        lens = f[f'in{i}.lens']
+        arrays = np.split(f[f'in{i}.data'], np.cumsum(lens)[:-1])
+        seqs.append(orc.new(kind, arrays, 0, _sort_desc(lens)))
+    assert_seq_equal(orc.compose(seqs, _sort_desc), f, 'out', 'P')
