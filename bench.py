@@ -179,9 +179,13 @@ def self_launch(args):
         sock.bind(('127.0.0.1', 0))
         port = sock.getsockname()[1]
     procs = []
+    # the host-sort thread count is decided ONCE, here, for all ranks (each would otherwise time 1/2/4/8 threads while
+    # its seven neighbours do the same): a rank's share of the cores, at most 4 (the sort stops scaling there)
+    cpus = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    sort_threads = os.environ.get('RUA_HOST_SORT', str(max(1, min(4, cpus // (2 * n)))))
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RUA_HOST_SORT=sort_threads)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     pending = dict(enumerate(procs))
@@ -240,6 +244,11 @@ def main():
     # rehearsal knobs (1-GPU box): RUA_BENCH_DEVICE pins every rank to one card, RUA_BENCH_BACKEND=gloo replaces RCCL
     dev = torch.device('cuda', int(os.environ.get('RUA_BENCH_DEVICE', local_rank)))
     torch.cuda.set_device(dev)
+    # one rank per GPU on one host: every rank keeps to its share of the cores (those next to its card) and caps torch's
+    # intra-op pool to it — eight unpinned ranks otherwise run eight host sorts and eight 128-thread pools on every core
+    from torchrua_amd.parallel import bind_rank_to_cpus
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+    my_cpus = bind_rank_to_cpus(local_rank, local_world, dev.index)
     import torch.distributed as dist
     use_dist = world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ)   # under torchrun
     if use_dist:
@@ -401,6 +410,8 @@ def main():
                        'sharding': f'{world} x contiguous batch shards ({B * world} sequences in all), one all-gather of [B,H]' if world > 1 else 'none',
                        'lens_source': 'host (C.new-style hand-over)',
                        'ranks_reported_by_process_group': ranks_reported,
+                       'cpus_of_rank0': len(my_cpus), 'torch_threads_rank0': torch.get_num_threads(),
+                       'host_sort': os.environ.get('RUA_HOST_SORT', 'self-tuned'),
                        'backend': (os.environ.get('RUA_BENCH_BACKEND', 'nccl') + (' (RCCL)' if os.environ.get('RUA_BENCH_BACKEND', 'nccl') == 'nccl' else '')) if use_dist else None},
             'per_rank': [{'rank': r, 'rows': int(row[0]), 'ms_per_step': round(row[1] / args.steps * 1e3, 4),
                           'pack_kernel_GBps': round((2.0 * row[0] * H * e + 8.0 * (3 * B + T)) / (row[2] * 1e-3) / 1e9, 1) if row[2] else None,

@@ -8,7 +8,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from helpers import orc
-from torchrua_amd.parallel import all_gather_rows, shard_bounds, sharded_reduce
+from torchrua_amd.parallel import all_gather_rows, plan_rank_cpus, shard_bounds, sharded_reduce
 
 
 def test_shard_bounds_cover_and_order():
@@ -19,6 +19,22 @@ def test_shard_bounds_cover_and_order():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_rank_cpu_plan():
+    """Every rank of a node gets its own cores, next to its card, whole cores first; no topology -> an even split."""
+    nodes = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}
+    gpus = [0, 0, 0, 0, 1, 1, 1, 1]
+    plans = [plan_rank_cpus(r, 8, list(range(256)), gpus, nodes) for r in range(8)]
+    assert all(len(p) == 32 for p in plans) and len({c for p in plans for c in p}) == 256
+    assert plans[0][:16] == list(range(16)) and plans[0][16:] == list(range(128, 144))     # cores + their siblings
+    assert all(c in nodes[1] for c in plans[5])
+    # a cgroup that allows only 16 CPUs, no topology: contiguous quarters
+    assert [plan_rank_cpus(r, 4, list(range(16))) for r in range(4)] == [list(range(4 * r, 4 * r + 4)) for r in range(4)]
+    assert plan_rank_cpus(0, 1, [3, 4]) == [3, 4]
+    assert plan_rank_cpus(2, 4, [7]) == [7]                 # fewer CPUs than ranks: never an empty set
+    # GPUs 0-1 of a two-rank job on one node of a larger machine
+    assert plan_rank_cpus(1, 2, list(range(256)), gpus, nodes) == list(range(32, 64)) + list(range(160, 192))
 
 
 def _free_port():

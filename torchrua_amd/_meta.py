@@ -302,6 +302,10 @@ def _host_sort_decide() -> int:
         if env.isdigit() and int(env) >= 1:
             return min(int(env), 64)
         cpus = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        # several ranks on one host (torch.distributed.run sets LOCAL_WORLD_SIZE) each run this test and then their
+        # own sorts at the same time: a rank counts only its share of the cores (parallel.bind_rank_to_cpus makes that
+        # literal), so that eight ranks do not each conclude that eight threads are free
+        cpus = max(1, cpus // max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1)))
         sample = torch.randint(8, 513, (65536,), generator=torch.Generator().manual_seed(1))
         best, best_t = 1, None
         for threads in (1, 2, 4, 8):
@@ -504,23 +508,25 @@ class _StagingRing:
             self.bufs[i] = buf
         return i, buf[:nbytes].view(dtype).view(shape)
 
-    def commit(self, i: int, staged: Tensor, dev: torch.device) -> Tensor:
+    def commit(self, i: int, staged: Tensor, dev: torch.device, stream_idle: bool = False) -> Tensor:
         """Enqueue the H2D of a slot filled through reserve()."""
         try:
-            return self._commit(i, staged, dev)
+            return self._commit(i, staged, dev, stream_idle)
         finally:
             self.busy[i] = False
 
-    def _commit(self, i: int, staged: Tensor, dev: torch.device) -> Tensor:
-        out, ev = self.h2d(staged, dev)
+    def _commit(self, i: int, staged: Tensor, dev: torch.device, stream_idle: bool = False) -> Tensor:
+        out, ev = self.h2d(staged, dev, stream_idle)
         self.events[i] = ev
         return out
 
-    def h2d(self, staged: Tensor, dev: torch.device):
-        """Enqueue the H2D of a PINNED host tensor; returns (device tensor, event that follows the copy)."""
+    def h2d(self, staged: Tensor, dev: torch.device, stream_idle: bool = False):
+        """Enqueue the H2D of a PINNED host tensor; returns (device tensor, event that follows the copy).
+        stream_idle: the caller has just synchronised the compute stream (a read-back of device-only lengths): there is
+        nothing to overlap with, and the side-stream hand-off would only add host work to the time the GPU idles."""
         cur = torch.cuda.current_stream(dev)
         ev = torch.cuda.Event()
-        if staged.numel() < self.SIDE_MIN_ELEMS or torch.cuda.is_current_stream_capturing():
+        if stream_idle or staged.numel() < self.SIDE_MIN_ELEMS or torch.cuda.is_current_stream_capturing():
             out = torch.empty(staged.shape, dtype=staged.dtype, device=dev)
             out.copy_(staged, non_blocking=True)
             ev.record(cur)
@@ -588,7 +594,7 @@ def pinned_to_device_async(pinned: Tensor, dev: torch.device) -> Tensor:
     return _ring(dev).h2d(pinned, dev)[0]
 
 
-def sorted_indices_to_device(host_lens_: Tensor, dev: torch.device) -> Tensor:
+def sorted_indices_to_device(host_lens_: Tensor, dev: torch.device, stream_idle: bool = False) -> Tensor:
     """The reference's host sort (core/view.py:48), written straight into a pinned staging slot and uploaded."""
     n = host_lens_.numel()
     if dev.type != 'cuda' or n == 0:
@@ -600,7 +606,7 @@ def sorted_indices_to_device(host_lens_: Tensor, dev: torch.device) -> Tensor:
     except BaseException:
         ring.busy[i] = False
         raise
-    return ring.commit(i, staged, dev)
+    return ring.commit(i, staged, dev, stream_idle)
 
 
 def lay_list(bptr: Optional[Tensor], tptr: Tensor) -> Lay:

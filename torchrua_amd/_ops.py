@@ -134,6 +134,7 @@ class _ListGather(torch.autograd.Function):
         n_rows = 1
         for d in ctx.src_shape[:ctx.lead]:
             n_rows *= d
+        flat = torch.where(flat < 0, flat + n_rows, flat)          # negative rows wrapped in the forward (like torch)
         g = scatter_sum_rows(grad.reshape((flat.numel(),) + hidden), flat, n_rows)
         return g.reshape(ctx.src_shape), None, None, None
 

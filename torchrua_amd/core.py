@@ -75,9 +75,10 @@ def _pack_meta(token_sizes: Tensor, dev: torch.device):
     # implementation-defined, so bit-exact parity means reproducing that very call (SURVEY.md §8a note;
     # _meta.host_sort_desc).  With device-only lengths the GPU idles from the read-back until the mover below is
     # launched, so nothing else sits between the two.
+    read_back = token_sizes.is_cuda and M._memo_get(token_sizes, 'host') is None      # device-only lengths: a sync now
     host = M.host_lens(token_sizes)
     B = lens.numel()
-    sorted_indices = M.sorted_indices_to_device(host, dev)
+    sorted_indices = M.sorted_indices_to_device(host, dev, stream_idle=read_back)
     T = M.max_len(token_sizes)
     batch_sizes = M.batch_sizes_from_host_lens(host, T)
     # one call for everything derived on the device; the internal vectors share one allocation:

@@ -5,12 +5,13 @@ Every op on the hot path is per-sequence, so rank r simply owns the contiguous s
 [r*B/R, (r+1)*B/R) and runs the single-GPU path on it: no payload ever crosses the fabric.  The only
 exchange is ONE all-gather of the reduced [B/R, H] outputs; contiguous shards make the gathered
 buffer come out in global batch order.  The reference has no distributed code."""
-from typing import Callable, Optional, Tuple
+import os
+from typing import Callable, List, Optional, Tuple
 
 import torch.distributed as dist
 from torch import Tensor
 
-__all__ = ['shard_bounds', 'all_gather_rows', 'sharded_reduce']
+__all__ = ['shard_bounds', 'all_gather_rows', 'sharded_reduce', 'bind_rank_to_cpus']
 
 
 def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -55,3 +56,86 @@ def all_gather_rows(local: Tensor, n_total: Optional[int] = None, group=None, as
 def sharded_reduce(local_fn: Callable[[], Tensor], n_total: Optional[int] = None, group=None) -> Tensor:
     """Run `local_fn` (this rank's pack -> reduce over its own sequences -> [B/R, H]) and all-gather."""
     return all_gather_rows(local_fn(), n_total=n_total, group=group)
+
+
+# ------------------------------------------------------------------ host side of a multi-rank node
+def _parse_cpulist(text: str) -> List[int]:
+    cpus: List[int] = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def _numa_node_of_gpu(pci_bus_id: str) -> int:
+    """NUMA node of a GPU from sysfs (-1 when the platform does not say)."""
+    for name in (pci_bus_id.lower(), pci_bus_id.lower().replace('0000:', '', 1)):
+        path = f'/sys/bus/pci/devices/{name}/numa_node'
+        if os.path.exists(path):
+            with open(path) as f:
+                return int(f.read().strip())
+    return -1
+
+
+def plan_rank_cpus(local_rank: int, local_world: int, allowed: List[int], gpu_nodes: Optional[List[int]] = None,
+                   node_cpus: Optional[dict] = None) -> List[int]:
+    """The CPUs rank `local_rank` of `local_world` ranks on this host should run on: a share of the CPUs of ITS
+    GPU's NUMA node (the pinned staging buffers, the host sort's scratch and the upload all live next to the card),
+    split evenly among the ranks whose GPUs sit on that node; without topology information a contiguous 1/world slice
+    of the allowed CPUs.  Pure function of its arguments (tests/test_parallel_gloo.py drives it with made-up
+    topologies); never returns an empty list."""
+    allowed = sorted(allowed)
+    if local_world <= 1 or not allowed:
+        return allowed
+    if gpu_nodes and node_cpus and len(gpu_nodes) >= local_world and gpu_nodes[local_rank] in node_cpus:
+        node = gpu_nodes[local_rank]
+        mine = [c for c in node_cpus[node] if c in set(allowed)]
+        peers = [r for r in range(local_world) if gpu_nodes[r] == node]
+        if mine and len(mine) >= len(peers):
+            k = peers.index(local_rank)
+            share = len(mine) // len(peers)
+            # SMT siblings are usually listed in the second half of a node's cpulist: deal the first half (one thread
+            # per core) out first, then the siblings, so that every rank gets whole cores
+            half = len(mine) // 2
+            if half >= len(peers) and half % len(peers) == 0:
+                per = half // len(peers)
+                return sorted(mine[k * per:(k + 1) * per] + mine[half + k * per:half + (k + 1) * per])
+            return mine[k * share:(k + 1) * share]
+    share = max(1, len(allowed) // local_world)
+    return allowed[local_rank * share:(local_rank + 1) * share] or allowed
+
+
+def bind_rank_to_cpus(local_rank: int, local_world: int, device_index: Optional[int] = None) -> List[int]:
+    """Pin this process (one rank of a multi-GPU job) to its share of the host's CPUs and cap torch's intra-op
+    thread pool to it; returns the CPU list (unchanged affinity when there is one rank, when RUA_NO_AFFINITY is set, or
+    when the platform offers no sched_setaffinity).  Eight ranks on one host otherwise share every core: eight host
+    sorts, eight 128-thread torch pools."""
+    import torch
+    if local_world <= 1 or os.environ.get('RUA_NO_AFFINITY') or not hasattr(os, 'sched_setaffinity'):
+        return sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else []
+    allowed = sorted(os.sched_getaffinity(0))
+    gpu_nodes, node_cpus = None, None
+    try:
+        gpu_nodes = [_numa_node_of_gpu(torch.cuda.get_device_properties(i).pci_bus_id)
+                     for i in range(torch.cuda.device_count())]
+        if device_index is not None and local_rank < len(gpu_nodes):
+            gpu_nodes[local_rank] = gpu_nodes[device_index]
+        node_cpus = {}
+        base = '/sys/devices/system/node'
+        for name in os.listdir(base):
+            if name.startswith('node') and name[4:].isdigit():
+                with open(os.path.join(base, name, 'cpulist')) as f:
+                    node_cpus[int(name[4:])] = _parse_cpulist(f.read())
+        if any(n < 0 for n in gpu_nodes[:local_world]):
+            gpu_nodes = None
+    except Exception:          # no sysfs, no pci_bus_id on this build: fall back to the contiguous split
+        gpu_nodes, node_cpus = None, None
+    cpus = plan_rank_cpus(local_rank, local_world, allowed, gpu_nodes, node_cpus)
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        return allowed
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), len(cpus))))
+    return cpus

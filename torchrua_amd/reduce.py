@@ -254,6 +254,9 @@ def scatter_logsumexp(tensor: T, index: T, source: T, include_self: bool = False
 _OPS = {'sum': K.SUM, 'mean': K.MEAN, 'max': K.MAX, 'min': K.MIN, 'prod': K.PROD, 'logsumexp': K.LOGSUMEXP}
 
 
+FUSED_MIN_UNITS = 16384      # below this many (sequence, column chunk) units pack_reduce takes the two-kernel form
+
+
 def pack_reduce(sequence: Z, op: str = 'sum', fused: bool = None):
     """(sequence.pack(), reduce_<op>(that PackedSequence)) in ONE pass over the payload.
 
@@ -280,7 +283,7 @@ def pack_reduce(sequence: Z, op: str = 'sum', fused: bool = None):
     n_seq = int(sequence.token_sizes.numel()) if not isinstance(sequence, P) else 0
     row_bytes = H * data.element_size()
     n_chunks = 1 if row_bytes <= 1024 else -(-row_bytes // 4096)
-    if fused is False or (fused is None and n_seq * n_chunks < M.TEAM_MAX_UNITS):     # fused=True: whenever it can
+    if fused is False or (fused is None and n_seq * n_chunks < FUSED_MIN_UNITS):     # fused=True: whenever it can
         fusable = False
     if not fusable:
         p = sequence.pack()
