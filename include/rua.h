@@ -93,6 +93,7 @@ enum rua_tmap {
 #define RUA_MOVE_TILE_LOG2(k) (((k) & 0xf) << 4)
 #define RUA_MOVE_XCD_SPAN_ON  256  /* every XCD takes ONE contiguous span of tiles (blockIdx % 8 picks the span) */
 #define RUA_MOVE_XCD_SPAN_OFF 512  /* tiles in plain blockIdx order                                             */
+#define RUA_MOVE_NO_TAIL8 1024     /* rows of 8 (mod 16) bytes: keep 8-byte lanes instead of 16-byte lanes + an 8-byte tail */
 
 /* K1. Exclusive prefix sum of n int64 (wavefront scan).  out[i] = sum(in[0..i)).
  * `ws` must hold rua_scan_ws_elems(n) int64.  If total != NULL, *total (device) = sum(in).
@@ -110,7 +111,7 @@ int rua_pack_meta(const int64_t* lens, const int64_t* sorted, int64_t B, int64_t
 
 /* K3 + K1 in one call — everything pack() derives on the device: rua_pack_meta's outputs plus
  *   boff[t] = sum(bsz[0..t))  (T entries)   and, if off != NULL,   off[b] = sum(lens[0..b))  (B entries).
- * Moderate sizes (T <= 2 048, B <= 32 768) take ONE launch instead of five; larger ones run the three steps back to
+ * Moderate sizes (T <= 2 048, B <= 131 072) take ONE launch instead of five; larger ones run the three steps back to
  * back.  `ws`: rua_scan_ws_elems(max(B, T)) int64 (only touched on the large path).  core/view.py:47-58 + utils.py:16-19. */
 int rua_pack_prepare(const int64_t* lens, const int64_t* sorted, int64_t B, int64_t T, int64_t* unsorted,
                      int64_t* bsz, int64_t* boff, int64_t* off, int64_t* ws, void* stream);

@@ -122,17 +122,19 @@ __global__ __launch_bounds__(RUA_BLOCK) void pack_meta_kernel(const int64_t* __r
 
 // Everything pack() needs in ONE launch when T and B are moderate (mid-size batches spend as long in the launch
 // gaps of five tiny kernels as in their payload): block 0 computes batch_sizes AND their exclusive offsets (T <=
-// one scan tile), block 1 the exclusive offsets of the lengths (a looping single-block scan, B <= 16 tiles),
-// the other blocks invert the permutation.
+// one scan tile); blocks 1 .. nt scan one tile of the lengths each — a block first adds up everything IN FRONT of
+// its tile by itself (B <= 64 tiles: at most 129 024 coalesced int64 from L2 per block, all blocks at once; a
+// single looping block would walk the 32 tiles of the north-star batch one after the other, and the three-pass scan
+// is three more launches); the other blocks invert the permutation.
 constexpr int64_t PREP_T_MAX = SCAN_TILE;
-constexpr int64_t PREP_B_MAX = 16 * SCAN_TILE;
+constexpr int64_t PREP_B_MAX = 64 * SCAN_TILE;
 
 __global__ __launch_bounds__(RUA_BLOCK) void pack_prepare_kernel(const int64_t* __restrict__ lens,
                                                                  const int64_t* __restrict__ sorted, int64_t B,
                                                                  int64_t T, int64_t* __restrict__ unsorted,
                                                                  int64_t* __restrict__ bsz,
                                                                  int64_t* __restrict__ boff,
-                                                                 int64_t* __restrict__ off) {
+                                                                 int64_t* __restrict__ off, int64_t n_off_tiles) {
   if (blockIdx.x == 0) {
     // batch_sizes: lens[sorted[r]] is non-increasing in r, bsz[t] = #{r : lens[sorted[r]] > t}.  A lane takes the
     // time steps tid, tid + 256, ... and runs their searches in LOCKSTEP (fixed trip count, SCAN_ITEMS independent
@@ -173,26 +175,31 @@ __global__ __launch_bounds__(RUA_BLOCK) void pack_prepare_kernel(const int64_t* 
       if (base + k < T) boff[base + k] = run;
       run += v[k];
     }
-  } else if (blockIdx.x == 1) {
+  } else if ((int64_t)blockIdx.x <= n_off_tiles) {
     if (!off) return;
-    int64_t carry = 0;
-    for (int64_t tile = 0; tile < B; tile += SCAN_TILE) {      // block-uniform loop
-      const int64_t base = tile + (int64_t)threadIdx.x * SCAN_ITEMS;
-      int64_t v[SCAN_ITEMS];
-      int64_t s = 0;
+    const int64_t tile = ((int64_t)blockIdx.x - 1) * SCAN_TILE;
+    // everything in front of this tile, added up by the whole block (8 independent loads in flight per thread)
+    int64_t pre = 0;
+    for (int64_t i0 = 0; i0 < tile; i0 += (int64_t)RUA_BLOCK * SCAN_ITEMS) {
 #pragma unroll
-      for (int k = 0; k < SCAN_ITEMS; ++k) { v[k] = (base + k < B) ? lens[base + k] : 0; s += v[k]; }
-      int64_t tot;
-      int64_t run = carry + block_exclusive_scan(s, &tot);
+      for (int k = 0; k < SCAN_ITEMS; ++k) pre += lens[i0 + (int64_t)k * RUA_BLOCK + threadIdx.x];   // (tile is a multiple of 2 048)
+    }
+    int64_t carry;
+    (void)block_exclusive_scan(pre, &carry);
+    const int64_t base = tile + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int64_t v[SCAN_ITEMS];
+    int64_t s = 0;
 #pragma unroll
-      for (int k = 0; k < SCAN_ITEMS; ++k) {
-        if (base + k < B) off[base + k] = run;
-        run += v[k];
-      }
-      carry += tot;
+    for (int k = 0; k < SCAN_ITEMS; ++k) { v[k] = (base + k < B) ? lens[base + k] : 0; s += v[k]; }
+    int64_t tot;
+    int64_t run = carry + block_exclusive_scan(s, &tot);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+      if (base + k < B) off[base + k] = run;
+      run += v[k];
     }
   } else {
-    const int64_t i = (int64_t)(blockIdx.x - 2) * RUA_BLOCK + threadIdx.x;
+    const int64_t i = ((int64_t)blockIdx.x - 1 - n_off_tiles) * RUA_BLOCK + threadIdx.x;
     if (i < B) {
       const int64_t b = sorted[i];
       if (b >= 0 && b < B) unsorted[b] = i;
@@ -356,8 +363,9 @@ int rua_pack_prepare(const int64_t* lens, const int64_t* sorted, int64_t B, int6
   if (!lens || !sorted || !unsorted || (T > 0 && (!bsz || !boff))) return RUA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (T <= PREP_T_MAX && B <= PREP_B_MAX) {
-    hipLaunchKernelGGL(pack_prepare_kernel, dim3(2 + grid_for(B)), dim3(RUA_BLOCK), 0, s, lens, sorted, B, T, unsorted,
-                       bsz, boff, off);
+    const int64_t nt = (B + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(pack_prepare_kernel, dim3((unsigned)(1 + nt + grid_for(B))), dim3(RUA_BLOCK), 0, s, lens, sorted, B,
+                       T, unsorted, bsz, boff, off, nt);
     return (int)hipGetLastError();
   }
   int r = rua_pack_meta(lens, sorted, B, T, unsorted, bsz, stream);

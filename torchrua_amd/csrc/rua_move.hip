@@ -31,6 +31,7 @@ constexpr int64_t MOVE_SPAN_MIN_TILES = 2048;       // launches at least this la
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x4 u32x4_a8 __attribute__((aligned(8)));     // a 16-byte piece that only sits on an 8-byte boundary
 
 template <int VEC> struct vec_of;
 template <> struct vec_of<16> { using type = u32x4; };
@@ -59,6 +60,19 @@ template <typename V, bool NT> __device__ __forceinline__ void st_row(char* p, V
   else *reinterpret_cast<V*>(p) = v;
 }
 
+// Rows that are a multiple of 8 but not of 16 bytes (H = 500 in bf16: 1 000-byte rows): every other row starts on an
+// 8-byte boundary only.  With 8-byte lanes such a row is two wave instructions of 512 and 488 bytes (measured 4.2 TB/s
+// where 1 024-byte rows move at 6.1); gfx950 takes a dwordx4 at any dword-aligned address, so the row goes as 62
+// sixteen-byte lanes and one 8-byte lane instead — ONE wave instruction again (TAIL8).
+template <bool NT> __device__ __forceinline__ u32x4 ld_row_a8(const char* p) {
+  if (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4_a8*>(p));
+  return *reinterpret_cast<const u32x4_a8*>(p);
+}
+template <bool NT> __device__ __forceinline__ void st_row_a8(char* p, u32x4 v) {
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4_a8*>(p));
+  else *reinterpret_cast<u32x4_a8*>(p) = v;
+}
+
 // lpr      : lanes (VEC-byte columns) per row = ceil(row_bytes / VEC)
 // lp_log2  : log2 of lanes a wave gives one row per instruction (<= 6); rows narrower than
 //            1 KiB share a wave instruction (64 >> lp_log2 rows at a time)
@@ -69,7 +83,9 @@ template <typename V, bool NT> __device__ __forceinline__ void st_row(char* p, V
 //            chip sweep the destination almost sequentially (see tile_of below and DESIGN.md §4).
 // tiles_per_xcd > 0: workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8); give every XCD ONE contiguous
 //            span of tiles_per_xcd tiles instead of every eighth tile.
-template <int VEC, bool SCATTER, bool NT, int RPT = 1, int TROWS = MOVE_TILE, int BLOCK = MOVE_BLOCK, int UNR = UNROLL>
+// TAIL8    : VEC == 16, rows end in an 8-byte piece and start on 8-byte boundaries (see above)
+template <int VEC, bool SCATTER, bool NT, int RPT = 1, int TROWS = MOVE_TILE, int BLOCK = MOVE_BLOCK, int UNR = UNROLL,
+          bool TAIL8 = false>
 __global__ __launch_bounds__(BLOCK) void move_rows_kernel(rua_layout D, rua_layout S, int32_t tmap,
                                                               int64_t targ, char* __restrict__ dst,
                                                               const char* __restrict__ src, int64_t row_bytes,
@@ -148,25 +164,54 @@ __global__ __launch_bounds__(BLOCK) void move_rows_kernel(rua_layout D, rua_layo
       if (D.kind == RUA_PACK && D.T > 0 && D.boff) {
         int64_t bt;
         const bool ok = coop_resolve([&](int64_t k) { return D.boff[k]; }, D.T, tile0 + w0, nw, lane1, t, bt);
-        if (mine && ok) {
-          resolved = true;
-          const int64_t r = j - bt;
-          if (same_pack) {
-            // roll / rev inside ONE PackedSequence: the rank r of a row is its own source rank, and its length is
-            // #{t : bsz[t] > r} — a search in the (L1-resident) batch_sizes instead of two random gathers per row
-            int64_t lo = 0, hi = D.T;
-            while (lo < hi) {
-              const int64_t mid = (lo + hi) >> 1;
-              if (D.bsz[mid] > r) lo = mid + 1; else hi = mid;
+        if (same_pack) {
+          // roll / rev inside ONE PackedSequence: the rank r of a row is its own source rank, and its length is
+          // #{t : bsz[t] > r} — read off batch_sizes instead of two random gathers per row.  The wave looks its rows'
+          // lengths up TOGETHER (a 10-step binary search per row was the longest dependent chain of the tile: cfg4's
+          // P.roll, 2-KiB rows): -bsz is non-decreasing, len = 1 + the largest k with -bsz[k] <= -(r + 1); the rows
+          // of a wave are neighbouring ranks, whose lengths sit within one 64-entry window of the smallest of them.
+          constexpr int64_t BIG = 0x7fffffffffffffffLL;
+          const bool have = mine && ok && j - bt >= 0 && j - bt < D.bsz[0];
+          const int64_t r = have ? j - bt : 0;
+          const int64_t x = have ? -(r + 1) : BIG;
+          int64_t base = x;
+#pragma unroll
+          for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {
+            const int64_t o = __shfl_xor(base, d, RUA_WAVE);
+            base = o < base ? o : base;
+          }
+          int64_t wlo = 0, W = BIG, k = 0, fk = 0;
+          bool hit = false;
+          if (base != BIG) {                                          // wave-uniform
+            coop_window([&](int64_t q) { return -D.bsz[q]; }, D.T, base, lane1, wlo, W);
+            hit = coop_lookup(W, wlo, D.T, x, k, fk);
+          }
+          if (mine && ok) {
+            resolved = true;
+            int64_t len = 0;
+            if (have) {
+              if (hit && fk <= x) {
+                len = k + 1;
+              } else {                                                // the window did not reach: search alone
+                int64_t lo = 0, hi = D.T;
+                while (lo < hi) {
+                  const int64_t mid = (lo + hi) >> 1;
+                  if (D.bsz[mid] > r) lo = mid + 1; else hi = mid;
+                }
+                len = lo;
+              }
             }
-            const int64_t len = lo;
             const int64_t ts = apply_tmap(tmap, targ, t, len, len);
-            if (ts >= 0 && ts < len) other = S.boff[ts] + r;
+            if (have && ts >= 0 && ts < len) other = S.boff[ts] + r;
             if (other >= S.n_rows) other = -1;
             s_ld[i] = other;
             s_st[i] = j;
             done = true;
-          } else if (r >= 0 && r < D.B) {
+          }
+        } else if (mine && ok) {
+          resolved = true;
+          const int64_t r = j - bt;
+          if (r >= 0 && r < D.B) {
             b = D.sorted ? D.sorted[r] : r;
             token = b >= 0 && b < D.B;
           }
@@ -223,12 +268,33 @@ __global__ __launch_bounds__(BLOCK) void move_rows_kernel(rua_layout D, rua_layo
         if (colok && r < nrows) {
           const int64_t ld = s_ld[r];
           st[u] = s_st[r];
-          if (ld >= 0 && st[u] >= 0) val[u] = ld_row<V, NT>(src + ld * row_bytes + col * VEC);
+          if (ld >= 0 && st[u] >= 0) {
+            if constexpr (TAIL8) {
+              const char* p = src + ld * row_bytes + col * VEC;
+              if (col == lpr - 1) {                       // the row's last, 8-byte piece
+                const u32x2 h = ld_row<u32x2, NT>(p);
+                const u32x4 v2 = {h.x, h.y, 0u, 0u};
+                val[u] = v2;
+              } else {
+                val[u] = ld_row_a8<NT>(p);
+              }
+            } else {
+              val[u] = ld_row<V, NT>(src + ld * row_bytes + col * VEC);
+            }
+          }
         }
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u)
-        if (st[u] >= 0) st_row<V, NT>(dst + st[u] * row_bytes + col * VEC, val[u]);
+        if (st[u] >= 0) {
+          if constexpr (TAIL8) {
+            char* p = dst + st[u] * row_bytes + col * VEC;
+            if (col == lpr - 1) { u32x2 h = {val[u].x, val[u].y}; st_row<u32x2, NT>(p, h); }
+            else st_row_a8<NT>(p, val[u]);
+          } else {
+            st_row<V, NT>(dst + st[u] * row_bytes + col * VEC, val[u]);
+          }
+        }
     }
   }
 }
@@ -377,7 +443,8 @@ constexpr int NARROW_RPT = 4;
 template <bool SCATTER, bool NT>
 static int launch_move(int vec, int64_t n_rows, hipStream_t s, const rua_layout& D, const rua_layout& S, int32_t tmap,
                        int64_t targ, char* dst, const char* src, int64_t row_bytes, uint4 fp, int64_t pad_row,
-                       bool narrow_same_pack, int tile_rows, bool xcd_span) {
+                       bool narrow_same_pack, int tile_rows, bool xcd_span, bool tail8 = false) {
+  if (tail8) vec = 16;
   const int64_t lpr = (row_bytes + vec - 1) / vec;
   int lp_log2 = 0;
   while ((1 << lp_log2) < lpr && lp_log2 < 6) ++lp_log2;
@@ -413,6 +480,17 @@ static int launch_move(int vec, int64_t n_rows, hipStream_t s, const rua_layout&
     case 64: RUA_LAUNCH_T(VEC, 64); break;     \
     default: RUA_LAUNCH_T(VEC, MOVE_TILE); break; \
   }
+#define RUA_LAUNCH_TAIL(TR) \
+  hipLaunchKernelGGL((move_rows_kernel<16, SCATTER, NT, 1, TR, MOVE_BLOCK, UNROLL, true>), g, b, 0, s, D, S, tmap, targ, dst, src, row_bytes, lpr, lp_log2, cpr, fp, pad_row, per_xcd)
+  if (tail8) {
+    switch (tile_rows) {
+      case 16: RUA_LAUNCH_TAIL(16); break;
+      case 64: RUA_LAUNCH_TAIL(64); break;
+      default: RUA_LAUNCH_TAIL(MOVE_TILE); break;
+    }
+    return (int)hipGetLastError();
+  }
+#undef RUA_LAUNCH_TAIL
   switch (vec) {
     case 16: RUA_LAUNCH16(); break;
     case 8:  RUA_LAUNCH(8); break;
@@ -452,7 +530,7 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
   }
   hipStream_t s = (hipStream_t)stream;
   // narrow rows between a PackedSequence and a batch-major layout: (rank x time) tiles
-  const int span_flags = RUA_MOVE_XCD_SPAN_ON | RUA_MOVE_XCD_SPAN_OFF;
+  const int span_flags = RUA_MOVE_XCD_SPAN_ON | RUA_MOVE_XCD_SPAN_OFF | RUA_MOVE_NO_TAIL8;
   if ((flags & ~span_flags) == 0 && tmap == RUA_T_SHIFT && tmap_arg == 0 && row_bytes <= TILE_MAX_ROW_BYTES) {
     const bool to_pack = dst->kind == RUA_PACK && (src->kind == RUA_CAT || src->kind == RUA_LEFT || src->kind == RUA_RIGHT);
     const bool from_pack = src->kind == RUA_PACK && dst->kind == RUA_CAT;   // padded destinations need the fill pass
@@ -479,18 +557,21 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
   const int tsel = (flags >> 4) & 0xf;               // developer override: RUA_MOVE_TILE_LOG2 / RUA_MOVE_XCD_SPAN_*
   if (tsel >= 2 && tsel <= 8) tile_rows = 1 << tsel;
   if (tile_rows > MOVE_BLOCK) tile_rows = MOVE_BLOCK;
+  // rows that are a multiple of 8 but not of 16 bytes: 16-byte lanes at 8-byte-aligned addresses + an 8-byte tail
+  // (RUA_MOVE_NO_TAIL8, a developer flag, keeps the 8-byte lanes for A/B runs)
+  const bool tail8 = vec == 8 && row_bytes >= 24 && !(flags & RUA_MOVE_NO_TAIL8);
   if (vec != 16) tile_rows = tile_rows <= 16 ? 16 : tile_rows <= 64 ? 64 : MOVE_TILE;
   const int64_t nr = dst->n_rows;
   bool xcd_span = (nr + tile_rows - 1) / tile_rows >= MOVE_SPAN_MIN_TILES;
   if (flags & RUA_MOVE_XCD_SPAN_ON) xcd_span = true;
   if (flags & RUA_MOVE_XCD_SPAN_OFF) xcd_span = false;
   if (flags & RUA_MOVE_SCATTER)
-    return nt ? launch_move<true, true>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, false, tile_rows, xcd_span)
-              : launch_move<true, false>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, false, tile_rows, xcd_span);
+    return nt ? launch_move<true, true>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, false, tile_rows, xcd_span, tail8)
+              : launch_move<true, false>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, false, tile_rows, xcd_span, tail8);
   // roll / rev inside ONE PackedSequence with rows of at most 32 B (3.1 -> 3.9 TB/s; no gain at 64 B): RPT rows per lane (the kernel's `same_pack` test)
   const bool narrow_same_pack = vec == 16 && row_bytes <= 32 && dst->kind == RUA_PACK && src->kind == RUA_PACK &&
                                 dst->bsz && dst->boff && dst->boff == src->boff && dst->sorted == src->sorted &&
                                 dst->len_add == 0 && src->len_add == 0 && dst->T == src->T && dst->T > 0;
-  return nt ? launch_move<false, true>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, narrow_same_pack, tile_rows, xcd_span)
-            : launch_move<false, false>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, narrow_same_pack, tile_rows, xcd_span);
+  return nt ? launch_move<false, true>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, narrow_same_pack, tile_rows, xcd_span, tail8)
+            : launch_move<false, false>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, narrow_same_pack, tile_rows, xcd_span, tail8);
 }
