@@ -419,9 +419,11 @@ def test_long_sequences_are_split(hidden, dtype):
     assert torch.equal(src.grad, torch.ones_like(src))
 
 
-@pytest.mark.parametrize('B,hi', [(1, 1), (300, 40), (5000, 2048), (32768, 9), (32769, 9), (70000, 3), (50, 2049)])
+@pytest.mark.parametrize('B,hi', [(1, 1), (300, 40), (5000, 2048), (32768, 9), (32769, 9), (70000, 3), (50, 2049), (65536, 600),
+                                  (131072, 3), (131073, 3), (2048, 5), (2049, 5), (4097, 2)])
 def test_pack_prepare_equals_the_separate_steps(B, hi):
-    """rua_pack_prepare (one launch up to T = 2 048 / B = 32 768, three steps beyond) vs torch on the host."""
+    """rua_pack_prepare (one launch up to T = 2 048 / B = 131 072 — a block per tile of the lengths —, three steps
+    beyond) vs torch on the host."""
     g = torch.Generator().manual_seed(B + hi)
     lens = torch.randint(1, hi + 1, (B,), generator=g)
     lens[int(torch.randint(0, B, (1,), generator=g))] = hi

@@ -16,6 +16,10 @@ SHAPES = [  # B, lo, hi, hidden, dtype
     (300, 1, 700, (136,), torch.bfloat16),     # 272-byte rows, T > 512
     (2049, 1, 9, (1,), torch.float32),          # scan tile boundary, 4-byte rows
     (70, 50, 400, (640,), torch.float32),       # 2 560-byte rows: 3 column chunks per row
+    (120, 1, 90, (500,), torch.bfloat16),       # 1 000-byte rows (8 mod 16): 16-byte lanes + an 8-byte tail; 8-byte-lane reducers, one wave per row
+    (90, 1, 80, (250,), torch.float32),         # the same width in fp32
+    (150, 1, 60, (13,), torch.bfloat16),        # 26-byte rows: 2-byte lanes
+    (40, 1, 50, (1004,), torch.bfloat16),       # 2 008-byte rows (8 mod 16, two column chunks)
 ]
 
 
@@ -55,7 +59,7 @@ def test_casts_selects_vs_oracle(shape):
         assert_same_seq(t._replace(data=t.data.contiguous()), orc.trunc(osq[k], (a, b)), f'trunc {k}')
 
 
-@pytest.mark.parametrize('shape', SHAPES[:2] + SHAPES[3:], ids=['B5000', 'B300-bf16', 'B70-wide'])
+@pytest.mark.parametrize('shape', SHAPES[:2] + SHAPES[3:], ids=[f'B{s[0]}-H{s[3][0]}-{str(s[4])[6:]}' for s in SHAPES[:2] + SHAPES[3:]])
 def test_reductions_vs_oracle(shape):
     lens, data = _inputs(shape)
     data = (data * 0.25).to(data.dtype)

@@ -12,7 +12,6 @@
 #pragma once
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
-#include <cstdlib>
 #include "rua_dev.h"
 
 namespace rua {
@@ -1350,126 +1349,6 @@ __global__ __launch_bounds__(RUA_BLOCK) void scatter_self_grad_kernel(const int6
   gself[i] = elem<T>::down(r);
 }
 
-// ---------------------------------------------------------------- fused pack + reduce, a strip of ranks per wave
-// rua_pack_reduce for SUM / MEAN / PROD on the vector path.  The COPY form of seg_reduce_kernel gives a wave ONE
-// sequence: it reads 8 consecutive rows of it (contiguous) and stores them to 8 PackedSequence rows a whole time step
-// apart — 1-KiB stores scattered over the destination, which HBM likes least (writes are the expensive half of a copy
-// here: DESIGN.md §4.1).  This kernel turns the wave by ninety degrees: it owns STRIP_SLOTS x (64 >> lp_log2)
-// ADJACENT RANKS and walks time; at step t it reads row t of each of its sequences (one 1-KiB piece per sequence,
-// every sequence a sequential stream — what the row mover's gather looks like) and stores them to rows
-// boff[t] + rank .. — ONE contiguous run of the PackedSequence per wave and step (8 KiB at 1-KiB rows), while the
-// per-sequence sums stay in the lane's registers, folded in time order (the order the one-wave-per-sequence reducer
-// uses: bit-identical sums).  Workgroups take rank groups in order, longest sequences first.
-constexpr int STRIP_SLOTS = 8;      // rank slots per lane = rows in flight per lane
-
-template <typename T, int OP, bool NT>
-__global__ __launch_bounds__(RUA_BLOCK) void pack_reduce_strip_kernel(rua_layout L, rua_layout CD,
-                                                                     const T* __restrict__ data, T* __restrict__ copy,
-                                                                     T* __restrict__ out, int64_t H, int lp_log2) {
-  using A = typename elem<T>::acc;
-  constexpr int EPL = 16 / sizeof(T);
-  struct alignas(16) Pack { T v[EPL]; };
-  typedef unsigned int RawV __attribute__((ext_vector_type(4)));
-  const int lane = threadIdx.x & (RUA_WAVE - 1), wave = threadIdx.x >> 6;
-  const int rpw = RUA_WAVE >> lp_log2;                       // ranks one wave instruction covers
-  const int g = lane >> lp_log2;
-  const int64_t col = ((int64_t)blockIdx.y * RUA_WAVE + (lane & ((1 << lp_log2) - 1))) * EPL;
-  const bool colok = col < H;
-  const int64_t q0 = ((int64_t)blockIdx.x * RUA_WAVES_PER_BLOCK + wave) * (rpw * STRIP_SLOTS);
-  if (q0 >= L.B) return;                                     // wave-uniform
-
-  int64_t base[STRIP_SLOTS], len[STRIP_SLOTS], seq[STRIP_SLOTS];
-  A acc[STRIP_SLOTS][EPL];
-  int64_t tmax = 0;
-#pragma unroll
-  for (int k = 0; k < STRIP_SLOTS; ++k) {
-    const int64_t q = q0 + (int64_t)k * rpw + g;
-    int64_t b = -1;
-    if (q < L.B) b = CD.sorted ? CD.sorted[q] : q;
-    if (b < 0 || b >= L.B) b = -1;                           // a corrupt order must not index out of range
-    seq[k] = b;
-    len[k] = b >= 0 ? seq_len(L, b) : 0;
-    if (len[k] < 0) len[k] = 0;
-    base[k] = 0;
-    if (b >= 0) {
-      switch (L.kind) {
-        case RUA_CAT:   base[k] = cat_off(L, b); break;
-        case RUA_LEFT:  base[k] = b * L.T_phys; break;
-        case RUA_RIGHT: base[k] = b * L.T_phys + (L.T_log - len[k]); break;
-      }
-    }
-    tmax = len[k] > tmax ? len[k] : tmax;
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) acc[k][e] = (OP == RUA_PROD) ? (A)1 : (A)0;
-  }
-#pragma unroll
-  for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {               // the longest sequence of the wave
-    const int64_t o = __shfl_xor(tmax, d, RUA_WAVE);
-    tmax = o > tmax ? o : tmax;
-  }
-  if (tmax > CD.T) tmax = CD.T;                              // lengths that do not match batch_sizes stay inside boff
-
-  for (int64_t t = 0; t < tmax; ++t) {
-    const int64_t bo = CD.boff[t];                           // wave-uniform: a scalar load
-    Pack p[STRIP_SLOTS];
-    bool on[STRIP_SLOTS];
-#pragma unroll
-    for (int k = 0; k < STRIP_SLOTS; ++k) {
-      const int64_t row = base[k] + t;
-      on[k] = colok && t < len[k] && row < L.n_rows;
-      if (on[k]) {
-        const T* src = data + row * H + col;
-        if (NT) {
-          RawV raw = __builtin_nontemporal_load(reinterpret_cast<const RawV*>(src));
-          __builtin_memcpy(&p[k], &raw, sizeof(Pack));
-        } else {
-          p[k] = *reinterpret_cast<const Pack*>(src);
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < STRIP_SLOTS; ++k) {
-      const int64_t crow = bo + q0 + (int64_t)k * rpw + g;
-      if (on[k] && crow < CD.n_rows) {
-        T* dstp = copy + crow * H + col;
-        if (NT) {
-          RawV raw;
-          __builtin_memcpy(&raw, &p[k], sizeof(Pack));
-          __builtin_nontemporal_store(raw, reinterpret_cast<RawV*>(dstp));
-        } else {
-          *reinterpret_cast<Pack*>(dstp) = p[k];
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < STRIP_SLOTS; ++k)
-      if (on[k]) {
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-          const A x = elem<T>::up(p[k].v[e]);
-          acc[k][e] = (OP == RUA_PROD) ? acc[k][e] * x : acc[k][e] + x;
-        }
-      }
-  }
-#pragma unroll
-  for (int k = 0; k < STRIP_SLOTS; ++k)
-    if (seq[k] >= 0 && colok) {
-      Pack o;
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) {
-        A r = acc[k][e];
-        if (OP == RUA_MEAN && len[k] > 0) r = r / (A)len[k];
-        o.v[e] = elem<T>::down(r);
-      }
-      *reinterpret_cast<Pack*>(out + seq[k] * H + col) = o;
-    }
-}
-
-static inline bool strip_enabled() {
-  static const bool on = [] { const char* e = getenv("RUA_PACK_REDUCE_STRIP"); return !(e && e[0] == '0'); }();
-  return on;
-}
-
 // workspace carving for the long-sequence split (see SplitWs)
 static inline int64_t split_max_extra(int64_t n_rows, int64_t split) { return split > 0 ? n_rows / split : 0; }
 constexpr int64_t SPLIT_GRID_CAP = 16384;   // tail / combine grids: 2x the wave slots of the chip, then stride
@@ -1556,7 +1435,11 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
   int lp_log2 = 0;
   while ((1 << lp_log2) < lpr && lp_log2 < 6) ++lp_log2;
   // rows wider than one wave instruction (1 KiB): one wave owns 4 column chunks, i.e. up to 4 KiB of the row
-  const bool wide = vec_ok && lpr > RUA_WAVE;
+  // (the same for 8-byte lanes: H = 500 in bf16 is 125 lanes — as two column chunks two waves each read every other
+  // 512-byte half of the rows: reduce over P at H = 500 5.0 -> 5.7 TB/s
+  // — over a PackedSequence only: over the batch-major layouts, whose sequences are contiguous, the two waves per row
+  // were the better half of the bytes in flight: 4.0 -> 2.7 TB/s when tried)
+  const bool wide = (vec_ok || (half_ok && L.kind == RUA_PACK)) && lpr > RUA_WAVE;
   const int cpw = wide ? 4 : 1;
   const int64_t n_chunks = (lpr + RUA_WAVE * cpw - 1) / (RUA_WAVE * cpw);
   const int64_t blocks = L.B * n_chunks;  // one wave per workgroup
@@ -1566,21 +1449,6 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
   static const rua_layout none = {};
   const rua_layout& cd = copy ? *CD : none;
   if (copy && !vec_ok) return RUA_EALIGN;   // fused pack + reduce: vector path only (caller falls back to two launches)
-  if (copy && vec_ok && (op == RUA_SUM || op == RUA_MEAN || op == RUA_PROD) && cd.kind == RUA_PACK && cd.boff &&
-      !(split > 0 && ws) && strip_enabled()) {
-    // a strip of adjacent ranks per wave: contiguous stores into the PackedSequence (pack_reduce_strip_kernel)
-    const int64_t ranks_per_block = (int64_t)(RUA_WAVE >> lp_log2) * STRIP_SLOTS * RUA_WAVES_PER_BLOCK;
-    const int64_t gx = (L.B + ranks_per_block - 1) / ranks_per_block;
-    const int64_t gy = (lpr + RUA_WAVE - 1) / RUA_WAVE;
-    if (gx > 0x7fffffffLL || gy > 65535) return RUA_ERANGE;
-    const dim3 gg((unsigned)gx, (unsigned)gy), bb(RUA_BLOCK);
-#define RUA_STRIP(OPV, NTV) \
-  hipLaunchKernelGGL((pack_reduce_strip_kernel<T, OPV, NTV>), gg, bb, 0, s, L, cd, (const T*)data, (T*)copy, (T*)out, H, lp_log2)
-    if (nt) { if (op == RUA_SUM) RUA_STRIP(RUA_SUM, true); else if (op == RUA_MEAN) RUA_STRIP(RUA_MEAN, true); else RUA_STRIP(RUA_PROD, true); }
-    else    { if (op == RUA_SUM) RUA_STRIP(RUA_SUM, false); else if (op == RUA_MEAN) RUA_STRIP(RUA_MEAN, false); else RUA_STRIP(RUA_PROD, false); }
-#undef RUA_STRIP
-    return (int)hipGetLastError();
-  }
   // (only when that still leaves >= 4 waves per SIMD: with fewer sequences one wave per sequence fills the chip better)
   if (L.kind == RUA_PACK && L.sorted && !copy && !perm && lp_log2 < 6 && !(split > 0 && ws) &&
       (L.B >> (6 - lp_log2)) >= RANKS_MIN_WAVES) {
@@ -1646,10 +1514,11 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
   return launch_reduce<T, EPLV, NTV, COPYV, CPWV>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self, \
                                                   empty_bits, extreme, cd, copy, split, ws, ties)
   if (copy) {
-    if (wide) { if (nt) RUA_GO(FULL, true, true, 4); else RUA_GO(FULL, false, true, 4); }
+    if (wide) { if (nt) RUA_GO(FULL, true, true, 4); else RUA_GO(FULL, false, true, 4); }      // (copy: vec_ok)
     if (nt) RUA_GO(FULL, true, true, 1); else RUA_GO(FULL, false, true, 1);
   }
-  if (wide) { if (nt) RUA_GO(FULL, true, false, 4); else RUA_GO(FULL, false, false, 4); }
+  if (wide && vec_ok) { if (nt) RUA_GO(FULL, true, false, 4); else RUA_GO(FULL, false, false, 4); }
+  if (wide && half_ok) RUA_GO(HALF, false, false, 4);
   if (vec_ok) { if (nt) RUA_GO(FULL, true, false, 1); else RUA_GO(FULL, false, false, 1); }
   if (half_ok) RUA_GO(HALF, false, false, 1);
   RUA_GO(1, false, false, 1);
