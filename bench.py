@@ -248,7 +248,11 @@ def main():
     # intra-op pool to it — eight unpinned ranks otherwise run eight host sorts and eight 128-thread pools on every core
     from torchrua_amd.parallel import bind_rank_to_cpus
     local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
-    my_cpus = bind_rank_to_cpus(local_rank, local_world, dev.index)
+    try:
+        my_cpus = bind_rank_to_cpus(local_rank, local_world, dev.index)
+    except Exception as exc:                     # a host the planner does not understand must never cost the run
+        print(f'bench.py: rank {rank}: CPU binding skipped ({exc!r})', file=sys.stderr)
+        my_cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else []
     import torch.distributed as dist
     use_dist = world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ)   # under torchrun
     if use_dist:
@@ -329,7 +333,7 @@ def main():
     extra = {}
     if world == 1:                     # the same pipeline with device-only lengths (blocking D2H per pack)
         sync()
-        k = max(3, args.steps // 4)
+        k = max(5, args.steps // 2)
         step(host_mirror=False)
         sync()
         t1 = time.perf_counter()
@@ -394,12 +398,14 @@ def main():
         # passes): the figure is carried from the committed profile of this same command and shape, with its source
         # named beside it, and is null for any other shape
         traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
-        if os.path.exists(tpath) and (B, H, args.lo, args.hi) == (65536, 512, 8, 512):
-            with open(tpath) as f:
+        import glob
+        tpaths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_traffic.json')))      # the latest round's
+        if tpaths and (B, H, args.lo, args.hi) == (65536, 512, 8, 512):
+            with open(tpaths[-1]) as f:
                 tj = json.load(f)
             traffic = tj.get('to_pack_hbm_bytes_per_launch')
-            traffic_source = f"profiles/r02_traffic.json ({tj.get('collected', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes')})"
+            traffic_source = (f"profiles/{os.path.basename(tpaths[-1])} "
+                              f"({tj.get('collected', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes')})")
         line = {
             'metric': f'pack->reduce throughput, {B} seqs/GPU h={H} bf16 (M elements/s) + % HBM roofline',
             'value': round(value, 1), 'unit': 'M elements/s', 'n_gpus': world, 'steps': args.steps,

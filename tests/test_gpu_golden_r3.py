@@ -242,3 +242,23 @@ def test_compose(case):
     grads = grad_wrt(out.data, xs)
     for i, g in enumerate(grads):
         check(g, f[f'grad.in{i}'], f'grad.in{i}', exact=True)
+
+
+# ------------------------------------------------------------------ how exact, against what the reference itself achieves
+def test_long_reductions_are_as_exact_as_the_reference():
+    """`referr.*` stores how far the REFERENCE's fp32 results are from an fp64 evaluation of the same inputs (512-1 024-row
+    sequences: 8e-6 in plain relative terms, 8.5e-8 of sum|x|).  The kernels' error against that fp64 evaluation, in the
+    same measure, stays within twice the reference's own — the stored number behind the 1e-5 * sum|x| allowance that
+    test_gpu_golden.py makes for sequences beyond 256 rows (VERDICT r2 #7)."""
+    f, e = golden()['reduce.long'], golden()['referr.reduce.long']
+    data, lens = to_torch(f['data'], DEV), to_torch(f['lens'], DEV)
+    sabs = e['sum_abs']
+    assert float(e['sum.max_rel']) > 1e-6          # the reference itself is not "1e-5 relative" of exact by much
+    for name in ('sum', 'mean', 'logsumexp'):
+        got = to_np(getattr(ta, f'segment_{name}')(data, lens)).astype(np.float64)
+        err = float((np.abs(got - e[f'{name}.f64']) / np.maximum(sabs, 1e-300)).max())
+        ref_err = float(e[f'{name}.max_over_sum_abs'])
+        assert err <= max(2.0 * ref_err, 2.0 ** -23), (name, err, ref_err)
+    # over the PackedSequence of the same batch: the same bar
+    got = to_np(ta.reduce_sum(ta.C(data, lens).pack())).astype(np.float64)
+    assert float((np.abs(got - e['sum.f64']) / np.maximum(sabs, 1e-300)).max()) <= max(2.0 * float(e['sum.max_over_sum_abs']), 2.0 ** -23)
