@@ -91,7 +91,7 @@ inline StopLists& stop_lists() {
   return s;
 }
 
-constexpr int64_t BRANCHLESS_MIN = 80;       // shorter segments keep the plain loop (less set-up than it saves)
+constexpr int64_t BRANCHLESS_MIN = 48;       // shorter segments keep the plain loop (less set-up than it saves)
 
 // listing the stops: one branch-free pass (2 compares, 2 stores per element) ...
 template <typename KV>
@@ -199,7 +199,40 @@ inline void leaf_sort(KV* first, KV* last) {
   }
 }
 
-struct Task { void* first; void* last; int64_t depth; bool narrow; };
+#if defined(__x86_64__)
+// the same with AVX-512 for the narrow elements whose keys lie in [0, 2^27) (lengths always do): a key and its position
+// in the leaf make ONE 32-bit word (key << 4 | 15 - position) — no two words are equal, a larger word comes earlier —
+// so the place of an element is the count of larger words: one compare of the 16 words against a broadcast, one popcount.
+__attribute__((target("avx512f"))) inline void leaf_sort_avx512(KV8* first, int m) {
+  const __m512i even = _mm512_set_epi32(30, 28, 26, 24, 22, 20, 18, 16, 14, 12, 10, 8, 6, 4, 2, 0);
+  const __m512i rev = _mm512_set_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+  // masked loads: only the leaf's own elements are touched (the neighbouring segment may belong to another thread)
+  const unsigned em = (1u << m) - 1u;
+  const __m512i v0 = _mm512_maskz_loadu_epi64((__mmask8)(em & 0xffu), (const void*)first);
+  const __m512i v1 = _mm512_maskz_loadu_epi64((__mmask8)(em >> 8), (const void*)(first + 8));
+  const __m512i keys = _mm512_permutex2var_epi32(v0, even, v1);
+  const __mmask16 valid = (__mmask16)((1u << m) - 1u);
+  const __m512i words = _mm512_maskz_or_epi32(valid, _mm512_slli_epi32(keys, 4), rev);   // absent lanes: 0, never larger
+  alignas(64) KV8 tmp[16];
+  alignas(64) uint32_t w[16];
+  _mm512_store_si512((void*)tmp, v0);
+  _mm512_store_si512((void*)(tmp + 8), v1);
+  _mm512_store_si512((void*)w, words);
+  for (int i = 0; i < m; ++i) {
+    const int r = __builtin_popcount((unsigned)_mm512_cmpgt_epu32_mask(words, _mm512_set1_epi32((int)w[i])));
+    first[r] = tmp[i];
+  }
+}
+#endif
+inline void leaf_sort_fast(KV8* first, KV8* last, bool small_keys) {
+#if defined(__x86_64__)
+  if (g_avx512 && small_keys) { if (last - first >= 2) leaf_sort_avx512(first, (int)(last - first)); return; }
+#endif
+  leaf_sort(first, last);
+}
+inline void leaf_sort_fast(KV16* first, KV16* last, bool) { leaf_sort(first, last); }
+
+struct Task { void* first; void* last; int64_t depth; bool narrow; bool small_keys; };
 
 std::atomic<int64_t> g_heap_segments{0};   // diagnostics: segments that ran out of depth budget, all calls so far
 
@@ -212,11 +245,11 @@ class Pool {
 
   // sort [first, last) with up to `threads` threads (the caller is one of them)
   template <typename KV>
-  void sort(KV* first, KV* last, int threads) {
+  void sort(KV* first, KV* last, int threads, bool small_keys = false) {
     const int64_t n = last - first;
     if (n < 2) return;
     const int64_t depth = 2 * floor_log2(n);
-    const Task root{first, last, depth, sizeof(KV) == sizeof(KV8)};
+    const Task root{first, last, depth, sizeof(KV) == sizeof(KV8), small_keys};
     if (threads <= 1 || n < 2 * SPAWN_MIN) {
       run(root, false);
       return;
@@ -325,11 +358,11 @@ class Pool {
       }
       --depth;
       KV* cut = last - first >= BRANCHLESS_MIN ? partition_pivot_lists(first, last) : partition_pivot(first, last);
-      if (spawn && last - cut >= SPAWN_MIN) push(Task{cut, last, depth, t.narrow});
-      else run_t<KV>(Task{cut, last, depth, t.narrow}, spawn);
+      if (spawn && last - cut >= SPAWN_MIN) push(Task{cut, last, depth, t.narrow, t.small_keys});
+      else run_t<KV>(Task{cut, last, depth, t.narrow, t.small_keys}, spawn);
       last = cut;
     }
-    leaf_sort(first, last);
+    leaf_sort_fast(first, last, t.small_keys);
   }
 
   std::mutex m_, entry_;
@@ -354,14 +387,14 @@ int rua_host_sort_desc(const int64_t* keys, int64_t n, int64_t* sorted_indices, 
   if (n < 0 || (n > 0 && (!keys || !sorted_indices))) return RUA_EINVAL;
   if (n == 0) return 0;
   std::vector<KV16>& v = scratch();
-  if ((int64_t)v.size() < n) v.resize((size_t)n);
+  if ((int64_t)v.size() < n + 16) v.resize((size_t)n + 16);
   const int threads = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
   int64_t lo = keys[0], hi = keys[0];
   for (int64_t i = 1; i < n; ++i) { lo = keys[i] < lo ? keys[i] : lo; hi = keys[i] > hi ? keys[i] : hi; }
   if (lo >= INT32_MIN && hi <= INT32_MAX && n <= 0xffffffffLL) {
     KV8* a = reinterpret_cast<KV8*>(v.data());       // (the scratch is sized for the wide elements)
     for (int64_t i = 0; i < n; ++i) { a[i].key = (int32_t)keys[i]; a[i].idx = (uint32_t)i; }
-    Pool::get().sort(a, a + n, threads);
+    Pool::get().sort(a, a + n, threads, lo >= 0 && hi < (1 << 27));
     for (int64_t i = 0; i < n; ++i) sorted_indices[i] = (int64_t)a[i].idx;
     return 0;
   }
