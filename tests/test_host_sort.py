@@ -129,6 +129,8 @@ def test_host_sort_under_sanitizers(tmp_path, sanitizer):
                     '-I', os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'c', 'host_sort_stress.cpp'),
                     os.path.join(ROOT, 'torchrua_amd', 'csrc', 'rua_host.cpp'), '-o', exe], check=True)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    if 'unexpected memory mapping' in out.stderr:
+        pytest.skip('this kernel\'s address-space layout is one the sanitizer runtime cannot run under')
     assert out.returncode == 0 and 'mismatches 0' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
     assert 'WARNING: ThreadSanitizer' not in out.stderr and 'ERROR: AddressSanitizer' not in out.stderr \
         and 'runtime error' not in out.stderr, out.stderr[-4000:]
