@@ -508,25 +508,23 @@ class _StagingRing:
             self.bufs[i] = buf
         return i, buf[:nbytes].view(dtype).view(shape)
 
-    def commit(self, i: int, staged: Tensor, dev: torch.device, stream_idle: bool = False) -> Tensor:
+    def commit(self, i: int, staged: Tensor, dev: torch.device) -> Tensor:
         """Enqueue the H2D of a slot filled through reserve()."""
         try:
-            return self._commit(i, staged, dev, stream_idle)
+            return self._commit(i, staged, dev)
         finally:
             self.busy[i] = False
 
-    def _commit(self, i: int, staged: Tensor, dev: torch.device, stream_idle: bool = False) -> Tensor:
-        out, ev = self.h2d(staged, dev, stream_idle)
+    def _commit(self, i: int, staged: Tensor, dev: torch.device) -> Tensor:
+        out, ev = self.h2d(staged, dev)
         self.events[i] = ev
         return out
 
-    def h2d(self, staged: Tensor, dev: torch.device, stream_idle: bool = False):
-        """Enqueue the H2D of a PINNED host tensor; returns (device tensor, event that follows the copy).
-        stream_idle: the caller has just synchronised the compute stream (a read-back of device-only lengths): there is
-        nothing to overlap with, and the side-stream hand-off would only add host work to the time the GPU idles."""
+    def h2d(self, staged: Tensor, dev: torch.device):
+        """Enqueue the H2D of a PINNED host tensor; returns (device tensor, event that follows the copy)."""
         cur = torch.cuda.current_stream(dev)
         ev = torch.cuda.Event()
-        if stream_idle or staged.numel() < self.SIDE_MIN_ELEMS or torch.cuda.is_current_stream_capturing():
+        if staged.numel() < self.SIDE_MIN_ELEMS or torch.cuda.is_current_stream_capturing():
             out = torch.empty(staged.shape, dtype=staged.dtype, device=dev)
             out.copy_(staged, non_blocking=True)
             ev.record(cur)
@@ -599,6 +597,14 @@ def sorted_indices_to_device(host_lens_: Tensor, dev: torch.device, stream_idle:
     n = host_lens_.numel()
     if dev.type != 'cuda' or n == 0:
         return host_sort_desc(host_lens_).to(dev)
+    if stream_idle:
+        # device-only lengths: the compute stream was synchronised a moment ago and the GPU idles until the mover is
+        # launched, so every host microsecond here shows.  No ring slot, no events, no side stream: a block from torch's
+        # pinned host cache, the sort straight into it, ONE async copy on the current stream (the host allocator keeps
+        # the block until that copy is done).
+        staged = torch.empty(n, dtype=torch.long, pin_memory=True)
+        host_sort_desc(host_lens_, out=staged)
+        return staged.to(dev, non_blocking=True)
     ring = _ring(dev)
     i, staged = ring.reserve((n,), torch.long)
     try:
@@ -606,7 +612,7 @@ def sorted_indices_to_device(host_lens_: Tensor, dev: torch.device, stream_idle:
     except BaseException:
         ring.busy[i] = False
         raise
-    return ring.commit(i, staged, dev, stream_idle)
+    return ring.commit(i, staged, dev)
 
 
 def lay_list(bptr: Optional[Tensor], tptr: Tensor) -> Lay:

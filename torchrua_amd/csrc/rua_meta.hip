@@ -288,6 +288,52 @@ __global__ __launch_bounds__(RUA_BLOCK) void enum_rows_kernel(rua_layout L, int6
   }
 }
 
+// L.idx() / R.idx() (flat storage row of every token of a padded batch, layout/left.py:73-77, right.py:74-79) and the
+// flat-only enumeration of a CattedSequence: a lane owns FOUR CONSECUTIVE tokens — one cooperative lookup for the
+// first of them, then it walks along the offsets (consecutive tokens share a sequence until the next boundary) — and
+// writes them as two 16-byte stores.  enum_rows_kernel resolved every token by itself: 60 us for the 136 MB of the
+// north-star batch, a quarter of the rate of a plain store stream.
+constexpr int FLAT_PER_LANE = 4;
+__global__ __launch_bounds__(RUA_BLOCK) void enum_flat_kernel(rua_layout L, int64_t n, int64_t* __restrict__ flat) {
+  constexpr int64_t BIG = 0x7fffffffffffffffLL;
+  const int lane = threadIdx.x & (RUA_WAVE - 1);
+  const int64_t wave_id = ((int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x) >> 6;
+  const int64_t j0 = wave_id * (RUA_WAVE * FLAT_PER_LANE);
+  if (j0 >= n) return;                                         // wave-uniform
+  int64_t lo, W;
+  coop_window([&](int64_t q) { return cat_off(L, q); }, L.B, j0, lane, lo, W);
+  const int64_t j = j0 + (int64_t)lane * FLAT_PER_LANE;
+  int64_t k, fk;
+  const bool ok = coop_lookup(W, lo, L.B, j < n ? j : n - 1, k, fk);
+  if (j >= n) return;
+  if (!ok) { k = search_cat(L, j); fk = cat_off(L, k); }
+  int64_t next = k + 1 < L.B ? cat_off(L, k + 1) : BIG;
+  int64_t len = L.kind == RUA_RIGHT ? seq_len(L, k) : 0;
+  int64_t row[FLAT_PER_LANE];
+#pragma unroll
+  for (int c = 0; c < FLAT_PER_LANE; ++c) {
+    const int64_t jj = j + c;
+    while (jj >= next) {                                       // the next sequence (zero-length ones are stepped over)
+      ++k;
+      fk = next;
+      next = k + 1 < L.B ? cat_off(L, k + 1) : BIG;
+      if (L.kind == RUA_RIGHT) len = seq_len(L, k);
+    }
+    const int64_t t = jj - fk;
+    row[c] = L.kind == RUA_CAT ? jj : L.kind == RUA_LEFT ? k * L.T_phys + t : k * L.T_phys + (L.T_log - len) + t;
+  }
+  if (j + FLAT_PER_LANE <= n && ((uintptr_t)flat & 15) == 0) {
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    const i64x2 a = {row[0], row[1]}, b = {row[2], row[3]};
+    *reinterpret_cast<i64x2*>(flat + j) = a;
+    *reinterpret_cast<i64x2*>(flat + j + 2) = b;
+  } else {
+#pragma unroll
+    for (int c = 0; c < FLAT_PER_LANE; ++c)
+      if (j + c < n) flat[j + c] = row[c];
+  }
+}
+
 // ------------------------------------------------------------------ masks
 // One lane writes 16 bytes (EPV elements) of the flat [B, T] grid: ONE integer division per 16-byte store locates
 // the first element, the rest walk along the row (and into the next one where a vector straddles a row end).
@@ -406,6 +452,12 @@ int rua_enum_rows(const rua_layout* lay, int64_t n_tokens, int64_t* batch_ptr, i
     return RUA_EINVAL;
   }
   if (n_tokens == 0) return 0;
+  if (!batch_ptr && !token_ptr && flat && (lay->kind == RUA_LEFT || lay->kind == RUA_RIGHT) && lay->off) {
+    const int64_t per_block = (int64_t)RUA_BLOCK * FLAT_PER_LANE;
+    hipLaunchKernelGGL(enum_flat_kernel, dim3((unsigned)((n_tokens + per_block - 1) / per_block)), dim3(RUA_BLOCK), 0,
+                       (hipStream_t)stream, *lay, n_tokens, flat);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(enum_rows_kernel, dim3(grid_for((n_tokens + ENUM_CHUNKS - 1) / ENUM_CHUNKS)), dim3(RUA_BLOCK), 0,
                      (hipStream_t)stream, *lay, n_tokens, batch_ptr, token_ptr, flat);
   return (int)hipGetLastError();
