@@ -192,8 +192,8 @@ enum rua_op {
 #define RUA_OP_SCRATCH_CLEAN 0x100
 #define RUA_OP_NO_EMPTY      0x200
 int64_t rua_reduce_ws_bytes(int64_t n_rows, int64_t H, int32_t dtype, int64_t split_rows);
-/* Waves (1, 2 or 4) that share one sequence in rua_segment_reduce for a 16-byte-aligned payload of `row_bytes`-wide
- * rows, B sequences, n_rows rows in all — the launcher's own rule, exported so that a host planner pricing
+/* Waves (1, 2 or 4) that share one sequence in rua_segment_reduce for an aligned payload of `row_bytes`-wide
+ * rows (multiples of 16 bytes, or of 8 bytes beyond one vector), B sequences, n_rows rows in all — the launcher's own rule, exported so that a host planner pricing
  * `split_rows` (a unit streams team-times as fast) cannot drift from it. */
 int rua_reduce_team_waves(int64_t n_rows, int64_t B, int64_t row_bytes);
 int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* data, void* out,

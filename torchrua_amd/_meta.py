@@ -667,7 +667,7 @@ def reduce_split_rows(lay: Lay, row_bytes: int = 1024, team_ok: bool = True) -> 
     # rows up to 1 KiB on the vector path, at most 16 384 units, >= 4 row groups per wave): a unit then streams
     # 2-4x as fast, and splitting — three launches and a pass over fp32 partials — is for real outliers only
     team = 1
-    if team_ok and 0 < row_bytes <= 1024 and row_bytes % 16 == 0:
+    if team_ok and 0 < row_bytes <= 1024 and row_bytes % 8 == 0:
         team = L.load().rua_reduce_team_waves(n, max(lay.B, 1), int(row_bytes))      # the launcher's own rule
     wave_rate = WAVE_RATE * team
     ideal_rows = int(0.75 * n * row_bytes / STREAM_RATE * wave_rate / rb_unit)   # rows a unit walks in 3/4 of the balanced time

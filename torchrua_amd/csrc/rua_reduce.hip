@@ -32,9 +32,10 @@ using namespace rua;
 extern "C" {
 
 int rua_reduce_team_waves(int64_t n_rows, int64_t B, int64_t row_bytes) {
-  // what dispatch_reduce_main decides for a 16-byte-aligned payload whose rows are a multiple of 16 bytes
-  if (row_bytes <= 0 || row_bytes % 16 != 0 || row_bytes > 16 * RUA_WAVE) return 1;
-  const int64_t lpr = row_bytes / 16;
+  // what dispatch_reduce_main decides for an aligned payload whose rows are a multiple of 16 bytes — or of 8 bytes,
+  // beyond one vector (16-byte lanes with an overlapping last lane)
+  if (row_bytes <= 0 || row_bytes % 8 != 0 || (row_bytes % 16 != 0 && row_bytes <= 16) || row_bytes > 16 * RUA_WAVE) return 1;
+  const int64_t lpr = (row_bytes + 15) / 16;
   int lp_log2 = 0;
   while ((1 << lp_log2) < lpr && lp_log2 < 6) ++lp_log2;
   return reduce_team_waves(n_rows, B, lp_log2, B);      // one column chunk per row: units = sequences

@@ -140,6 +140,8 @@ __device__ __forceinline__ Unit<T, EPL> make_unit(const rua_layout& L, const rua
   u.rsub = lane >> lp_log2;
   u.col = (chunk * CPW * RUA_WAVE + (lane & ((1 << lp_log2) - 1))) * EPL;   // sub-chunk c adds c * 64 * EPL
   u.colok = u.col < H && live;
+  // rows that end in half a vector (dispatch_reduce_main: tail_ok): the last lane covers the row's last EPL elements
+  if (EPL > 1 && CPW == 1 && u.col < H && u.col + EPL > H) u.col = H - EPL;
   u.live = live;
   u.len = live ? seq_len(L, u.b) : 0;
   u.n_rows = L.n_rows;
@@ -202,8 +204,10 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
   using A = typename elem<T>::acc;
   constexpr int UT = CPW == 1 ? UNROLL_T : UNROLL_T / 2;     // rows in flight (x CPW loads each)
   constexpr int CW = RUA_WAVE * EPL;                          // elements per 64-lane column chunk
-  struct alignas(sizeof(T) * EPL) Pack { T v[EPL]; };
-  typedef unsigned int RawV __attribute__((ext_vector_type(sizeof(T) * EPL >= 4 ? sizeof(T) * EPL / 4 : 1)));
+  // (a 16-byte piece may sit on an 8-byte boundary only: rows of 8 (mod 16) bytes, see dispatch_reduce_main)
+  struct alignas(sizeof(T) * EPL > 8 ? 8 : sizeof(T) * EPL) Pack { T v[EPL]; };
+  typedef unsigned int RawV0 __attribute__((ext_vector_type(sizeof(T) * EPL >= 4 ? sizeof(T) * EPL / 4 : 1)));
+  typedef RawV0 RawV __attribute__((aligned(sizeof(T) * EPL > 8 ? 8 : (sizeof(T) * EPL >= 4 ? sizeof(T) * EPL : 4))));
   const int rpw = U.rpw, rsub = U.rsub;
   const bool colok = U.colok;
   const int64_t col = U.col, base = U.base, tb = U.tb, L_rows = U.n_rows;
@@ -1426,7 +1430,16 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
   constexpr int FULL = 16 / sizeof(T);
   constexpr int HALF = FULL >= 4 ? FULL / 2 : 1;      // 8-byte loads: hidden sizes that are a multiple of 8 bytes only
   const uintptr_t fptrs = (uintptr_t)data | (uintptr_t)out | (uintptr_t)copy | (uintptr_t)ties;
-  const bool vec_ok = (H % FULL == 0) && (fptrs % 16 == 0);
+  const bool aligned_ok = (H % FULL == 0) && (fptrs % 16 == 0);
+  // Rows of 8 (mod 16) bytes (H = 500 in bf16): every other row starts on an 8-byte boundary only and the last lane of
+  // a row would hold half a vector.  gfx950 takes a dwordx4 at any dword-aligned address, and the LAST lane simply
+  // covers the last FULL elements of the row, overlapping its neighbour by half a vector: both lanes fold the same
+  // elements in the same order and store the same results (make_unit clamps the column).  Round 2 used 8-byte lanes
+  // there — two column chunks, two waves per row, 4.0 TB/s for segment_max over a CattedSequence at H = 500.
+  // (Not with include_self == 1: the store then reads the old row, and two lanes would fold it in twice.)
+  const bool tail_ok = !aligned_ok && FULL > 1 && H > FULL && (H + FULL - 1) / FULL <= RUA_WAVE &&
+                       (H * (int64_t)sizeof(T)) % 8 == 0 && (fptrs % 8 == 0) && include_self != 1 && !copy;
+  const bool vec_ok = aligned_ok || tail_ok;
   // (H = 300 or 650 in bf16 — GloVe vectors, PTB-sized LSTMs: the scalar path moves 128 B per wave instruction and
   // measured 2.9 TB/s; 8-byte lanes move 512 B)
   const bool half_ok = !vec_ok && HALF > 1 && (H % HALF == 0) && (fptrs % 8 == 0);
@@ -1448,7 +1461,7 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
   const unsigned g = (unsigned)blocks;
   static const rua_layout none = {};
   const rua_layout& cd = copy ? *CD : none;
-  if (copy && !vec_ok) return RUA_EALIGN;   // fused pack + reduce: vector path only (caller falls back to two launches)
+  if (copy && !aligned_ok) return RUA_EALIGN;   // fused pack + reduce: vector path only (caller falls back to two launches)
   // (only when that still leaves >= 4 waves per SIMD: with fewer sequences one wave per sequence fills the chip better)
   if (L.kind == RUA_PACK && L.sorted && !copy && !perm && lp_log2 < 6 && !(split > 0 && ws) &&
       (L.B >> (6 - lp_log2)) >= RANKS_MIN_WAVES) {
