@@ -69,9 +69,19 @@ def _parse_cpulist(text: str) -> List[int]:
     return cpus
 
 
-def _numa_node_of_gpu(pci_bus_id: str) -> int:
+def _pci_name(props) -> str:
+    """sysfs name (dddd:bb:dd.f) of a GPU from torch's device properties: `pci_bus_id` is a string on some builds and
+    the bus NUMBER (with `pci_domain_id` / `pci_device_id` beside it) on others."""
+    bus = getattr(props, 'pci_bus_id', None)
+    if isinstance(bus, str):
+        return bus.lower()
+    dom, dev = int(getattr(props, 'pci_domain_id', 0) or 0), int(getattr(props, 'pci_device_id', 0) or 0)
+    return f'{dom:04x}:{int(bus):02x}:{dev:02x}.0'
+
+
+def _numa_node_of_gpu(pci_name: str) -> int:
     """NUMA node of a GPU from sysfs (-1 when the platform does not say)."""
-    for name in (pci_bus_id.lower(), pci_bus_id.lower().replace('0000:', '', 1)):
+    for name in (pci_name, '0000:' + pci_name if pci_name.count(':') == 1 else pci_name):
         path = f'/sys/bus/pci/devices/{name}/numa_node'
         if os.path.exists(path):
             with open(path) as f:
@@ -118,7 +128,7 @@ def bind_rank_to_cpus(local_rank: int, local_world: int, device_index: Optional[
     allowed = sorted(os.sched_getaffinity(0))
     gpu_nodes, node_cpus = None, None
     try:
-        gpu_nodes = [_numa_node_of_gpu(torch.cuda.get_device_properties(i).pci_bus_id)
+        gpu_nodes = [_numa_node_of_gpu(_pci_name(torch.cuda.get_device_properties(i)))
                      for i in range(torch.cuda.device_count())]
         if device_index is not None and local_rank < len(gpu_nodes):
             gpu_nodes[local_rank] = gpu_nodes[device_index]
