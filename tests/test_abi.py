@@ -102,10 +102,12 @@ def test_reducer_split_policy():
     assert M.reduce_split_rows(FakeLay(34_000_000, 65536, 1024), 2048) == 0    # cfg4
     assert M.reduce_split_rows(FakeLay(1_070_000, 4096, 512), 512) == 0        # cfg2: LPT hides 512-row sequences
     # few units: a team of 4 waves per unit (rows up to 1 KiB on the vector path) fills the chip without the three
-    # launches of the split; rows the team kernel does not take (wider than 1 KiB, odd widths) are still cut
+    # launches of the split — rows of 8 (mod 16) bytes included since round 3 (16-byte lanes with an overlapping last
+    # lane); rows the team kernel does not take (wider than 1 KiB, widths that are no multiple of 8) are still cut
     assert M.reduce_split_rows(FakeLay(133_000, 512, 512), 1024) == 0
     assert M.reduce_split_rows(FakeLay(133_000, 512, 512), 2048) == 64
-    assert M.reduce_split_rows(FakeLay(133_000, 512, 512), 1000) == 65
+    assert M.reduce_split_rows(FakeLay(133_000, 512, 512), 1000) == 0
+    assert M.reduce_split_rows(FakeLay(133_000, 512, 512), 1004) == 65
     assert M.reduce_split_rows(FakeLay(533_000, 2048, 512), 128) == 0          # narrow rows: the longest walk is 16 us
     assert 64 <= M.reduce_split_rows(FakeLay(1_131_008, 2048, 1_000_000), 1024) <= 256   # one giant sequence
     assert M.reduce_split_rows(FakeLay(100_000_000, 64, 5_000_000), 1024) == 4096
@@ -114,5 +116,11 @@ def test_reducer_split_policy():
     blind = M.reduce_split_rows(FakeLay(1_070_000, 4096, None), 512)           # cfg2 with device-only lengths:
     assert blind > 512                                                         # armed, but nothing of cfg2 is cut
     assert M.reduce_split_rows(FakeLay(200, 3, 150), 1024) == 0
+    # the wave-team rule the planner prices with IS the launcher's (rua_reduce_team_waves): a few fixed points
+    lib = _lib.load()
+    assert lib.rua_reduce_team_waves(133_000, 512, 1024) == 4 and lib.rua_reduce_team_waves(133_000, 512, 1000) == 4
+    assert lib.rua_reduce_team_waves(133_000, 512, 1004) == 1 and lib.rua_reduce_team_waves(133_000, 512, 2048) == 1
+    assert lib.rua_reduce_team_waves(17_046_960, 65536, 1024) == 1                 # plenty of units: one wave each
+    assert lib.rua_reduce_team_waves(40_000, 512, 1024) == 2 and lib.rua_reduce_team_waves(8, 512, 16) == 1
     t = torch.tensor([3, 9, 2])
     assert M.known_max_len(t) == 9 and M.known_max_len(None) is None

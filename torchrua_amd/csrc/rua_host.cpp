@@ -144,7 +144,10 @@ __attribute__((target("avx512f"))) inline void list_stops_avx512(const KV8* a, i
   nl_out = nl;
   nr_out = nr;
 }
-const bool g_avx512 = __builtin_cpu_supports("avx512f") && std::getenv("RUA_HOST_SORT_SCALAR") == nullptr;
+const bool g_avx512 = [] {
+  __builtin_cpu_init();        // (this runs as a static initialiser of a shared library: do not rely on constructor order)
+  return __builtin_cpu_supports("avx512f") && std::getenv("RUA_HOST_SORT_SCALAR") == nullptr;
+}();
 #else
 const bool g_avx512 = false;
 #endif
