@@ -294,7 +294,22 @@ __global__ __launch_bounds__(RUA_BLOCK) void enum_rows_kernel(rua_layout L, int6
 // writes them as two 16-byte stores.  enum_rows_kernel resolved every token by itself: 60 us for the 136 MB of the
 // north-star batch, a quarter of the rate of a plain store stream.
 constexpr int FLAT_PER_LANE = 4;
-__global__ __launch_bounds__(RUA_BLOCK) void enum_flat_kernel(rua_layout L, int64_t n, int64_t* __restrict__ flat) {
+__device__ __forceinline__ void store4(int64_t* __restrict__ dst, int64_t j, int64_t n, const int64_t (&v)[FLAT_PER_LANE]) {
+  if (j + FLAT_PER_LANE <= n && ((uintptr_t)dst & 15) == 0) {
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    const i64x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    *reinterpret_cast<i64x2*>(dst + j) = a;
+    *reinterpret_cast<i64x2*>(dst + j + 2) = b;
+  } else {
+#pragma unroll
+    for (int c = 0; c < FLAT_PER_LANE; ++c)
+      if (j + c < n) dst[j + c] = v[c];
+  }
+}
+
+// the batch-major layouts (C / L / R enumerate their tokens sequence by sequence): ptr() and idx() — any of bp, tp, flat
+__global__ __launch_bounds__(RUA_BLOCK) void enum_flat_kernel(rua_layout L, int64_t n, int64_t* __restrict__ bp,
+                                                              int64_t* __restrict__ tp, int64_t* __restrict__ flat) {
   constexpr int64_t BIG = 0x7fffffffffffffffLL;
   const int lane = threadIdx.x & (RUA_WAVE - 1);
   const int64_t wave_id = ((int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x) >> 6;
@@ -309,7 +324,7 @@ __global__ __launch_bounds__(RUA_BLOCK) void enum_flat_kernel(rua_layout L, int6
   if (!ok) { k = search_cat(L, j); fk = cat_off(L, k); }
   int64_t next = k + 1 < L.B ? cat_off(L, k + 1) : BIG;
   int64_t len = L.kind == RUA_RIGHT ? seq_len(L, k) : 0;
-  int64_t row[FLAT_PER_LANE];
+  int64_t row[FLAT_PER_LANE], kb[FLAT_PER_LANE], tt[FLAT_PER_LANE];
 #pragma unroll
   for (int c = 0; c < FLAT_PER_LANE; ++c) {
     const int64_t jj = j + c;
@@ -320,18 +335,48 @@ __global__ __launch_bounds__(RUA_BLOCK) void enum_flat_kernel(rua_layout L, int6
       if (L.kind == RUA_RIGHT) len = seq_len(L, k);
     }
     const int64_t t = jj - fk;
+    kb[c] = k;
+    tt[c] = t;
     row[c] = L.kind == RUA_CAT ? jj : L.kind == RUA_LEFT ? k * L.T_phys + t : k * L.T_phys + (L.T_log - len) + t;
   }
-  if (j + FLAT_PER_LANE <= n && ((uintptr_t)flat & 15) == 0) {
-    typedef long long i64x2 __attribute__((ext_vector_type(2)));
-    const i64x2 a = {row[0], row[1]}, b = {row[2], row[3]};
-    *reinterpret_cast<i64x2*>(flat + j) = a;
-    *reinterpret_cast<i64x2*>(flat + j + 2) = b;
-  } else {
+  if (bp) store4(bp, j, n, kb);
+  if (tp) store4(tp, j, n, tt);
+  if (flat) store4(flat, j, n, row);
+}
+
+// P.ptr(): tokens in storage order, (sorted[rank], t) — layout/pack.py:23-27 — the same way: a lane owns four
+// consecutive storage rows, looks the first one's time step up with its wave and walks along boff
+__global__ __launch_bounds__(RUA_BLOCK) void enum_pack_kernel(rua_layout L, int64_t n, int64_t* __restrict__ bp,
+                                                              int64_t* __restrict__ tp) {
+  constexpr int64_t BIG = 0x7fffffffffffffffLL;
+  const int lane = threadIdx.x & (RUA_WAVE - 1);
+  const int64_t wave_id = ((int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x) >> 6;
+  const int64_t j0 = wave_id * (RUA_WAVE * FLAT_PER_LANE);
+  if (j0 >= n) return;                                         // wave-uniform
+  int64_t lo, W;
+  coop_window([&](int64_t q) { return L.boff[q]; }, L.T, j0, lane, lo, W);
+  const int64_t j = j0 + (int64_t)lane * FLAT_PER_LANE;
+  int64_t t, bt;
+  const bool ok = coop_lookup(W, lo, L.T, j < n ? j : n - 1, t, bt);
+  if (j >= n) return;
+  if (!ok) { t = search_boff(L.boff, L.T, j); bt = L.boff[t]; }
+  int64_t next = t + 1 < L.T ? L.boff[t + 1] : BIG;
+  int64_t kb[FLAT_PER_LANE], tt[FLAT_PER_LANE];
 #pragma unroll
-    for (int c = 0; c < FLAT_PER_LANE; ++c)
-      if (j + c < n) flat[j + c] = row[c];
+  for (int c = 0; c < FLAT_PER_LANE; ++c) {
+    const int64_t jj = j + c;
+    while (jj >= next) {
+      ++t;
+      bt = next;
+      next = t + 1 < L.T ? L.boff[t + 1] : BIG;
+    }
+    int64_t r = jj - bt;
+    if (r < 0 || r >= L.B) r = 0;              // a token count that does not match batch_sizes must not index out of range
+    kb[c] = L.sorted ? L.sorted[r] : r;
+    tt[c] = t;
   }
+  if (bp) store4(bp, j, n, kb);
+  if (tp) store4(tp, j, n, tt);
 }
 
 // ------------------------------------------------------------------ masks
@@ -352,10 +397,23 @@ __global__ __launch_bounds__(RUA_BLOCK) void mask_kernel(const int64_t* __restri
     int64_t b = e0 / T, t = e0 - b * T;
     int64_t len = lens[b];
     Vec v;
+    if (sizeof(E) == 1 && t + EPV <= T) {
+      // a bool / byte mask (bmask: 32 MiB at the north-star shape) whose 16 elements lie in one row: the first n1 bytes
+      // are `one`, the rest `zero` — two 64-bit selects instead of sixteen compare-and-step rounds
+      const int64_t left = len - t;
+      const int n1 = left <= 0 ? 0 : left >= EPV ? EPV : (int)left;
+      const uint64_t ones = 0x0101010101010101ull * (uint64_t)(uint8_t)one, zeros = 0x0101010101010101ull * (uint64_t)(uint8_t)zero;
+      const int lo_n = n1 < 8 ? n1 : 8, hi_n = n1 > 8 ? n1 - 8 : 0;
+      const uint64_t lo_m = lo_n >= 8 ? ~0ull : ((1ull << (8 * lo_n)) - 1ull);
+      const uint64_t hi_m = hi_n >= 8 ? ~0ull : ((1ull << (8 * hi_n)) - 1ull);
+      uint64_t w[2] = {(ones & lo_m) | (zeros & ~lo_m), (ones & hi_m) | (zeros & ~hi_m)};
+      __builtin_memcpy(&v, w, sizeof(Vec));
+    } else {
 #pragma unroll
-    for (int i = 0; i < EPV; ++i) {
-      v.v[i] = t < len ? one : zero;
-      if (++t == T) { t = 0; ++b; len = b < B ? lens[b] : 0; }
+      for (int i = 0; i < EPV; ++i) {
+        v.v[i] = t < len ? one : zero;
+        if (++t == T) { t = 0; ++b; len = b < B ? lens[b] : 0; }
+      }
     }
     *reinterpret_cast<Vec*>(out + e0) = v;
   } else {
@@ -452,10 +510,17 @@ int rua_enum_rows(const rua_layout* lay, int64_t n_tokens, int64_t* batch_ptr, i
     return RUA_EINVAL;
   }
   if (n_tokens == 0) return 0;
-  if (!batch_ptr && !token_ptr && flat && (lay->kind == RUA_LEFT || lay->kind == RUA_RIGHT) && lay->off) {
+  if (lay->kind == RUA_PACK && (batch_ptr || token_ptr) && !flat) {      // P.ptr()
+    const int64_t per_block = (int64_t)RUA_BLOCK * FLAT_PER_LANE;
+    hipLaunchKernelGGL(enum_pack_kernel, dim3((unsigned)((n_tokens + per_block - 1) / per_block)), dim3(RUA_BLOCK), 0,
+                       (hipStream_t)stream, *lay, n_tokens, batch_ptr, token_ptr);
+    return (int)hipGetLastError();
+  }
+  // the batch-major layouts with ragged lengths: four consecutive tokens per lane (C.idx() alone stays an iota)
+  if (lay->kind != RUA_PACK && lay->off && lay->lens && (batch_ptr || token_ptr || lay->kind != RUA_CAT)) {
     const int64_t per_block = (int64_t)RUA_BLOCK * FLAT_PER_LANE;
     hipLaunchKernelGGL(enum_flat_kernel, dim3((unsigned)((n_tokens + per_block - 1) / per_block)), dim3(RUA_BLOCK), 0,
-                       (hipStream_t)stream, *lay, n_tokens, flat);
+                       (hipStream_t)stream, *lay, n_tokens, batch_ptr, token_ptr, flat);
     return (int)hipGetLastError();
   }
   hipLaunchKernelGGL(enum_rows_kernel, dim3(grid_for((n_tokens + ENUM_CHUNKS - 1) / ENUM_CHUNKS)), dim3(RUA_BLOCK), 0,
