@@ -185,6 +185,8 @@ def warm(nbytes: int, device=None, blocks: int = 3) -> int:
     """Opt-in, at the caller's expense: put `blocks` blocks of `nbytes` into torch's allocator cache so that
     empty_for has something to choose from.  Returns how many it got (an OutOfMemoryError ends it early)."""
     dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:                      # 'cuda' without an index: tensors carry one, and so must the bookkeeping
+        dev = torch.device('cuda', torch.cuda.current_device())
     got: List[Tensor] = []
     with _lock:
         for _ in range(max(0, blocks)):
