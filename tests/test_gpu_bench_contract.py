@@ -103,6 +103,8 @@ def test_bench_legs_are_sane_at_the_north_star_shape():
     f = d['fused_pack_reduce']
     assert f['kernel_ms'] > 0 and f['ms_per_step'] <= 1.25 * f['kernel_ms'], f
     assert d['device_lens']['ms_per_step'] <= 1.4 * kernels, (d['device_lens'], kernels)
+    on_dev = d['device_lens']['produced_on_device']            # lengths a previous kernel left on the device
+    assert on_dev['ms_per_step'] <= 1.4 * kernels and 0.6 <= on_dev['frac_of_hbm_peak_wall'] < 1
     assert d['roofline']['frac'] >= 0.6 and d['pipeline']['frac_of_hbm_peak_wall'] >= 0.6
     par = d['parity']
     assert par['max_exact'] is True and par['sum_f32_vs_fp64_over_sum_abs'] <= 1e-5
