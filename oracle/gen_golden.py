@@ -625,6 +625,26 @@ def compose_case(case, spec, H, seed, grads=True):
             put(case, f'grad.in{i}', gi)
 
 
+def view_case(case, lens, H, dtype, seed):
+    """X.cat_view() / left_view(fill) / pack_view() / right_view(fill) (core/view.py:21-77): the destination container's
+    METADATA around either the untouched storage (cat / pack views) or a freshly filled one (padded views)."""
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.as_tensor(lens, dtype=torch.long)
+    N = int(lens.sum())
+    data = torch.randn((N, H), generator=g).to(dtype)
+    put(case, 'lens', lens)
+    put(case, 'data', data)
+    c = C(data, lens)
+    seqs = {k: as_kind(c, k) for k in 'CLPR'}
+    put(case, 'sorted_indices', seqs['P'].sorted_indices)
+    for k, z in seqs.items():
+        put_seq(case, f'view.{k}.C', z.cat_view())
+        put_seq(case, f'view.{k}.L', z.left_view(FILL))
+        put_seq(case, f'view.{k}.R', z.right_view(FILL))
+        put_seq(case, f'view.{k}.P', z.pack_view())
+        put_seq(case, f'view.{k}.L.long', z.left_view(7, dtype=torch.long))
+
+
 def reference_fold_error(case_from, store_from, keep_f64=True):
     """how far the reference's OWN fp32 results are from an fp64 evaluation of the same inputs, for the
     long-sequence reduce fixtures — the stored number behind the bound tests/test_gpu_golden.py uses there."""
@@ -673,6 +693,8 @@ def round3():
                                    ('R', rng.randint(1, 5, 7)), ('C', rng.randint(1, 5, 1))], 2, seed=551)
     compose_case('compose.ties', [(k, rng.randint(1, 4, n)) for k, n in zip('CLPRCLPRCLPRCLPRCLPR', [3] * 20)], 1, seed=552)
     compose_case('compose.one', [('R', rng.randint(1, 6, 19))], 4, seed=553)
+    view_case('view.a', rng.randint(1, 6, 9), 3, torch.float32, seed=560)
+    view_case('view.ties18', rng.randint(1, 4, 18), 2, torch.bfloat16, seed=561)
     reference_fold_error('reduce.long', 'extra.npz')
     reference_fold_error('reduce.h512', 'extra.npz', keep_f64=False)
     np.savez_compressed(os.path.join(OUT, 'r3.npz'), **store)

@@ -262,3 +262,27 @@ def test_long_reductions_are_as_exact_as_the_reference():
     # over the PackedSequence of the same batch: the same bar
     got = to_np(ta.reduce_sum(ta.C(data, lens).pack())).astype(np.float64)
     assert float((np.abs(got - e['sum.f64']) / np.maximum(sabs, 1e-300)).max()) <= max(2.0 * float(e['sum.max_over_sum_abs']), 2.0 ** -23)
+
+
+# ------------------------------------------------------------------ views
+@pytest.mark.parametrize('case', cases('view.'))
+def test_views(case):
+    """core/view.py:21-77 — the destination container's metadata around the untouched storage (cat / pack views: the
+    SAME storage object) or a freshly filled one (padded views, with and without a dtype)."""
+    f = golden()[case]
+    bf = f['data'].dtype == np.uint16
+    data, lens = to_torch(f['data'], DEV, bf16=bf), to_torch(f['lens'], DEV)
+    if not local_sort_matches(f['lens'], f['sorted_indices']):
+        pytest.skip('torch.sort tie order on this host differs from the generating machine')
+    c = ta.C(data, lens)
+    for k in 'CLPR':
+        z = as_kind(c, k)
+        v = z.cat_view()
+        assert_same_seq(v, seq_from(f, f'view.{k}.C', 'C'), f'view.{k}.C')
+        assert v.data.data_ptr() == z.data.data_ptr()                       # a view: no payload moved
+        assert_same_seq(z.left_view(FILL), seq_from(f, f'view.{k}.L', 'L'), f'view.{k}.L')
+        assert_same_seq(z.right_view(FILL), seq_from(f, f'view.{k}.R', 'R'), f'view.{k}.R')
+        pv = z.pack_view()
+        assert_same_seq(pv, seq_from(f, f'view.{k}.P', 'P'), f'view.{k}.P')
+        assert pv.data.data_ptr() == z.data.data_ptr() and pv.batch_sizes.device.type == 'cpu'
+        assert_same_seq(z.left_view(7, dtype=torch.long), seq_from(f, f'view.{k}.L.long', 'L'), f'view.{k}.L.long')

@@ -85,3 +85,19 @@ def test_compose(case):
         arrays = np.split(f[f'in{i}.data'], np.cumsum(lens)[:-1])
         seqs.append(orc.new(kind, arrays, 0, _sort_desc(lens)))
     assert_seq_equal(orc.compose(seqs, _sort_desc), f, 'out', 'P')
+
+
+@pytest.mark.parametrize('case', cases('view.'))
+def test_views(case):
+    """core/view.py:21-77: cat_view / left_view / pack_view / right_view of every layout."""
+    f = golden()[case]
+    fill = _fill_for(f)
+    c = orc.C(f['data'], f['lens'])
+    srt = f['sorted_indices']
+    for k in KINDS:
+        z = _as_kind(c, k, fill, srt)
+        assert_seq_equal(orc.cat_view(z), f, f'view.{k}.C', 'C')
+        assert_seq_equal(orc._padded_view(z, 'L', fill), f, f'view.{k}.L', 'L')
+        assert_seq_equal(orc._padded_view(z, 'R', fill), f, f'view.{k}.R', 'R')
+        assert_seq_equal(orc.pack_view(z, srt), f, f'view.{k}.P', 'P')
+        assert_seq_equal(orc._padded_view(z, 'L', 7, np.int64), f, f'view.{k}.L.long', 'L')
