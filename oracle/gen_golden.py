@@ -645,6 +645,32 @@ def view_case(case, lens, H, dtype, seed):
         put_seq(case, f'view.{k}.L.long', z.left_view(7, dtype=torch.long))
 
 
+def scatter_dim_case(case, S, M, H, seed):
+    """scatter_*(tensor, index, source, include_self, dim) with dim != 0 (reduce.py:6-31 hand `dim` to torch.index_reduce /
+    index_add): a [H, S] target reduced along its LAST dimension, and a 3-d one along the middle."""
+    import warnings
+    g = torch.Generator().manual_seed(seed)
+    index = torch.randint(0, S, (M,), generator=g)
+    put(case, 'index', index)
+    for tag, tshape, sshape, dim in (('last', (H, S), (H, M), 1), ('neg', (H, S), (H, M), -1), ('mid', (2, S, H), (2, M, H), 1)):
+        tensor = torch.randn(tshape, generator=g)
+        source = torch.randn(sshape, generator=g)
+        put(case, f'{tag}.tensor', tensor)
+        put(case, f'{tag}.source', source)
+        put(case, f'{tag}.dim', np.asarray(dim, dtype=np.int64))
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            for name in ('max', 'min', 'sum', 'mean', 'prod', 'logsumexp'):
+                for inc in (False, True):
+                    try:
+                        out = getattr(ref, f'scatter_{name}')(tensor, index, source, include_self=inc, dim=dim)
+                    except IndexError as e:
+                        # reference limit: scatter_logsumexp indexes `m[index]` along dim 0 whatever `dim` is (reduce.py:30)
+                        skipped.append(f'{case}/{tag}.scatter_{name}.{int(inc)}: {type(e).__name__}')
+                        continue
+                    put(case, f'{tag}.scatter_{name}.{int(inc)}', out)
+
+
 def reference_fold_error(case_from, store_from, keep_f64=True):
     """how far the reference's OWN fp32 results are from an fp64 evaluation of the same inputs, for the
     long-sequence reduce fixtures — the stored number behind the bound tests/test_gpu_golden.py uses there."""
@@ -695,6 +721,7 @@ def round3():
     compose_case('compose.one', [('R', rng.randint(1, 6, 19))], 4, seed=553)
     view_case('view.a', rng.randint(1, 6, 9), 3, torch.float32, seed=560)
     view_case('view.ties18', rng.randint(1, 4, 18), 2, torch.bfloat16, seed=561)
+    scatter_dim_case('scatterdim.a', 7, 40, 5, seed=570)
     reference_fold_error('reduce.long', 'extra.npz')
     reference_fold_error('reduce.h512', 'extra.npz', keep_f64=False)
     np.savez_compressed(os.path.join(OUT, 'r3.npz'), **store)

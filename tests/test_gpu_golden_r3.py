@@ -286,3 +286,24 @@ def test_views(case):
         assert_same_seq(pv, seq_from(f, f'view.{k}.P', 'P'), f'view.{k}.P')
         assert pv.data.data_ptr() == z.data.data_ptr() and pv.batch_sizes.device.type == 'cpu'
         assert_same_seq(z.left_view(7, dtype=torch.long), seq_from(f, f'view.{k}.L.long', 'L'), f'view.{k}.L.long')
+
+
+# ------------------------------------------------------------------ scatter_* along another dimension
+@pytest.mark.parametrize('case', cases('scatterdim.'))
+def test_scatter_along_another_dim(case):
+    """reduce.py:6-31 hand `dim` to torch.index_reduce / index_add; here the reduced dimension is brought to the front
+    and back around the row kernels.  max / min exact, the others 1e-5."""
+    f = golden()[case]
+    idx = to_torch(f['index'], DEV)
+    for tag in ('last', 'neg', 'mid'):
+        ten, src, dim = to_torch(f[f'{tag}.tensor'], DEV), to_torch(f[f'{tag}.source'], DEV), int(f[f'{tag}.dim'])
+        for name in ('max', 'min', 'sum', 'mean', 'prod', 'logsumexp'):
+            for inc in (0, 1):
+                got = getattr(ta, f'scatter_{name}')(ten, idx, src, include_self=bool(inc), dim=dim)
+                if f'{tag}.scatter_{name}.{inc}' not in f:         # the reference's scatter_logsumexp raises for dim != 0
+                    ref0 = getattr(ta, f'scatter_{name}')(ten.movedim(dim, 0).contiguous(), idx, src.movedim(dim, 0).contiguous(),
+                                                         include_self=bool(inc)).movedim(0, dim)
+                    assert torch.equal(got, ref0)
+                    continue
+                check(got, f[f'{tag}.scatter_{name}.{inc}'], f'{tag}.scatter_{name}.{inc}', exact=name in ('max', 'min'))
+        assert to_np(ten).tobytes() == f[f'{tag}.tensor'].tobytes()           # the target is not written

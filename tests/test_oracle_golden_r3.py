@@ -101,3 +101,26 @@ def test_views(case):
         assert_seq_equal(orc._padded_view(z, 'R', fill), f, f'view.{k}.R', 'R')
         assert_seq_equal(orc.pack_view(z, srt), f, f'view.{k}.P', 'P')
         assert_seq_equal(orc._padded_view(z, 'L', 7, np.int64), f, f'view.{k}.L.long', 'L')
+
+
+@pytest.mark.parametrize('case', cases('scatterdim.'))
+def test_scatter_along_another_dim(case):
+    """scatter_*(..., dim != 0): the oracle reduces along rows, so `dim` goes to the front and back (what
+    torch.index_reduce's `dim` means)."""
+    f = golden()[case]
+    idx = f['index']
+    for tag in ('last', 'neg', 'mid'):
+        ten, src, dim = f[f'{tag}.tensor'], f[f'{tag}.source'], int(f[f'{tag}.dim'])
+        t0, s0 = np.ascontiguousarray(np.moveaxis(ten, dim, 0)), np.ascontiguousarray(np.moveaxis(src, dim, 0))
+        for name in ('max', 'min', 'sum', 'mean', 'prod', 'logsumexp'):
+            for inc in (0, 1):
+                got = getattr(orc, f'scatter_{name}')(t0.reshape(t0.shape[0], -1), idx, s0.reshape(s0.shape[0], -1),
+                                                      include_self=bool(inc)).reshape(t0.shape)
+                got = np.moveaxis(got, 0, dim)
+                if f'{tag}.scatter_{name}.{inc}' not in f:
+                    continue          # the reference's scatter_logsumexp raises for dim != 0 (META.json)
+                exp = f[f'{tag}.scatter_{name}.{inc}']
+                if name in ('max', 'min'):
+                    np.testing.assert_array_equal(got, exp, err_msg=f'{tag}.{name}.{inc}')
+                else:
+                    np.testing.assert_allclose(got, exp, rtol=2e-6, atol=2e-6, err_msg=f'{tag}.{name}.{inc}')
