@@ -671,6 +671,24 @@ def scatter_dim_case(case, S, M, H, seed):
                     put(case, f'{tag}.scatter_{name}.{int(inc)}', out)
 
 
+def mask_case(case, lens, H, dtype, seed):
+    """X.mask(zero, one, dtype) / X.bmask() / X.fmask() for every layout (mask.py:6-38); the mask of a right-aligned
+    container is the LOGICAL [b, t] grid too (ptr() enumerates tokens, not storage slots)."""
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.as_tensor(lens, dtype=torch.long)
+    data = torch.randn((int(lens.sum()), H), generator=g).to(dtype)
+    put(case, 'lens', lens)
+    put(case, 'data', data)
+    c = C(data, lens)
+    for k in 'CLPR':
+        z = as_kind(c, k)
+        put(case, f'bmask.{k}', z.bmask())
+        put(case, f'fmask.{k}', z.fmask())
+        put(case, f'mask.{k}.i32', z.mask(zero=-3, one=9, dtype=torch.int32))
+        put(case, f'mask.{k}.u8', z.mask(zero=7, one=1, dtype=torch.uint8))
+        put(case, f'mask.{k}.own', z.mask(zero=0.5, one=-2.0))             # dtype=None: the payload's own
+
+
 def reference_fold_error(case_from, store_from, keep_f64=True):
     """how far the reference's OWN fp32 results are from an fp64 evaluation of the same inputs, for the
     long-sequence reduce fixtures — the stored number behind the bound tests/test_gpu_golden.py uses there."""
@@ -722,6 +740,8 @@ def round3():
     view_case('view.a', rng.randint(1, 6, 9), 3, torch.float32, seed=560)
     view_case('view.ties18', rng.randint(1, 4, 18), 2, torch.bfloat16, seed=561)
     scatter_dim_case('scatterdim.a', 7, 40, 5, seed=570)
+    mask_case('maskall.f32', rng.randint(1, 20, 13), 2, torch.float32, seed=580)
+    mask_case('maskall.bf16', rng.randint(1, 5, 21), 4, torch.bfloat16, seed=581)
     reference_fold_error('reduce.long', 'extra.npz')
     reference_fold_error('reduce.h512', 'extra.npz', keep_f64=False)
     np.savez_compressed(os.path.join(OUT, 'r3.npz'), **store)

@@ -307,3 +307,21 @@ def test_scatter_along_another_dim(case):
                     continue
                 check(got, f[f'{tag}.scatter_{name}.{inc}'], f'{tag}.scatter_{name}.{inc}', exact=name in ('max', 'min'))
         assert to_np(ten).tobytes() == f[f'{tag}.tensor'].tobytes()           # the target is not written
+
+
+# ------------------------------------------------------------------ masks of every layout
+@pytest.mark.parametrize('case', cases('maskall.'))
+def test_masks_of_every_layout(case):
+    """mask.py:6-38 on C / L / P / R: bool, additive float (the payload's dtype, bf16 included), int32, uint8 and the
+    payload's own dtype — bit-exact."""
+    f = golden()[case]
+    bf = f['data'].dtype == np.uint16
+    c = ta.C(to_torch(f['data'], DEV, bf16=bf), to_torch(f['lens'], DEV))
+    for k in 'CLPR':
+        z = as_kind(c, k)
+        assert to_np(z.bmask()).tobytes() == f[f'bmask.{k}'].tobytes(), f'bmask.{k}'
+        assert to_np(z.fmask()).tobytes() == f[f'fmask.{k}'].tobytes(), f'fmask.{k}'
+        assert to_np(z.mask(zero=-3, one=9, dtype=torch.int32)).tobytes() == f[f'mask.{k}.i32'].tobytes()
+        assert to_np(z.mask(zero=7, one=1, dtype=torch.uint8)).tobytes() == f[f'mask.{k}.u8'].tobytes()
+        got = z.mask(zero=0.5, one=-2.0)
+        assert got.dtype == c.data.dtype and to_np(got).tobytes() == f[f'mask.{k}.own'].tobytes(), f'mask.{k}.own'

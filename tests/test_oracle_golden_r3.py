@@ -124,3 +124,20 @@ def test_scatter_along_another_dim(case):
                     np.testing.assert_array_equal(got, exp, err_msg=f'{tag}.{name}.{inc}')
                 else:
                     np.testing.assert_allclose(got, exp, rtol=2e-6, atol=2e-6, err_msg=f'{tag}.{name}.{inc}')
+
+
+@pytest.mark.parametrize('case', cases('maskall.'))
+def test_masks_of_every_layout(case):
+    f = golden()[case]
+    fill = _fill_for(f)
+    bf = f['data'].dtype == np.uint16
+    c = orc.C(f['data'], f['lens'])
+    srt = _sort_desc(f['lens'])
+    for k in KINDS:
+        z = _as_kind(c, k, fill, srt)
+        np.testing.assert_array_equal(orc.mask(z, False, True, np.bool_), f[f'bmask.{k}'])
+        np.testing.assert_array_equal(orc.mask(z, -3, 9, np.int32), f[f'mask.{k}.i32'])
+        np.testing.assert_array_equal(orc.mask(z, 7, 1, np.uint8), f[f'mask.{k}.u8'])
+        if not bf:
+            np.testing.assert_array_equal(orc.mask(z, np.finfo(np.float32).min, 0, np.float32), f[f'fmask.{k}'])
+            np.testing.assert_array_equal(orc.mask(z, 0.5, -2.0, np.float32), f[f'mask.{k}.own'])
