@@ -124,3 +124,20 @@ def test_reducer_split_policy():
     assert lib.rua_reduce_team_waves(40_000, 512, 1024) == 2 and lib.rua_reduce_team_waves(8, 512, 16) == 1
     t = torch.tensor([3, 9, 2])
     assert M.known_max_len(t) == 9 and M.known_max_len(None) is None
+
+
+def test_dtype_and_device_movers():
+    """layout/cat.py:13-59 and twins: to / double / float / half / long / int / short / char / byte / cpu / detach return
+    the same container type with the payload converted and the lengths left as they are (plain torch plumbing: runs on
+    the CPU)."""
+    import torchrua_amd as ta
+    for cls, shape in ((ta.C, (6, 3)), (ta.L, (2, 4, 3)), (ta.R, (2, 4, 3))):
+        z = cls(torch.randn(shape, requires_grad=True), torch.tensor([2, 4]))
+        for name, dtype in (('double', torch.double), ('float', torch.float), ('half', torch.half), ('long', torch.long),
+                            ('int', torch.int), ('short', torch.short), ('char', torch.int8), ('byte', torch.uint8)):
+            out = getattr(z, name)()
+            assert type(out) is cls and out.data.dtype == dtype and out.token_sizes.dtype == torch.long
+            assert torch.equal(out.token_sizes, z.token_sizes)
+        out = z.to(dtype=torch.bfloat16, device=torch.device('cpu'))
+        assert type(out) is cls and out.data.dtype == torch.bfloat16 and out.data.device.type == 'cpu'
+        assert type(z.cpu()) is cls and not z.detach().data.requires_grad and z.detach().data.data_ptr() == z.data.data_ptr()
