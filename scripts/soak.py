@@ -62,6 +62,14 @@ while time.time() < t_end:
             assert_same_seq(z.roll(s), orc.roll(osq[k], s, srt), f'roll {k} {s}')
             assert_same_seq(z.rev(), orc.rev(osq[k], srt), f'rev {k}')
             assert np.array_equal(to_np(z.last()), orc.last(osq[k])), f'last {k}'
+            if N <= 3_000_000:          # the integer kernels (ptr / idx / masks), bit-exact
+                bp, tp = z.ptr()
+                obp, otp = orc.ptr(osq[k])
+                assert np.array_equal(to_np(bp), obp) and np.array_equal(to_np(tp), otp), f'ptr {k}'
+                assert np.array_equal(to_np(z.idx().data), orc.idx(osq[k]).data), f'idx {k}'
+                if B * int(lens.max()) <= 4_000_000:
+                    assert np.array_equal(to_np(z.bmask()), orc.mask(osq[k], False, True, np.bool_)), f'bmask {k}'
+                    assert np.array_equal(to_np(ta.get_mask(z)), orc.get_mask(osq[k])), f'get_mask {k}'
         if dtype != torch.int64:
             f = data.double().numpy() if dtype == torch.float64 else data.float().numpy()
             ulp = {torch.float32: 0.0, torch.float64: 0.0, torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dtype]
