@@ -289,94 +289,99 @@ __global__ __launch_bounds__(RUA_BLOCK) void enum_rows_kernel(rua_layout L, int6
 }
 
 // L.idx() / R.idx() (flat storage row of every token of a padded batch, layout/left.py:73-77, right.py:74-79) and the
-// flat-only enumeration of a CattedSequence: a lane owns FOUR CONSECUTIVE tokens — one cooperative lookup for the
+// flat-only enumeration of a CattedSequence: a lane owns EIGHT CONSECUTIVE tokens — one cooperative lookup for the
 // first of them, then it walks along the offsets (consecutive tokens share a sequence until the next boundary) — and
-// writes them as two 16-byte stores.  enum_rows_kernel resolved every token by itself: 60 us for the 136 MB of the
+// writes them as 16-byte stores.  enum_rows_kernel resolved every token by itself: 60 us for the 136 MB of the
 // north-star batch, a quarter of the rate of a plain store stream.
-constexpr int FLAT_PER_LANE = 4;
-__device__ __forceinline__ void store4(int64_t* __restrict__ dst, int64_t j, int64_t n, const int64_t (&v)[FLAT_PER_LANE]) {
-  if (j + FLAT_PER_LANE <= n && ((uintptr_t)dst & 15) == 0) {
+constexpr int ENUM_PAIR = 2;        // consecutive tokens per lane and chunk: one 16-byte store per output
+constexpr int ENUM_NCH = 4;         // chunks of 64 * ENUM_PAIR tokens one wave enumerates from ONE search + window
+__device__ __forceinline__ void store2(int64_t* __restrict__ dst, int64_t j, int64_t n, int64_t a, int64_t b) {
+  if (j + 1 < n && ((uintptr_t)dst & 15) == 0) {
     typedef long long i64x2 __attribute__((ext_vector_type(2)));
-    const i64x2 a = {v[0], v[1]}, b = {v[2], v[3]};
-    *reinterpret_cast<i64x2*>(dst + j) = a;
-    *reinterpret_cast<i64x2*>(dst + j + 2) = b;
+    const i64x2 v = {a, b};
+    *reinterpret_cast<i64x2*>(dst + j) = v;      // lanes side by side: 1 KiB per wave instruction
   } else {
-#pragma unroll
-    for (int c = 0; c < FLAT_PER_LANE; ++c)
-      if (j + c < n) dst[j + c] = v[c];
+    if (j < n) dst[j] = a;
+    if (j + 1 < n) dst[j + 1] = b;
   }
 }
 
-// the batch-major layouts (C / L / R enumerate their tokens sequence by sequence): ptr() and idx() — any of bp, tp, flat
+// the batch-major layouts (C / L / R enumerate their tokens sequence by sequence): ptr() and idx() — any of bp, tp, flat.
+// A lane owns TWO CONSECUTIVE tokens of each of the wave's four chunks — one lookup for the first, a step along the
+// offsets for the second — and writes them as ONE 16-byte store per output, the lanes of a wave side by side.
+// (enum_rows_kernel resolved and stored every token by itself: 60 us for L.idx() at the north-star shape, a quarter of the
+// rate of a plain store stream; 4 and 8 consecutive tokens per lane save lookups but stride the stores: 39 / 50 us.)
 __global__ __launch_bounds__(RUA_BLOCK) void enum_flat_kernel(rua_layout L, int64_t n, int64_t* __restrict__ bp,
                                                               int64_t* __restrict__ tp, int64_t* __restrict__ flat) {
   constexpr int64_t BIG = 0x7fffffffffffffffLL;
   const int lane = threadIdx.x & (RUA_WAVE - 1);
   const int64_t wave_id = ((int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x) >> 6;
-  const int64_t j0 = wave_id * (RUA_WAVE * FLAT_PER_LANE);
+  const int64_t j0 = wave_id * (RUA_WAVE * ENUM_PAIR * ENUM_NCH);
   if (j0 >= n) return;                                         // wave-uniform
   int64_t lo, W;
   coop_window([&](int64_t q) { return cat_off(L, q); }, L.B, j0, lane, lo, W);
-  const int64_t j = j0 + (int64_t)lane * FLAT_PER_LANE;
-  int64_t k, fk;
-  const bool ok = coop_lookup(W, lo, L.B, j < n ? j : n - 1, k, fk);
-  if (j >= n) return;
-  if (!ok) { k = search_cat(L, j); fk = cat_off(L, k); }
-  int64_t next = k + 1 < L.B ? cat_off(L, k + 1) : BIG;
-  int64_t len = L.kind == RUA_RIGHT ? seq_len(L, k) : 0;
-  int64_t row[FLAT_PER_LANE], kb[FLAT_PER_LANE], tt[FLAT_PER_LANE];
 #pragma unroll
-  for (int c = 0; c < FLAT_PER_LANE; ++c) {
-    const int64_t jj = j + c;
-    while (jj >= next) {                                       // the next sequence (zero-length ones are stepped over)
+  for (int c = 0; c < ENUM_NCH; ++c) {
+    const int64_t c0 = j0 + (int64_t)c * (RUA_WAVE * ENUM_PAIR);
+    if (c0 >= n) break;                                        // wave-uniform
+    const int64_t j = c0 + (int64_t)lane * ENUM_PAIR;
+    int64_t k, fk;
+    const bool ok = coop_lookup(W, lo, L.B, j < n ? j : n - 1, k, fk);
+    if (j >= n) continue;
+    if (!ok) { k = search_cat(L, j); fk = cat_off(L, k); }
+    int64_t len = L.kind == RUA_RIGHT ? seq_len(L, k) : 0;
+    const int64_t k0 = k, t0 = j - fk;
+    const int64_t r0 = L.kind == RUA_CAT ? j : L.kind == RUA_LEFT ? k * L.T_phys + t0 : k * L.T_phys + (L.T_log - len) + t0;
+    // the second token: the same sequence, or the next one that holds a token (zero-length ones are stepped over)
+    int64_t next = k + 1 < L.B ? cat_off(L, k + 1) : BIG;
+    while (j + 1 >= next) {
       ++k;
       fk = next;
       next = k + 1 < L.B ? cat_off(L, k + 1) : BIG;
       if (L.kind == RUA_RIGHT) len = seq_len(L, k);
     }
-    const int64_t t = jj - fk;
-    kb[c] = k;
-    tt[c] = t;
-    row[c] = L.kind == RUA_CAT ? jj : L.kind == RUA_LEFT ? k * L.T_phys + t : k * L.T_phys + (L.T_log - len) + t;
+    const int64_t t1 = j + 1 - fk;
+    const int64_t r1 = L.kind == RUA_CAT ? j + 1 : L.kind == RUA_LEFT ? k * L.T_phys + t1 : k * L.T_phys + (L.T_log - len) + t1;
+    if (bp) store2(bp, j, n, k0, k);
+    if (tp) store2(tp, j, n, t0, t1);
+    if (flat) store2(flat, j, n, r0, r1);
   }
-  if (bp) store4(bp, j, n, kb);
-  if (tp) store4(tp, j, n, tt);
-  if (flat) store4(flat, j, n, row);
 }
 
-// P.ptr(): tokens in storage order, (sorted[rank], t) — layout/pack.py:23-27 — the same way: a lane owns four
-// consecutive storage rows, looks the first one's time step up with its wave and walks along boff
+// P.ptr(): tokens in storage order, (sorted[rank], t) — layout/pack.py:23-27 — the same way
 __global__ __launch_bounds__(RUA_BLOCK) void enum_pack_kernel(rua_layout L, int64_t n, int64_t* __restrict__ bp,
                                                               int64_t* __restrict__ tp) {
   constexpr int64_t BIG = 0x7fffffffffffffffLL;
   const int lane = threadIdx.x & (RUA_WAVE - 1);
   const int64_t wave_id = ((int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x) >> 6;
-  const int64_t j0 = wave_id * (RUA_WAVE * FLAT_PER_LANE);
+  const int64_t j0 = wave_id * (RUA_WAVE * ENUM_PAIR * ENUM_NCH);
   if (j0 >= n) return;                                         // wave-uniform
   int64_t lo, W;
   coop_window([&](int64_t q) { return L.boff[q]; }, L.T, j0, lane, lo, W);
-  const int64_t j = j0 + (int64_t)lane * FLAT_PER_LANE;
-  int64_t t, bt;
-  const bool ok = coop_lookup(W, lo, L.T, j < n ? j : n - 1, t, bt);
-  if (j >= n) return;
-  if (!ok) { t = search_boff(L.boff, L.T, j); bt = L.boff[t]; }
-  int64_t next = t + 1 < L.T ? L.boff[t + 1] : BIG;
-  int64_t kb[FLAT_PER_LANE], tt[FLAT_PER_LANE];
 #pragma unroll
-  for (int c = 0; c < FLAT_PER_LANE; ++c) {
-    const int64_t jj = j + c;
-    while (jj >= next) {
+  for (int c = 0; c < ENUM_NCH; ++c) {
+    const int64_t c0 = j0 + (int64_t)c * (RUA_WAVE * ENUM_PAIR);
+    if (c0 >= n) break;                                        // wave-uniform
+    const int64_t j = c0 + (int64_t)lane * ENUM_PAIR;
+    int64_t t, bt;
+    const bool ok = coop_lookup(W, lo, L.T, j < n ? j : n - 1, t, bt);
+    if (j >= n) continue;
+    if (!ok) { t = search_boff(L.boff, L.T, j); bt = L.boff[t]; }
+    int64_t r = j - bt;
+    if (r < 0 || r >= L.B) r = 0;              // a token count that does not match batch_sizes must not index out of range
+    const int64_t b0 = L.sorted ? L.sorted[r] : r, t0 = t;
+    int64_t next = t + 1 < L.T ? L.boff[t + 1] : BIG;
+    while (j + 1 >= next) {
       ++t;
       bt = next;
       next = t + 1 < L.T ? L.boff[t + 1] : BIG;
     }
-    int64_t r = jj - bt;
-    if (r < 0 || r >= L.B) r = 0;              // a token count that does not match batch_sizes must not index out of range
-    kb[c] = L.sorted ? L.sorted[r] : r;
-    tt[c] = t;
+    r = j + 1 - bt;
+    if (r < 0 || r >= L.B) r = 0;
+    const int64_t b1 = L.sorted ? L.sorted[r] : r;
+    if (bp) store2(bp, j, n, b0, b1);
+    if (tp) store2(tp, j, n, t0, t);
   }
-  if (bp) store4(bp, j, n, kb);
-  if (tp) store4(tp, j, n, tt);
 }
 
 // ------------------------------------------------------------------ masks
@@ -511,14 +516,14 @@ int rua_enum_rows(const rua_layout* lay, int64_t n_tokens, int64_t* batch_ptr, i
   }
   if (n_tokens == 0) return 0;
   if (lay->kind == RUA_PACK && (batch_ptr || token_ptr) && !flat) {      // P.ptr()
-    const int64_t per_block = (int64_t)RUA_BLOCK * FLAT_PER_LANE;
+    const int64_t per_block = (int64_t)RUA_BLOCK * ENUM_PAIR * ENUM_NCH;
     hipLaunchKernelGGL(enum_pack_kernel, dim3((unsigned)((n_tokens + per_block - 1) / per_block)), dim3(RUA_BLOCK), 0,
                        (hipStream_t)stream, *lay, n_tokens, batch_ptr, token_ptr);
     return (int)hipGetLastError();
   }
-  // the batch-major layouts with ragged lengths: four consecutive tokens per lane (C.idx() alone stays an iota)
+  // the batch-major layouts with ragged lengths (C.idx() alone stays an iota)
   if (lay->kind != RUA_PACK && lay->off && lay->lens && (batch_ptr || token_ptr || lay->kind != RUA_CAT)) {
-    const int64_t per_block = (int64_t)RUA_BLOCK * FLAT_PER_LANE;
+    const int64_t per_block = (int64_t)RUA_BLOCK * ENUM_PAIR * ENUM_NCH;
     hipLaunchKernelGGL(enum_flat_kernel, dim3((unsigned)((n_tokens + per_block - 1) / per_block)), dim3(RUA_BLOCK), 0,
                        (hipStream_t)stream, *lay, n_tokens, batch_ptr, token_ptr, flat);
     return (int)hipGetLastError();
