@@ -10,8 +10,6 @@ One step = one pass of the hot path over one batch already resident in HBM:
     out = reduce_sum(p)                 # segmented reduce over the PackedSequence -> [B, H]
     (N > 1: one RCCL all-gather of `out`; sequences are sharded, payload never crosses xGMI)
 Nothing is cached between steps: every step uploads the lengths again, re-sorts, re-scans, re-moves.
-The library runs with its defaults: output placement (torchrua_amd/_placement.py) is opt-in and OFF
-here unless RUA_PLACEMENT=1 is exported; the line says which (`placement.enabled`).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the pack row mover:
 algorithmic bytes 2*N*H*e + 8*(3B+T)), timed with HIP events on the launch stream
@@ -307,7 +305,6 @@ def main():
             torch.cuda.synchronize(dev)
 
     p = out = None
-    from torchrua_amd import _placement
     for _ in range(max(args.warmup, 2)):   # at least 2: the loop keeps the previous PackedSequence alive, so the
                                            # allocator needs two steps to own both 17 GB buffers
         p, out = step()      # keep the previous result alive exactly like the timed loop does, so the caching
@@ -447,9 +444,6 @@ def main():
             'reduce_kernel': {'kernel': 'seg_reduce_kernel<bf16,8,SUM,NT> (over P)', 'avg_ms': round(red_ms, 4),
                               'achieved': round(reduce_bytes / (red_ms * 1e-3) / 1e9, 1), 'unit': 'GB/s',
                               'frac': round(reduce_bytes / (red_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-            'placement': {'enabled': bool(_placement.ENABLED), 'stats': dict(_placement.stats),
-                          'note': 'opt-in (RUA_PLACEMENT=1): choose among CACHED output blocks by their measured move '
-                                  'time; off by default, never allocates on its own'},
             'pipeline': {'algorithmic_bytes': pack_bytes + reduce_bytes,
                          'kernel_ms': round(move_ms + red_ms, 4),
                          'frac_of_hbm_peak_kernels': round((pack_bytes + reduce_bytes) / ((move_ms + red_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

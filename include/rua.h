@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RUA_ABI_VERSION 3
+#define RUA_ABI_VERSION 4
 
 /* argument errors (negative so they cannot collide with hipError_t) */
 #define RUA_EINVAL   (-1)  /* bad enum / null pointer / negative size      */
@@ -146,7 +146,16 @@ int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32_t tmap, in
                   const void* fill16, int64_t pad_row, int32_t flags, void* stream);
 
 /* ---- reductions ------------------------------------------------------------ */
-enum rua_dtype { RUA_F32 = 0, RUA_BF16 = 1, RUA_F16 = 2, RUA_F64 = 3 };
+enum rua_dtype {
+  RUA_F32 = 0, RUA_BF16 = 1, RUA_F16 = 2, RUA_F64 = 3,
+  /* integer element types (ABI 4): rua_segment_reduce only, over a CAT layout with or without `perm` — the
+   * scatter_* of reduce.py:6-23 on integer tensors, which the reference hands to torch.index_reduce / index_add like
+   * any other dtype.  SUM / MEAN / MAX / MIN / PROD in the element type itself, bit-exact: sums and products wrap,
+   * MEAN is ATen's floor division by a count held in the same type (so the count wraps too); `extreme`, `ws`,
+   * `ties_out` and `empty_bits` are ignored (empty sequences yield the op's identity unless include_self == 2),
+   * LOGSUMEXP is RUA_EINVAL. */
+  RUA_I64 = 4, RUA_I32 = 5, RUA_I16 = 6, RUA_I8 = 7, RUA_U8 = 8
+};
 #define RUA_TIES_FINAL 2   /* rua_segment_reduce_backward's include_self: see there */
 #define RUA_BWD_FILL_PADDING 0x100  /* OR-ed into that include_self: also write zeros into the rows of a padded
                                       layout that hold no token (grad_in then needs no pre-zeroing)              */

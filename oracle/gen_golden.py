@@ -7,6 +7,7 @@ never reference source.  Run here (the reference never travels to the GPU box):
 Outputs:
     tests/golden/small.npz     every hot-path function on tiny + seeded random cases
     tests/golden/sha.json      SHA-256 of the reference's outputs on reduced BASELINE.json configs
+    tests/golden/r4.npz        (--round4) scatter_* on integer tensors; names.json: dir() of the reference's modules
     tests/golden/r3.npz        (--round3) compose, Z- / tensor-keyed indexing, split, and gradients of every op under
                                one fixed cotangent, from the reference's CPU autograd
 """
@@ -756,8 +757,97 @@ def round3():
         print('  reference raised:', line)
 
 
+def scatter_int_case(case, S, M, H, dtype, seed, lo, hi, dims=False):
+    """scatter_{sum,max,min,prod,mean} on INTEGER tensors (reduce.py:6-23 hand any dtype to torch.index_reduce /
+    index_add): both include_self values, buckets nobody names, repeated values (ties), negatives where the type has
+    them, sums / products / counts that wrap.  `dims`: also along another dimension than 0."""
+    import warnings
+    g = torch.Generator().manual_seed(seed)
+    shape_t, shape_s = ((S,), (M,)) if H == 0 else ((S, H), (M, H))
+    index = torch.randint(0, S, (M,), generator=g)
+    if S > 3:
+        index[index == 1] = 0                       # bucket 1 stays empty; bucket 0 doubles
+    tensor = torch.randint(lo, hi + 1, shape_t, generator=g).to(dtype)
+    source = torch.randint(lo, hi + 1, shape_s, generator=g).to(dtype)
+    put(case, 'index', index)
+    put(case, 'tensor', tensor)
+    put(case, 'source', source)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for name in ('max', 'min', 'sum', 'mean', 'prod'):
+            for inc in (False, True):
+                put(case, f'scatter_{name}.{int(inc)}',
+                    getattr(ref, f'scatter_{name}')(tensor, index, source, include_self=inc))
+        if dims and H:
+            tt, ss = tensor.t().contiguous(), source.t().contiguous()       # [H, S] reduced along its last dimension
+            put(case, 'last.tensor', tt)
+            put(case, 'last.source', ss)
+            for name in ('max', 'min', 'sum', 'mean', 'prod'):
+                for inc in (False, True):
+                    put(case, f'last.scatter_{name}.{int(inc)}',
+                        getattr(ref, f'scatter_{name}')(tt, index, ss, include_self=inc, dim=-1))
+
+
+def reference_names():
+    """{module: {name: kind}} for the reference package and every submodule: what `dir()` shows a user
+    (torchrua/__init__.py:1-8 star-imports every helper).  Names only — the drop-in namespace is held to this list."""
+    import importlib
+    import pkgutil
+    import types
+
+    def kind(v):
+        if isinstance(v, types.ModuleType):
+            return 'module'
+        if isinstance(v, type):
+            return 'class'
+        if callable(v):
+            return 'callable'
+        return 'other'
+
+    out = {}
+    mods = ['torchrua'] + [m.name for m in pkgutil.walk_packages(ref.__path__, 'torchrua.')]
+    for name in mods:
+        mod = importlib.import_module(name)
+        out[name] = {n: kind(getattr(mod, n)) for n in sorted(dir(mod)) if not n.startswith('__')}
+    return out
+
+
+def round4():
+    """tests/golden/r4.npz + names.json (earlier files stay byte-for-byte): VERDICT r3 — integer scatter_* and the
+    reference's module-level names."""
+    global store
+    store = {}
+    I = torch
+    scatter_int_case('scatter_int.i64', 9, 60, 3, I.int64, seed=600, lo=-50, hi=50, dims=True)
+    scatter_int_case('scatter_int.i64.vec2', 6, 40, 2, I.int64, seed=601, lo=-9, hi=9)           # 16-byte rows
+    scatter_int_case('scatter_int.i64.flat', 11, 90, 0, I.int64, seed=602, lo=-3, hi=3)          # 1-d: counting tokens
+    scatter_int_case('scatter_int.i64.big', 5, 70, 4, I.int64, seed=603, lo=-(2 ** 40), hi=2 ** 40)   # products wrap
+    scatter_int_case('scatter_int.i32', 8, 50, 5, I.int32, seed=610, lo=-2000, hi=2000, dims=True)
+    scatter_int_case('scatter_int.i32.vec4', 7, 64, 8, I.int32, seed=611, lo=-(2 ** 30), hi=2 ** 30)  # sums wrap
+    scatter_int_case('scatter_int.i16', 10, 80, 7, I.int16, seed=620, lo=-300, hi=300)
+    scatter_int_case('scatter_int.i16.vec8', 4, 33, 16, I.int16, seed=621, lo=-32768, hi=32767)
+    scatter_int_case('scatter_int.i8', 6, 70, 3, I.int8, seed=630, lo=-128, hi=127, dims=True)
+    scatter_int_case('scatter_int.i8.vec16', 5, 45, 32, I.int8, seed=631, lo=-5, hi=5)
+    scatter_int_case('scatter_int.i8.count_wraps', 3, 900, 2, I.int8, seed=632, lo=-4, hi=4)     # > 127 and > 255 per bucket
+    scatter_int_case('scatter_int.u8', 6, 70, 3, I.uint8, seed=640, lo=0, hi=255, dims=True)
+    scatter_int_case('scatter_int.u8.count_wraps', 2, 600, 16, I.uint8, seed=641, lo=0, hi=3)
+    scatter_int_case('scatter_int.i64.wide', 300, 5000, 33, I.int64, seed=650, lo=-1000, hi=1000)
+    scatter_int_case('scatter_int.i32.one_bucket', 1, 2000, 4, I.int32, seed=651, lo=-7, hi=7)
+    np.savez_compressed(os.path.join(OUT, 'r4.npz'), **store)
+    with open(os.path.join(OUT, 'names.json'), 'w') as f:
+        json.dump(reference_names(), f, indent=0, sort_keys=True)
+    meta_path = os.path.join(OUT, 'META.json')
+    meta = json.load(open(meta_path))
+    meta['r4_n_arrays'] = len(store)
+    with open(meta_path, 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print('wrote', len(store), 'round-4 arrays;', os.path.getsize(os.path.join(OUT, 'r4.npz')), 'bytes')
+
+
 if __name__ == '__main__':
-    if '--round3' in sys.argv:
+    if '--round4' in sys.argv:
+        round4()
+    elif '--round3' in sys.argv:
         round3()
     elif '--foreign' in sys.argv:
         foreign()
@@ -768,3 +858,4 @@ if __name__ == '__main__':
         extra()
         foreign()
         round3()
+        round4()

@@ -453,7 +453,29 @@ def segment_last(data, lens):
     return last(C(data, lens))
 
 
+_INT_KINDS = {np.dtype(np.int64): 0, np.dtype(np.int32): 1, np.dtype(np.int16): 2, np.dtype(np.int8): 3,
+              np.dtype(np.uint8): 4}
+
+
+def _index_reduce_int(tensor, index, source, op: int, include_self: bool):
+    """reduce.py:6-23 on integer tensors: ATen's own steps in the tensor's integer type (rua_oracle.c)."""
+    tensor = np.array(tensor, order='C', copy=True)
+    kind = _INT_KINDS[tensor.dtype]
+    source = np.ascontiguousarray(source, dtype=tensor.dtype)
+    index = _i64(index)
+    S = tensor.shape[0]
+    H = int(np.prod(tensor.shape[1:], dtype=np.int64))
+    assert index.size == 0 or (index.min() >= 0 and index.max() < S), 'index out of range'
+    counts = np.empty(S, I64)
+    lib().orc_index_reduce_int(_p(tensor), ctypes.c_int64(S), ctypes.c_int64(H), _p(index), _p(source),
+                               ctypes.c_int64(index.size), ctypes.c_int(op), ctypes.c_int(int(include_self)),
+                               ctypes.c_int(kind), _p(counts))
+    return tensor
+
+
 def _index_reduce(tensor, index, source, op: int, include_self: bool):
+    if np.asarray(tensor).dtype in _INT_KINDS:
+        return _index_reduce_int(tensor, index, source, op, include_self)
     tensor = np.array(tensor, dtype=np.float32, order='C', copy=True)
     source = np.ascontiguousarray(source, dtype=np.float32)
     index = _i64(index)
@@ -478,7 +500,8 @@ def scatter_min(tensor, index, source, include_self=False):
 
 def scatter_sum(tensor, index, source, include_self=False):
     """reduce.py:14-15 (index_add into tensor, or into zeros)."""
-    base = tensor if include_self else np.zeros_like(np.asarray(tensor, dtype=np.float32))
+    t = np.asarray(tensor)
+    base = tensor if include_self else np.zeros_like(t if t.dtype in _INT_KINDS else np.asarray(tensor, dtype=np.float32))
     return _index_reduce(base, index, source, 0, True)
 
 

@@ -28,11 +28,6 @@ def timeit(name, fn, nbytes, iters=10):
     charged ~8 us of launch latency that a running pipeline never sees; the single-call latency is printed beside it."""
     fn()
     torch.cuda.synchronize()
-    from torchrua_amd import _placement
-    if _placement.ENABLED and nbytes >= 2 * _placement.MIN_BYTES:
-        for _ in range(9):          # outputs of 2 GiB and more: let the placement settle (DESIGN.md §4.1a), untimed
-            fn()
-            torch.cuda.synchronize()
 
     def once(reps):
         e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)

@@ -22,7 +22,7 @@ def golden():
     global _small
     if _small is None:
         out = {}
-        for fname in ('small.npz', 'extra.npz', 'foreign.npz', 'r3.npz'):   # oracle/gen_golden.py: main / extra / foreign / round3
+        for fname in ('small.npz', 'extra.npz', 'foreign.npz', 'r3.npz', 'r4.npz'):   # oracle/gen_golden.py: main / extra / foreign / round3 / round4
             z = np.load(os.path.join(GOLDEN, fname))
             for key in z.files:
                 case, name = key.split('/', 1)

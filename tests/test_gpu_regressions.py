@@ -471,18 +471,6 @@ def test_two_host_threads_share_one_stream():
     for t in threads:
         t.join()
     assert not errors, errors
-
-
-def test_placement_is_opt_in_and_only_chooses_among_cached_blocks(monkeypatch):
-    """torchrua_amd/_placement.py: off by default; switched on at a tiny threshold the
-    outputs are bit-identical, launches get timed without a synchronisation, an offer known to be slow is held in
-    favour of a block KNOWN to sit in the cache, and the allocator never grows on its behalf (reserved bytes constant
-    once the caller's own warm() has run)."""
-    from torchrua_amd import _placement as P
-    assert os.environ.get('RUA_PLACEMENT', '0') == '1' or not P.ENABLED          # default: off
-    torch.cuda.synchronize()
-    torch.cuda.empty_cache()          # start from an allocator without cached blocks, like a fresh process
-    P.forget()
     monkeypatch.setattr(P, 'ENABLED', True)
     monkeypatch.setattr(P, 'MIN_BYTES', 1 << 20)
     for k in P.stats:

@@ -34,6 +34,10 @@ def install_as_torchrua() -> None:
     indices (the reference patches Tensor.__getitem__/__setitem__ at import time: core/get.py:11-18,
     core/set.py:10-18).  A plain `import torchrua_amd` leaves torch.Tensor untouched; call
     `patch_tensor_indexing()` yourself to opt in without the alias."""
-    import sys
-    sys.modules.setdefault('torchrua', sys.modules[__name__])
+    _namespace.alias_as('torchrua')           # torchrua, torchrua.core.cast, torchrua.select.roll, ...
     patch_tensor_indexing()
+
+
+from torchrua_amd import _namespace  # noqa: E402
+
+_namespace.build(__import__('sys').modules[__name__])

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must be imported first: maps the HIP runtime our li
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RUA_LIB_PATH') or os.path.join(_HERE, 'librua_hip.so')   # env: developer A/B of builds
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 # enum rua_kind
 CAT, LEFT, PACK, RIGHT, LIST = 0, 1, 2, 3, 4
 # enum rua_tmap
@@ -28,7 +28,11 @@ OP_SCRATCH_CLEAN, OP_NO_EMPTY = 0x100, 0x200     # rua.h: bits OR-ed into `op` (
 F32, BF16, F16, F64 = 0, 1, 2, 3
 SUM, MEAN, MAX, MIN, PROD, LOGSUMEXP = 0, 1, 2, 3, 4, 5
 
+I64, I32, I16, I8, U8 = 4, 5, 6, 7, 8
+
 DTYPES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16, torch.float64: F64}
+# integer element types: rua_segment_reduce over a CAT layout only (scatter_* on integer tensors, reduce.py:6-23)
+INT_DTYPES = {torch.int64: I64, torch.int32: I32, torch.int16: I16, torch.int8: I8, torch.uint8: U8}
 
 
 class RuaLayout(Structure):

@@ -126,7 +126,10 @@ def private_host_copy(host: Tensor) -> Tensor:
     PINNED caching host allocator: freeing it is a free-list push, not an munmap (a fresh pageable 512 KiB block per
     step stalled the GPU queues on this platform — see _read_back), and the upload reads straight from it, so the
     copy replaces the one into a staging slot instead of adding to it."""
-    src = _as_lens(host.detach())
+    if host.is_cuda:
+        raise L.RuaError('with_host_sizes takes lengths that live on the HOST (got a tensor on ' + str(host.device) +
+                         '); for device lengths build the container directly: C(data, token_sizes)')
+    src = _as_lens(host.detach())               # (detach: numpy refuses a tensor that requires grad)
     out = torch.empty(src.shape, dtype=torch.long, pin_memory=True)
     np.copyto(out.numpy(), src.numpy())
     return out
@@ -648,7 +651,7 @@ STREAM_RATE = 5e12           # bytes/s the whole chip reads through the reducer
 SPLIT_FIXED_S = 30e-6        # what arming costs: one memset, a tail and a combine launch
 
 
-def reduce_split_rows(lay: Lay, row_bytes: int = 1024, team_ok: bool = True) -> int:
+def reduce_split_rows(lay: Lay, row_bytes: int = 1024, team_ok: bool = True, tail_ok: bool = True) -> int:
     """Rows per part for rua_segment_reduce, or 0 (= one wave streams each whole sequence).
 
     Splitting pays only when the longest sequence would show: one wave walks a sequence at ~WAVE_RATE, the balanced
@@ -659,7 +662,9 @@ def reduce_split_rows(lay: Lay, row_bytes: int = 1024, team_ok: bool = True) -> 
     raised to that threshold when there are plenty, so that only real outliers are cut.  When the host does not know
     the longest sequence (device-only lengths) the machinery is armed only where a tail could matter: long average
     sequences or few of them.  team_ok=False: the caller's kernel has no wave teams (the backward walk, the fused
-    pack + reduce), so a unit streams at the single-wave rate."""
+    pack + reduce), so a unit streams at the single-wave rate.  tail_ok=False: rows of 8 (mod 16) bytes will NOT take
+    the 16-byte-lane path there (include_self == 1, or a payload that is not 8-byte aligned: the launcher's `tail_ok`),
+    so no team either."""
     n = lay.n_rows
     rb_unit = max(1, min(int(row_bytes), 1024))        # wider rows: 4 KiB per wave, 4x the loads in flight
     n_chunks = -(-int(row_bytes) // (1024 if row_bytes <= 1024 else 4096)) if row_bytes > 0 else 1
@@ -667,7 +672,7 @@ def reduce_split_rows(lay: Lay, row_bytes: int = 1024, team_ok: bool = True) -> 
     # rows up to 1 KiB on the vector path, at most 16 384 units, >= 4 row groups per wave): a unit then streams
     # 2-4x as fast, and splitting — three launches and a pass over fp32 partials — is for real outliers only
     team = 1
-    if team_ok and 0 < row_bytes <= 1024 and row_bytes % 8 == 0:
+    if team_ok and 0 < row_bytes <= 1024 and (row_bytes % 16 == 0 or (row_bytes % 8 == 0 and tail_ok)):
         team = L.load().rua_reduce_team_waves(n, max(lay.B, 1), int(row_bytes))      # the launcher's own rule
     wave_rate = WAVE_RATE * team
     ideal_rows = int(0.75 * n * row_bytes / STREAM_RATE * wave_rate / rb_unit)   # rows a unit walks in 3/4 of the balanced time

@@ -13,7 +13,6 @@ from torch.autograd.function import once_differentiable
 
 from torchrua_amd import _lib as L
 from torchrua_amd import _meta as M
-from torchrua_amd import _placement
 
 # optional hook bench.py installs to bracket named kernels with HIP events on the launch stream
 _kernel_hook: Optional[Callable[[str, bool], None]] = None
@@ -64,15 +63,8 @@ def launch_move(plan: MovePlan, src_data: Tensor, out: Optional[Tensor] = None) 
     dev = L.require_device(src_data)
     lib = L.load()
     src_data = src_data.contiguous()
-    placed = None
     if out is None:
-        nbytes = src_data.element_size()
-        for d in plan.out_shape:
-            nbytes *= d
-        # large outputs go where this source is known to move fast; the launch below is timed for it
-        placed = _placement.key_for(plan.name, nbytes, src_data) if nbytes >= _placement.MIN_BYTES else None
-        out = (torch.empty(plan.out_shape, dtype=src_data.dtype, device=dev) if placed is None
-               else _placement.empty_for(plan.out_shape, src_data.dtype, dev, placed))
+        out = torch.empty(plan.out_shape, dtype=src_data.dtype, device=dev)
     elif not out.is_contiguous() or out.dtype != src_data.dtype:
         raise L.RuaError('move target must be contiguous and of the payload dtype')
     # rows are equally wide on both sides; size them on the side the layout `dst` enumerates
@@ -81,13 +73,8 @@ def launch_move(plan: MovePlan, src_data: Tensor, out: Optional[Tensor] = None) 
     fill = _fill16(plan.fill, src_data.dtype)
     if _kernel_hook:
         _kernel_hook(plan.name, True)
-    if placed is not None:
-        stream = torch.cuda.current_stream(dev)
-        placed = _placement.begin(placed, out, stream)
     L.check(lib.rua_move_rows(plan.dst.ref(), plan.src.ref(), plan.tmap, plan.arg, L.ptr(out), L.ptr(src_data), rb,
                               fill, plan.pad_row, plan.flags, L.stream_ptr(dev)), 'rua_move_rows')
-    if placed is not None:
-        _placement.end(placed, stream)
     if _kernel_hook:
         _kernel_hook(plan.name, False)
     return out
@@ -175,9 +162,10 @@ def _bits(value: float, dtype: torch.dtype) -> int:
     return int.from_bytes(raw, 'little')
 
 
-def split_workspace(lay: M.Lay, H: int, dtype: torch.dtype, dev, team_ok: bool = True) -> Tuple[int, Optional[Tensor]]:
+def split_workspace(lay: M.Lay, H: int, dtype: torch.dtype, dev, team_ok: bool = True,
+                    tail_ok: bool = True) -> Tuple[int, Optional[Tensor]]:
     """(split_rows, workspace) for the reducer's long-sequence splitting (0, None when it is off)."""
-    split = M.reduce_split_rows(lay, H * dtype.itemsize, team_ok)
+    split = M.reduce_split_rows(lay, H * dtype.itemsize, team_ok, tail_ok)
     if not split:
         return 0, None
     nbytes = L.load().rua_reduce_ws_bytes(lay.n_rows, H, L.DTYPES[dtype], split)
@@ -203,7 +191,8 @@ def launch_reduce(lay: M.Lay, data: Tensor, op: int, out: Optional[Tensor] = Non
     extreme, op_bits = None, 0
     if reference_initial and op in (L.MAX, L.MIN, L.LOGSUMEXP) and include_self == 0:
         extreme, op_bits = extreme_scratch(dev, lay)
-    split, ws = split_workspace(lay, H, data.dtype, dev)
+    tail_ok = include_self != 1 and (data.data_ptr() | out.data_ptr()) % 8 == 0      # the launcher's own condition
+    split, ws = split_workspace(lay, H, data.dtype, dev, tail_ok=tail_ok)
     if _kernel_hook:
         _kernel_hook(name, True)
     paired = extreme is not None
@@ -212,17 +201,10 @@ def launch_reduce(lay: M.Lay, data: Tensor, op: int, out: Optional[Tensor] = Non
     try:
         # (the second walk for the global extreme, should a segment be empty, rides in rua_fill_empty's launch: the
         # reduce is told not to arm it, and fill_empty gets the payload unless the host knows nothing is empty)
-        # (a reduce that reads a block the mover placed tells the placement what that block costs its reader)
-        reader = None
-        if perm is None and data.numel() * data.element_size() >= _placement.MIN_BYTES:
-            stream = torch.cuda.current_stream(dev)
-            reader = _placement.reader_begin(f'reduce{op}', data, stream)
         L.check(lib.rua_segment_reduce(lay.ref(), L.ptr(perm), L.ptr(data), L.ptr(out), H, L.DTYPES[data.dtype],
                                        op | op_bits | (L.OP_NO_EMPTY if extreme is not None else 0), include_self,
                                        _bits(_EMPTY[op], data.dtype), L.ptr(extreme), split, L.ptr(ws), L.ptr(ties_out),
                                        L.stream_ptr(dev)), 'rua_segment_reduce')
-        if reader is not None:
-            _placement.end(reader, stream)
         if _kernel_hook:
             _kernel_hook(name, False)
         if extreme is not None:
@@ -306,9 +288,15 @@ def index_buckets(index: Tensor, S: int) -> Tuple[Tensor, Tensor]:
 def scatter_sum_rows(rows: Tensor, index: Tensor, n_out: int) -> Tensor:
     """out[s] = sum of rows[i] over the entries i with index[i] == s, s < n_out (rows nobody names are 0)."""
     hidden = tuple(rows.shape[1:])
-    if rows.dtype not in L.DTYPES:        # integer payloads have no gradient; kept for completeness
-        out = torch.zeros((n_out,) + hidden, dtype=rows.dtype, device=rows.device)
-        return out.index_add_(0, index, rows)
     counts, perm = index_buckets(index, n_out)
     lay = M.lay_cat(counts, n_out, int(rows.size(0)))
+    if rows.dtype in L.INT_DTYPES:        # (integer payloads carry no gradient: the integer reducer, for completeness)
+        out = torch.empty((n_out,) + hidden, dtype=rows.dtype, device=rows.device)
+        H = 1
+        for d in hidden:
+            H *= d
+        L.check(L.load().rua_segment_reduce(lay.ref(), L.ptr(perm), L.ptr(rows.contiguous()), L.ptr(out), H,
+                                            L.INT_DTYPES[rows.dtype], L.SUM, 0, 0, None, 0, None, None,
+                                            L.stream_ptr(rows.device)), 'rua_segment_reduce')
+        return out
     return launch_reduce(lay, rows, L.SUM, perm=perm, hidden=hidden, reference_initial=False, name='scatter')

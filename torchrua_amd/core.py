@@ -336,26 +336,30 @@ for _cls in (C, L, P, R):
     _cls.__setitem__ = _setitem(_cls)
 
 
+def tensor_getitem(self: T, key):
+    """core/get.py:11-18: `tensor[Z]` re-wraps a container of row indices; any other key is torch's own indexing.
+    Payload on a HIP device goes through the row mover, like container[Z]."""
+    if isinstance(key, (C, L, P, R)):
+        if self.is_cuda and self.dim() >= 1:
+            return key._replace(data=_gather_flat(self, key.data))
+        return key._replace(data=_tensor_getitem(self, key.data))
+    return _tensor_getitem(self, key)
+
+
+def tensor_setitem(self: T, key, value) -> None:
+    """core/set.py:10-18: `tensor[Z] = value` scatters through a container of row indices."""
+    if isinstance(key, (C, L, P, R)):
+        if self.is_cuda and self.dim() >= 1:
+            return _scatter_flat(self, key.data, value)
+        return _tensor_setitem(self, key.data, value)
+    return _tensor_setitem(self, key, value)
+
+
 def patch_tensor_indexing() -> None:
     """Twin of the reference's import-time patch of Tensor.__getitem__/__setitem__ (core/get.py:11-18,
     core/set.py:10-18): lets `tensor[Z]` re-wrap a container of row indices and `tensor[Z] = value` scatter through
     one.  `install_as_torchrua()` applies it (importing the reference does); a plain `import torchrua_amd` does not,
-    so that ordinary tensor indexing in the process is left untouched.  Payload on a HIP device goes through the
-    row mover, like container[Z]."""
-    def tensor_getitem(self: T, key):
-        if isinstance(key, (C, L, P, R)):
-            if self.is_cuda and self.dim() >= 1:
-                return key._replace(data=_gather_flat(self, key.data))
-            return key._replace(data=_tensor_getitem(self, key.data))
-        return _tensor_getitem(self, key)
-
-    def tensor_setitem(self: T, key, value) -> None:
-        if isinstance(key, (C, L, P, R)):
-            if self.is_cuda and self.dim() >= 1:
-                return _scatter_flat(self, key.data, value)
-            return _tensor_setitem(self, key.data, value)
-        return _tensor_setitem(self, key, value)
-
+    so that ordinary tensor indexing in the process is left untouched."""
     Tensor.__getitem__ = tensor_getitem
     Tensor.__setitem__ = tensor_setitem
 

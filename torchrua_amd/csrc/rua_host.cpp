@@ -323,7 +323,11 @@ class Pool {
             std::this_thread::yield();              // a worker: the caller is about to clear active_
             continue;
           }
-          while (queued_.load(std::memory_order_acquire) == 0 && pending_.load(std::memory_order_acquire) != 0) cpu_relax();
+          // (bounded: under a CPU quota or with oversubscribed ranks the spinners could starve the one thread that
+          // holds the only task — after ~4 000 pauses, a few tens of microseconds, they give their core away instead)
+          for (int spins = 0; queued_.load(std::memory_order_acquire) == 0 && pending_.load(std::memory_order_acquire) != 0; ++spins) {
+            if (spins < 4096) cpu_relax(); else std::this_thread::yield();
+          }
           continue;
         }
         t = q_.front();

@@ -289,9 +289,10 @@ __global__ __launch_bounds__(RUA_BLOCK) void enum_rows_kernel(rua_layout L, int6
 }
 
 // L.idx() / R.idx() (flat storage row of every token of a padded batch, layout/left.py:73-77, right.py:74-79) and the
-// flat-only enumeration of a CattedSequence: a lane owns EIGHT CONSECUTIVE tokens — one cooperative lookup for the
-// first of them, then it walks along the offsets (consecutive tokens share a sequence until the next boundary) — and
-// writes them as 16-byte stores.  enum_rows_kernel resolved every token by itself: 60 us for the 136 MB of the
+// flat-only enumeration of a CattedSequence: a lane owns TWO CONSECUTIVE tokens (ENUM_PAIR) of each of its wave's four
+// chunks — one cooperative lookup for the first, then a step along the offsets (consecutive tokens share a sequence
+// until the next boundary) — and writes the pair as ONE 16-byte store, the lanes of a wave side by side (four and
+// eight tokens per lane were measured and dropped: they stride the stores).  enum_rows_kernel resolved every token by itself: 60 us for the 136 MB of the
 // north-star batch, a quarter of the rate of a plain store stream.
 constexpr int ENUM_PAIR = 2;        // consecutive tokens per lane and chunk: one 16-byte store per output
 constexpr int ENUM_NCH = 4;         // chunks of 64 * ENUM_PAIR tokens one wave enumerates from ONE search + window

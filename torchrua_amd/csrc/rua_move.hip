@@ -559,7 +559,9 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
   if (tile_rows > MOVE_BLOCK) tile_rows = MOVE_BLOCK;
   // rows that are a multiple of 8 but not of 16 bytes: 16-byte lanes at 8-byte-aligned addresses + an 8-byte tail
   // (RUA_MOVE_NO_TAIL8, a developer flag, keeps the 8-byte lanes for A/B runs)
-  const bool tail8 = vec == 8 && row_bytes >= 24 && !(flags & RUA_MOVE_NO_TAIL8);
+  // Only rows that really END in an 8-byte piece: vec == 8 also comes from a base pointer that is only 8-byte aligned
+  // under rows of a multiple of 16 bytes (a view at a storage offset), and those have no tail — they keep 8-byte lanes.
+  const bool tail8 = vec == 8 && (row_bytes & 15) == 8 && row_bytes >= 24 && !(flags & RUA_MOVE_NO_TAIL8);
   if (vec != 16) tile_rows = tile_rows <= 16 ? 16 : tile_rows <= 64 ? 64 : MOVE_TILE;
   const int64_t nr = dst->n_rows;
   bool xcd_span = (nr + tile_rows - 1) / tile_rows >= MOVE_SPAN_MIN_TILES;

@@ -25,6 +25,9 @@ __global__ void extreme_init_entry_kernel(unsigned long long* ext, int want_max_
                        const void* out, const void* gout, const void* aux, void* gself, int op, int inc);
 RUA_DECL(f32) RUA_DECL(bf16) RUA_DECL(f16) RUA_DECL(f64)
 #undef RUA_DECL
+// integer element types (rua_reduce_int.hip)
+int reduce_int(int dtype, int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data, void* out,
+               int64_t H, int include_self);
 }  // namespace rua
 
 using namespace rua;
@@ -113,6 +116,10 @@ int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* d
   op &= 0xff;
   if (ties && op != RUA_MAX && op != RUA_MIN) return RUA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  if (dtype >= RUA_I64 && dtype <= RUA_U8) {        // integer tensors: scatter_* only (reduce.py:6-23)
+    if (ties || lay->kind != RUA_CAT) return RUA_EINVAL;
+    return reduce_int(dtype, op, s, *lay, perm, data, out, H, include_self);
+  }
   if (extreme && !clean && (op == RUA_MAX || op == RUA_MIN || op == RUA_LOGSUMEXP)) {
     hipLaunchKernelGGL(extreme_init_entry_kernel, dim3(1), dim3(128), 0, s, (unsigned long long*)extreme,
                        op == RUA_MIN ? 1 : 0);

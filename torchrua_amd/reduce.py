@@ -203,8 +203,8 @@ def _scatter(tensor: T, index: T, source: T, op: int, include_self: bool, dim: i
         d = dim % nd
         out = _scatter(tensor.movedim(d, 0), index, source.movedim(d, 0), op, include_self, 0)
         return out.movedim(0, d)
-    if tensor.dtype not in K.DTYPES:
-        raise K.RuaError(f'reductions support {list(K.DTYPES)}; got {tensor.dtype}')
+    if tensor.dtype not in K.DTYPES and tensor.dtype not in K.INT_DTYPES:
+        raise K.RuaError(f'scatter_* supports {list(K.DTYPES) + list(K.INT_DTYPES)}; got {tensor.dtype}')
     # what torch.index_add / index_reduce reject (reduce.py:6-31 inherit their checks): the kernel is launched with
     # the source's element type and the destination's row width, so a mismatch would write out of bounds
     if source.dtype != tensor.dtype:
@@ -217,7 +217,34 @@ def _scatter(tensor: T, index: T, source: T, op: int, include_self: bool, dim: i
                          f'(got {tuple(index.shape)} for {source.size(0)} rows)')
     if index.dtype not in (torch.long, torch.int32):
         raise K.RuaError(f'scatter_*: index must be int64 or int32 (got {index.dtype})')
+    if tensor.dtype in K.INT_DTYPES:
+        return _scatter_int(tensor, index, source, op, bool(include_self))
     return _Scatter.apply(tensor, index, source, op, bool(include_self))
+
+
+def _scatter_int(tensor: T, index: T, source: T, op: int, include_self: bool) -> T:
+    """scatter_* on integer tensors: the reference hands them to torch.index_reduce / index_add like any other dtype
+    (reduce.py:6-23).  Same buckets, an integer reducer (rua_reduce_int.hip): the element type's own wrapping sums and
+    products, and ATen's floor division by a count of that type for `mean`.  Bit-exact; integers carry no gradient."""
+    if op == K.LOGSUMEXP:
+        # reduce.py:26-31 on integers is a float computation (exp of a difference that wraps for unsigned types);
+        # torch.logsumexp itself takes floating tensors only
+        raise K.RuaError('scatter_logsumexp takes floating-point tensors (got ' + str(tensor.dtype) + ')')
+    S = tensor.size(0)
+    counts, perm = _buckets(index, S)
+    lay = M.lay_cat(counts, S, int(source.size(0)))
+    H = 1
+    for d in tensor.shape[1:]:
+        H *= d
+    if op == K.SUM and not include_self:
+        out, mode = torch.empty(tensor.shape, dtype=tensor.dtype, device=tensor.device), 0      # index_add into zeros
+    else:
+        out, mode = tensor.detach().clone(memory_format=torch.contiguous_format), (1 if include_self else 2)
+    source = source.detach().contiguous()
+    K.check(K.load().rua_segment_reduce(lay.ref(), K.ptr(perm), K.ptr(source), K.ptr(out), H, K.INT_DTYPES[tensor.dtype],
+                                        op, mode, 0, None, 0, None, None, K.stream_ptr(tensor.device)),
+            'rua_segment_reduce')
+    return out
 
 
 def scatter_max(tensor: T, index: T, source: T, include_self: bool = False, dim: int = 0):
@@ -293,10 +320,7 @@ def pack_reduce(sequence: Z, op: str = 'sum', fused: bool = None):
     lens, sorted_indices, unsorted, batch_sizes, bsz_dev, boff = _pack_meta(sequence.token_sizes, dev)
     n = int(data.size(0)) if isinstance(sequence, C) else M.total_len(sequence.token_sizes)
     B = lens.numel()
-    nbytes = n * H * data.element_size()
-    placed = O._placement.key_for('pack_reduce', nbytes, data) if nbytes >= O._placement.MIN_BYTES else None
-    pdata = (torch.empty((n,) + hidden, dtype=data.dtype, device=dev) if placed is None
-             else O._placement.empty_for((n,) + hidden, data.dtype, dev, placed))
+    pdata = torch.empty((n,) + hidden, dtype=data.dtype, device=dev)
     p = P(data=pdata, batch_sizes=batch_sizes, sorted_indices=sorted_indices, unsorted_indices=unsorted)
     M.adopt_pack(p, lens, boff, bsz_dev)
     dst = M.lay_pack(p, lens=lens, boff=boff, T=batch_sizes.numel(), n_rows=n)
@@ -310,15 +334,10 @@ def pack_reduce(sequence: Z, op: str = 'sum', fused: bool = None):
     if paired:
         O._scratch_pair.acquire()
     try:
-        if placed is not None:
-            stream = torch.cuda.current_stream(dev)
-            placed = O._placement.begin(placed, pdata, stream)
         K.check(lib.rua_pack_reduce(src.ref(), dst.ref(), K.ptr(data), K.ptr(pdata), K.ptr(out), H, K.DTYPES[data.dtype],
                                     code | op_bits | (K.OP_NO_EMPTY if extreme is not None else 0),
                                     O._bits(O._EMPTY[code], data.dtype), K.ptr(extreme), split, K.ptr(ws),
                                     K.stream_ptr(dev)), 'rua_pack_reduce')
-        if placed is not None:
-            O._placement.end(placed, stream)
         if O._kernel_hook:
             O._kernel_hook('pack_reduce', False)
         if extreme is not None:

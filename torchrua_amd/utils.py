@@ -1,5 +1,5 @@
 """Index primitives — mirror of torchrua.utils (reference utils.py:7-26), each one kernel."""
-from typing import Tuple
+from typing import Any, List, Tuple
 
 import torch
 from torch import Tensor
@@ -7,7 +7,7 @@ from torch import Tensor
 from torchrua_amd import _lib as K
 from torchrua_amd import _meta as M
 
-__all__ = ['major_sizes_to_ptr', 'get_offsets', 'invert_permutation']
+__all__ = ['major_sizes_to_ptr', 'get_offsets', 'invert_permutation']   # (what the reference's other modules import)
 
 
 def get_offsets(sizes: Tensor) -> Tensor:
@@ -41,3 +41,29 @@ def invert_permutation(tensor: Tensor) -> Tensor:
     inv = torch.empty_like(p)
     K.check(lib.rua_pack_meta(None, K.ptr(p), p.numel(), 0, K.ptr(inv), None, K.stream_ptr(dev)), 'rua_pack_meta')
     return inv
+
+
+# ---- utils.py:33-51: shape helpers the reference defines and never calls (dead code there).  Kept for
+# the drop-in namespace only; they are shape arithmetic around torch.gather, not part of the hot path.
+def with_shape(shape, dim: int, value: int) -> List[int]:
+    """utils.py:33-36: `shape` with entry `dim` replaced."""
+    out = [int(d) for d in shape]
+    out[dim] = value
+    return out
+
+
+def broadcast_shapes(*sizes, dim: int) -> List[List[int]]:
+    """utils.py:39-41: broadcast every dimension but `dim`, which each shape keeps."""
+    common = torch.broadcast_shapes(*(with_shape(size, dim, 1) for size in sizes))
+    return [with_shape(common, dim, size[dim]) for size in sizes]
+
+
+def broadcast_tensors(*tensors: Tensor, dim: int) -> List[Tensor]:
+    """utils.py:44-46."""
+    return [t.expand(shape) for t, shape in zip(tensors, broadcast_shapes(*(t.size() for t in tensors), dim=dim))]
+
+
+def gather(tensor: Tensor, index: Tensor, dim: int) -> Tensor:
+    """utils.py:49-51."""
+    tensor, index = broadcast_tensors(tensor, index, dim=dim)
+    return tensor.gather(dim=dim, index=index)
