@@ -90,13 +90,13 @@ def test_long_sequences_against_fp64(name, B, lo, hi, H, dtype):
 def test_split_tail_combine_against_fp64(name, split, monkeypatch):
     """Force the long-sequence machinery (parts of `split` rows, a tail kernel, the ordered combine) on sequences of
     thousands of rows: the partial sums merge in part order and must meet the same bar."""
-    monkeypatch.setattr(M, 'reduce_split_rows', lambda lay, row_bytes=1024, team_ok=True: split)
+    monkeypatch.setattr(M, 'reduce_split_rows', lambda lay, *a, **k: split)
     lens, x = _inputs(9, 2000, 6000, 32, torch.float32, seed=split, prod=name == 'prod')
     c = ta.with_host_sizes(x.to(DEV), lens)
     for z in (c, c.pack()):
         _check(name, getattr(ta, f'reduce_{name}')(z), x, lens, torch.float32)
     # the two associations (split / whole) are both within the bar and agree with each other far inside it
-    monkeypatch.setattr(M, 'reduce_split_rows', lambda lay, row_bytes=1024, team_ok=True: 0)
+    monkeypatch.setattr(M, 'reduce_split_rows', lambda lay, *a, **k: 0)
     whole = getattr(ta, f'reduce_{name}')(c)
     _check(name, whole, x, lens, torch.float32)
 

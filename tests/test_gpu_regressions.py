@@ -471,53 +471,3 @@ def test_two_host_threads_share_one_stream():
     for t in threads:
         t.join()
     assert not errors, errors
-    monkeypatch.setattr(P, 'ENABLED', True)
-    monkeypatch.setattr(P, 'MIN_BYTES', 1 << 20)
-    for k in P.stats:
-        P.stats[k] = 0
-    g = torch.Generator().manual_seed(2)
-    lens = torch.randint(1, 50, (700,), generator=g)
-    data = torch.randn(int(lens.sum()), 128, generator=g).to(DEV)          # 8.7 MB payload
-    nbytes = data.numel() * data.element_size()
-    want = orc.to_pack(orc.C(data.cpu().numpy(), lens.numpy()), host_sort(lens))
-    keep = None
-    grown = None
-    for i in range(8):                # only what the loop itself frees is cached: timed launches, no growth
-        p = ta.with_host_sizes(data, lens).pack()
-        torch.cuda.synchronize()                                          # (so that the timings are in for the next choice)
-        assert np.array_equal(p.data.cpu().numpy(), want.data)
-        assert torch.equal(ta.reduce_sum(p), ta.segment_sum(data, lens.to(DEV)))
-        keep = p                                                          # the previous output stays alive for one step
-        if i == 3:
-            grown = torch.cuda.memory_reserved()
-    assert P.stats['timed'] >= 4 and torch.cuda.memory_reserved() == grown and not P._frozen
-    # the caller opts into more blocks to choose from
-    assert P.warm(nbytes, DEV, blocks=3) == 3
-    reserved = torch.cuda.memory_reserved()
-    key = next(iter(P._tried))
-    size = (DEV.index if DEV.index is not None else torch.cuda.current_device(), nbytes)
-    del keep, p
-    first = P._base(ta.with_host_sizes(data, lens).pack().data)          # the block the allocator offers first
-    torch.cuda.synchronize()
-    assert len(P._blocks[size]) >= 3
-    for b in P._blocks[size]:                                            # call that one slow, every other one fast
-        P._tried[key].add(b)
-        P._times[(key, b)] = (5.0 if b == first else 1.0, 5)
-    monkeypatch.setattr(P, '_harvest', lambda: None)          # (real timings would overwrite the made-up ones)
-    got = [P._base(ta.with_host_sizes(data, lens).pack().data) for _ in range(4)]
-    assert first not in got, (first, got)
-    assert P.stats['rejected'] >= 1 and not P._frozen
-    assert torch.cuda.memory_reserved() == reserved                      # never grew
-    # every cached block slow too: nothing better is known to be cached -> the first offer is taken, nothing is held
-    for b in P._blocks[size]:
-        P._times[(key, b)] = (5.0, 5)
-    P._times[(key, sorted(P._blocks[size])[0])] = (1.0, 5)
-    alive = [torch.empty(nbytes, dtype=torch.uint8, device=DEV) for _ in range(8)]   # ... and the fast one is in use
-    p = ta.with_host_sizes(data, lens).pack()
-    assert np.array_equal(p.data.cpu().numpy(), want.data)
-    del alive
-    # off: plain torch.empty
-    monkeypatch.setattr(P, 'ENABLED', False)
-    p = ta.with_host_sizes(data, lens).pack()
-    assert np.array_equal(p.data.cpu().numpy(), want.data)
-    P.forget()
