@@ -163,6 +163,30 @@ def parity_leg(ta, data, lens_host, out_bf16, n_sample=256):
         'bar': '1e-5 relative (BASELINE.json north_star); integer outputs bit-exact (checked by tests, not here)'}
 
 
+def _ranges(cpus):
+    """[0, 1, 2, 3, 8, 9] -> '0-3,8-9' (the CPU set a rank bound itself to)."""
+    out, run = [], []
+    for c in sorted(cpus):
+        if run and c == run[-1] + 1:
+            run.append(c)
+        else:
+            if run:
+                out.append(run)
+            run = [c]
+    if run:
+        out.append(run)
+    return ','.join(f'{r[0]}-{r[-1]}' if len(r) > 1 else str(r[0]) for r in out)
+
+
+def _gpu_numa_node(dev):
+    """What parallel.bind_rank_to_cpus reads from sysfs for this card (None when the platform does not say)."""
+    try:
+        from torchrua_amd import parallel
+        return parallel._numa_node_of_gpu(parallel._pci_name(torch.cuda.get_device_properties(dev.index or 0)))
+    except Exception:
+        return None
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks here, one fresh child process per GPU, BEFORE
     anything in this process touches the GPU (the parent never does), and leave with their exit code.  The children
@@ -281,6 +305,7 @@ def main():
             c = ta.C(data, lens_host.to(dev))                 # device-only lengths: pack() must read them back
         p = c.pack()
         out = ta.reduce_sum(p)
+        enqueue_s[0] = time.perf_counter()        # the rank's own host work ends here; what follows waits for peers
         if use_dist:
             # ONE RCCL all-gather of [B, H] per step, on RCCL's stream: it overlaps the next step's
             # kernels; at most one is in flight, and the last one is waited for inside the timed region
@@ -291,6 +316,7 @@ def main():
         return p, out
 
     pending = []
+    enqueue_s = [0.0]
     lens_master = lens_host.to(dev)
 
     def drain():
@@ -315,7 +341,7 @@ def main():
     for _ in range(args.steps):
         h0 = time.perf_counter()
         p, out = step()
-        host_ms.append((time.perf_counter() - h0) * 1e3)
+        host_ms.append((enqueue_s[0] - h0) * 1e3)       # pack() + reduce_sum() enqueued (host sort included)
     sync()
     dt = time.perf_counter() - t0
     if args.trace_host and rank == 0:
@@ -386,8 +412,22 @@ def main():
             'note': 'one kernel returns the PackedSequence AND the [B,H] sums; 2/3 of the pipeline traffic'}
 
 
-    # per-rank facts: rows, own wall clock, own kernel times (HIP events on the launch stream)
-    mine = [float(N), dt, timer.mean_ms('to_pack') or 0.0, timer.mean_ms('reduce') or 0.0]
+    # the host side of a rank, with every other rank of the node live: the enqueue loop (Python + ctypes per step) and
+    # the host sort of this rank's lengths, all ranks sorting at the same moment (per-rank host time
+    # must stay under the per-rank kernel time when eight ranks share one host)
+    from torchrua_amd import _meta
+    if use_dist:
+        dist.barrier()
+    ts = time.perf_counter()
+    for _ in range(20):
+        _meta.host_sort_desc(lens_host)
+    sort_ms = (time.perf_counter() - ts) / 20 * 1e3
+    host_enqueue_ms = sum(host_ms) / max(1, len(host_ms))
+    cpu_sets = [list(my_cpus)]
+
+    # per-rank facts: rows, own wall clock, own kernel times (HIP events on the launch stream), own host times
+    mine = [float(N), dt, timer.mean_ms('to_pack') or 0.0, timer.mean_ms('reduce') or 0.0, host_enqueue_ms, sort_ms,
+            float(torch.get_num_threads())]
     per_rank = [mine]
     ranks_reported = 1
     if use_dist:
@@ -398,6 +438,8 @@ def main():
         table[rank] = torch.tensor(mine, dtype=torch.float64, device=dev)
         dist.all_reduce(table)                      # every rank fills its own row
         per_rank = table.cpu().tolist()
+        cpu_sets = [None] * world
+        dist.all_gather_object(cpu_sets, list(my_cpus))
         dt = max(row[1] for row in per_rank)        # the slowest rank sets the job's time
     n_total = sum(row[0] for row in per_rank)
 
@@ -431,11 +473,15 @@ def main():
                        'lens_source': 'host (C.new-style hand-over)',
                        'ranks_reported_by_process_group': ranks_reported,
                        'cpus_of_rank0': len(my_cpus), 'torch_threads_rank0': torch.get_num_threads(),
+                       'numa_node_of_rank0_gpu': _gpu_numa_node(dev),
                        'host_sort': os.environ.get('RUA_HOST_SORT', 'self-tuned'),
                        'backend': (os.environ.get('RUA_BENCH_BACKEND', 'nccl') + (' (RCCL)' if os.environ.get('RUA_BENCH_BACKEND', 'nccl') == 'nccl' else '')) if use_dist else None},
             'per_rank': [{'rank': r, 'rows': int(row[0]), 'ms_per_step': round(row[1] / args.steps * 1e3, 4),
                           'pack_kernel_GBps': round((2.0 * row[0] * H * e + 8.0 * (3 * B + T)) / (row[2] * 1e-3) / 1e9, 1) if row[2] else None,
-                          'reduce_kernel_GBps': round((row[0] * H * e + 1.0 * B * H * e + 8.0 * B) / (row[3] * 1e-3) / 1e9, 1) if row[3] else None}
+                          'reduce_kernel_GBps': round((row[0] * H * e + 1.0 * B * H * e + 8.0 * B) / (row[3] * 1e-3) / 1e9, 1) if row[3] else None,
+                          'kernel_ms': round(row[2] + row[3], 4), 'host_enqueue_ms': round(row[4], 4),
+                          'host_sort_ms': round(row[5], 4), 'torch_threads': int(row[6]),
+                          'cpus': _ranges(cpu_sets[r]) if r < len(cpu_sets) and cpu_sets[r] is not None else None}
                          for r, row in enumerate(per_rank)],
             'roofline': {'bound': 'hbm', 'kernel': 'move_rows_kernel<16,false,NT,1,16,256,4> (C->P pack, 16-row tiles)',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -1,0 +1,183 @@
+"""HBM traffic of single operators from the PMC counters (passes over the keys of index_buckets,
+over-fetch of narrow rows and pads).
+
+    # on the GPU box, one pass per counter (the pool refuses --pmc together with trace domains):
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmcops_fetch -o run -- python3 scripts/pmc_ops.py run
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmcops_write -o run -- python3 scripts/pmc_ops.py run
+    python3 scripts/pmc_ops.py run --time > gpurun_out/pmcops_time.json          # HIP-event times, no profiler
+    python3 scripts/pmc_ops.py summarize r04                                     # -> profiles/r04_pmc_ops.json
+
+`run` executes a fixed list of operator groups; every group is `REPS` launches of one operator, and a tiny byte-mask
+launch (rua::mask_kernel<unsigned long, 1>: get_mask of a two-sequence batch, used by none of the operators measured) separates the groups, so the counter
+rows — one per dispatch, in dispatch order — can be cut into groups without naming kernels.  Counter unit: KiB.
+gfx950: FETCH_SIZE reports half of the bytes of a wide coalesced read stream (MI355X_MICROARCH.md, HBM section), so
+reads are doubled; other access widths are uncalibrated in absolute terms — the `calib.*` groups (a streaming copy
+through the same mover at 1 KiB, 64 B and 32 B rows, whose traffic is known) give the scale for each width.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REPS = 3
+MARK = 'mask_kernel<unsigned long'
+
+
+def groups():
+    """[(name, algorithmic_bytes, callable)] — built lazily: every group allocates its own inputs and frees them."""
+    import torch
+
+    import torchrua_amd as ta
+    from torchrua_amd import _ops as O
+    from torchrua_amd.layout import describe
+    dev = torch.device('cuda:0')
+
+    def ragged(seed, B, lo, hi, H, dtype=torch.bfloat16):
+        g = torch.Generator().manual_seed(seed)
+        lens = torch.randint(lo, hi + 1, (B,), generator=g)
+        n = int(lens.sum())
+        data = torch.empty((n, H), dtype=dtype, device=dev)
+        step = 1 << 22
+        for a in range(0, n, step):
+            data[a:a + step] = torch.randn((min(n, a + step) - a, H), device=dev)
+        return lens, data
+
+    def north_star():
+        lens, data = ragged(5, 65536, 8, 512, 512)
+        c = ta.with_host_sizes(data, lens)
+        p = c.pack()
+        N, H, B, T, e = data.size(0), 512, 65536, int(lens.max()), 2
+        bp = c.ptr()[0]
+        shuffled = bp[torch.randperm(N, device=dev)]
+        yield 'ns.index_buckets(shuffled)', 2 * N * 8, lambda: O.index_buckets(shuffled, B)
+        yield 'ns.index_buckets(p.ptr()[0])', 2 * N * 8, (lambda ix=p.ptr()[0]: O.index_buckets(ix, B))
+        ten = torch.zeros(B, H, dtype=torch.bfloat16, device=dev)
+        yield 'ns.scatter_sum(shuffled)', N * H * e + B * H * e + 2 * N * 8, lambda: ta.scatter_sum(ten, shuffled, data)
+        yield 'ns.c.pack()', 2 * N * H * e, lambda: c.pack()
+        yield 'ns.c.left()', N * H * e + B * T * H * e, lambda: c.left()
+        yield 'ns.p.left()', N * H * e + B * T * H * e, lambda: p.left()
+        yield 'ns.c.roll(0)  [calib: streaming copy, 1 KiB rows]', 2 * N * H * e, lambda: c.roll(0)
+        lft = c.left()
+        yield 'ns.l.idx()', N * 8, lambda: lft.idx()
+        yield 'ns.c.bmask()', B * T, lambda: c.bmask()
+
+    def narrow(H):
+        rows = int(8e9 / (H * 2))
+        B = max(1024, rows // 260)
+        lens, data = ragged(H, B, 8, 512, H)
+        c = ta.with_host_sizes(data, lens)
+        p = c.pack()
+        nb = data.numel() * 2
+        cl, pl = describe(c), describe(p)
+        out = torch.empty_like(data)
+        tag = f'w{H * 2}'
+        yield f'{tag}.pack', 2 * nb, lambda: O.launch_move(O.MovePlan(pl, cl, data.shape), data, out=out)
+        yield f'{tag}.P.cat', 2 * nb, lambda: O.launch_move(O.MovePlan(cl, pl, data.shape), p.data, out=out)
+        yield f'{tag}.P.roll(1)', 2 * nb, lambda: O.launch_move(O.MovePlan(pl, pl, data.shape, tmap=1, arg=1), p.data, out=out)
+        yield f'{tag}.C.roll(0)  [calib: streaming copy, {H * 2} B rows]', 2 * nb, lambda: O.launch_move(O.MovePlan(cl, cl, data.shape, tmap=1, arg=0), data, out=out)
+
+    yield from north_star()
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    for H in (16, 32):
+        yield from narrow(H)
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
+def run(timed: bool):
+    import torch
+
+    import torchrua_amd as ta
+    dev = torch.device('cuda:0')
+    tiny = ta.with_host_sizes(torch.zeros(4, 2, device=dev), torch.tensor([1, 3]))
+    times = {}
+    order = []
+    for name, nbytes, fn in groups():
+        fn()                                     # untimed, uncounted warm-up BEFORE the marker
+        torch.cuda.synchronize()
+        ta.get_mask(tiny)                        # the marker: everything up to the next marker is this group
+        e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+        e0.record()
+        for _ in range(REPS):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        order.append(name)
+        times[name] = {'algorithmic_bytes': nbytes, 'ms_per_call': e0.elapsed_time(e1) / REPS}
+    ta.get_mask(tiny)
+    torch.cuda.synchronize()
+    if timed:
+        print(json.dumps({'order': order, 'ops': times}, indent=1))
+
+
+def counter_rows(d, counter):
+    files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+    rows = []
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r['Counter_Name'] == counter:
+                rows.append((int(r['Dispatch_Id']), r['Kernel_Name'], float(r['Counter_Value'])))
+    per = collections.OrderedDict()                      # several rows per dispatch (one per instance): sum them
+    for did, name, v in sorted(rows):
+        if did in per:
+            per[did][1] += v
+        else:
+            per[did] = [name, v]
+    return list(per.values())
+
+
+def cut(rows, order):
+    """Counter rows in dispatch order -> {group: {kernel: KiB per CALL}} using the marker launches."""
+    out, cur, gi = {}, None, -1
+    for name, v in rows:
+        if MARK in name:
+            gi += 1
+            cur = order[gi] if gi < len(order) else None
+            if cur is not None:
+                out[cur] = collections.defaultdict(float)
+            continue
+        if cur is not None:
+            short = name.replace('void ', '').split('(')[0][:90]
+            out[cur][short] += v / REPS
+    return out
+
+
+def summarize(tag):
+    G = os.path.join(ROOT, 'gpurun_out')
+    meta = json.load(open(os.path.join(G, 'pmcops_time.json')))
+    order = meta['order']
+    fetch = cut(counter_rows(os.path.join(G, 'pmcops_fetch'), 'FETCH_SIZE'), order)
+    write = cut(counter_rows(os.path.join(G, 'pmcops_write'), 'WRITE_SIZE'), order)
+    out = {'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of scripts/pmc_ops.py; per CALL of the operator '
+                   '(all its kernels); read = 2 * FETCH_SIZE KiB (gfx950: half of a wide read stream is reported), write = '
+                   'WRITE_SIZE KiB; widths other than 16 B per lane are uncalibrated in absolute terms: compare with the '
+                   'calib rows of the same width', 'ops': collections.OrderedDict()}
+    for name in order:
+        rd = 2.0 * 1024 * sum(fetch.get(name, {}).values())
+        wr = 1024.0 * sum(write.get(name, {}).values())
+        alg = meta['ops'][name]['algorithmic_bytes']
+        ms = meta['ops'][name]['ms_per_call']
+        out['ops'][name] = {
+            'algorithmic_bytes': alg, 'ms_per_call': round(ms, 4), 'algorithmic_TBps': round(alg / ms / 1e9, 3),
+            'hbm_read_bytes': rd, 'hbm_write_bytes': wr, 'traffic_over_algorithmic': round((rd + wr) / alg, 3) if alg else None,
+            'kernels_read_KiB_x2': {k: round(2 * v, 1) for k, v in fetch.get(name, {}).items()},
+            'kernels_write_KiB': {k: round(v, 1) for k, v in write.get(name, {}).items()}}
+    path = os.path.join(ROOT, 'profiles', f'{tag}_pmc_ops.json')
+    with open(path, 'w') as f:
+        json.dump(out, f, indent=1)
+    for name, o in out['ops'].items():
+        print(f"{name:55s} {o['ms_per_call']:9.3f} ms  alg {o['algorithmic_bytes'] / 1e9:7.3f} GB  "
+              f"read {o['hbm_read_bytes'] / 1e9:7.3f}  write {o['hbm_write_bytes'] / 1e9:7.3f}  x{o['traffic_over_algorithmic']}")
+
+
+if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'summarize':
+        summarize(sys.argv[2] if len(sys.argv) > 2 else 'r04')
+    else:
+        run('--time' in sys.argv)

@@ -1,5 +1,6 @@
 // rua_meta.hip — index-generation kernels (int64, bit-exact): prefix scan, PackedSequence
 // metadata, row enumeration (ptr/idx) and masks.  gfx950, wave64.  See include/rua.h.
+#include <stdlib.h>
 #include "rua_dev.h"
 
 namespace rua {
@@ -349,6 +350,53 @@ __global__ __launch_bounds__(RUA_BLOCK) void enum_flat_kernel(rua_layout L, int6
   }
 }
 
+// The same enumeration SEQUENCE BY SEQUENCE, for batches whose sequences are long enough to fill wave instructions
+// (average >= ENUM_SEQ_MIN_AVG_* tokens): a wave takes ENUM_SEQ_PER_WAVE consecutive sequences — their offsets and
+// lengths arrive in ONE coalesced load, lane i holding sequence i's — and writes every sequence's tokens as a run of
+// 16-byte stores (two tokens per lane, lanes side by side).  No search at all: the only dependent load in front of the
+// stores is that one.  The runs start wherever the sequence starts, so the 16-byte stores sit on 8-byte boundaries
+// (gfx950 takes a dwordx4 at any dword-aligned address).  L.idx() at the north-star shape: see DESIGN.md §4.2.
+constexpr int ENUM_SEQ_PER_WAVE = 8;
+// measured (gpurun_out/r4d/enum_ab.txt, MI355X): L.idx() 36.9 -> 24.2 us at the north-star shape (average 260 tokens),
+// 50 -> 41 us at an average of 48, but 41 -> 72 us at an average of 20; with batch_ptr / token_ptr as well (two or
+// three stores per token) the per-sequence form only draws level from ~130 tokens up (46.6 -> 44.4 us at 260)
+constexpr int64_t ENUM_SEQ_MIN_AVG_FLAT = 48, ENUM_SEQ_MIN_AVG_PTR = 128;
+typedef long long i64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ void store_run2(int64_t* __restrict__ dst, int64_t t, int64_t len, int64_t a, int64_t b) {
+  if (t + 1 < len) {
+    const i64x2_a8 v = {a, b};
+    *reinterpret_cast<i64x2_a8*>(dst + t) = v;
+  } else if (t < len) {
+    dst[t] = a;
+  }
+}
+__global__ __launch_bounds__(RUA_BLOCK) void enum_seq_kernel(rua_layout L, int64_t n, int64_t* __restrict__ bp,
+                                                             int64_t* __restrict__ tp, int64_t* __restrict__ flat) {
+  const int lane = threadIdx.x & (RUA_WAVE - 1);
+  const int64_t wave_id = ((int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x) >> 6;
+  const int64_t b0 = wave_id * ENUM_SEQ_PER_WAVE;
+  if (b0 >= L.B) return;                                       // wave-uniform
+  const int64_t bl = b0 + lane;
+  const bool have = lane < ENUM_SEQ_PER_WAVE && bl < L.B;
+  const int64_t my_off = have ? cat_off(L, bl) : 0;
+  const int64_t my_len = have ? seq_len(L, bl) : 0;
+#pragma unroll
+  for (int i = 0; i < ENUM_SEQ_PER_WAVE; ++i) {
+    const int64_t b = b0 + i;
+    if (b >= L.B) break;                                       // wave-uniform
+    const int64_t off = __shfl(my_off, i, RUA_WAVE);
+    int64_t len = __shfl(my_len, i, RUA_WAVE);
+    if (off + len > n) len = n - off;                          // lengths that overrun the output read as cut short
+    if (len <= 0) continue;                                    // wave-uniform
+    const int64_t r0 = L.kind == RUA_CAT ? off : L.kind == RUA_LEFT ? b * L.T_phys : b * L.T_phys + (L.T_log - seq_len(L, b));
+    for (int64_t t = (int64_t)lane * 2; t < len; t += RUA_WAVE * 2) {
+      if (bp) store_run2(bp + off, t, len, b, b);
+      if (tp) store_run2(tp + off, t, len, t, t + 1);
+      if (flat) store_run2(flat + off, t, len, r0 + t, r0 + t + 1);
+    }
+  }
+}
+
 // P.ptr(): tokens in storage order, (sorted[rank], t) — layout/pack.py:23-27 — the same way
 __global__ __launch_bounds__(RUA_BLOCK) void enum_pack_kernel(rua_layout L, int64_t n, int64_t* __restrict__ bp,
                                                               int64_t* __restrict__ tp) {
@@ -389,7 +437,10 @@ __global__ __launch_bounds__(RUA_BLOCK) void enum_pack_kernel(rua_layout L, int6
 // One lane writes 16 bytes (EPV elements) of the flat [B, T] grid: ONE integer division per 16-byte store locates
 // the first element, the rest walk along the row (and into the next one where a vector straddles a row end).
 // The B x T int64 grid of get_mask is 256 MiB at the north-star shape: a pure store stream.
-template <typename E>
+// VPT: 16-byte stores per thread (a workgroup's u-th store instruction covers one contiguous 4 KiB).  A byte mask is
+// 32 MiB at the north-star shape: with one store per thread the kernel was 8 192 short-lived workgroups, each waiting
+// one L2 round trip for its `lens[b]` before its only store (3.5 TB/s); four per thread put four loads in flight first.
+template <typename E, int VPT>
 __global__ __launch_bounds__(RUA_BLOCK) void mask_kernel(const int64_t* __restrict__ lens, int64_t B, int64_t T,
                                                          E* __restrict__ out, E zero, E one, int64_t n,
                                                          int64_t head) {
@@ -397,10 +448,15 @@ __global__ __launch_bounds__(RUA_BLOCK) void mask_kernel(const int64_t* __restri
   struct alignas(16) Vec { E v[EPV]; };
   // elements [0, head) in front of the first 16-byte boundary and the tail behind the last one go one by one
   const int64_t nvec = (n - head) / EPV;
-  const int64_t k = (int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < VPT; ++u) {
+  const int64_t k = ((int64_t)blockIdx.x * VPT + u) * RUA_BLOCK + threadIdx.x;
   if (k < nvec) {
     const int64_t e0 = head + k * EPV;
-    int64_t b = e0 / T, t = e0 - b * T;
+    // (a 64-bit division is ~100 instructions; for a byte mask that is one per 16 output BYTES and the kernel was bound
+    // by it: grids below 2^32 cells divide in 32 bits)
+    int64_t b = n <= 0xffffffffLL ? (int64_t)((uint32_t)e0 / (uint32_t)T) : e0 / T;
+    int64_t t = e0 - b * T;
     int64_t len = lens[b];
     Vec v;
     if (sizeof(E) == 1 && t + EPV <= T) {
@@ -431,6 +487,7 @@ __global__ __launch_bounds__(RUA_BLOCK) void mask_kernel(const int64_t* __restri
       const int64_t b = e / T, t = e - b * T;
       out[e] = t < lens[b] ? one : zero;
     }
+  }
   }
 }
 
@@ -524,6 +581,15 @@ int rua_enum_rows(const rua_layout* lay, int64_t n_tokens, int64_t* batch_ptr, i
   }
   // the batch-major layouts with ragged lengths (C.idx() alone stays an iota)
   if (lay->kind != RUA_PACK && lay->off && lay->lens && (batch_ptr || token_ptr || lay->kind != RUA_CAT)) {
+    static const int seq_knob = [] { const char* e = getenv("RUA_ENUM_SEQ"); return e ? atoi(e) : -1; }();   // developer A/B
+    const int64_t min_avg = (batch_ptr || token_ptr) ? ENUM_SEQ_MIN_AVG_PTR : ENUM_SEQ_MIN_AVG_FLAT;
+    const bool by_seq = seq_knob >= 0 ? seq_knob != 0 : n_tokens >= lay->B * min_avg;
+    if (by_seq && lay->len_add == 0) {
+      const int64_t waves = (lay->B + ENUM_SEQ_PER_WAVE - 1) / ENUM_SEQ_PER_WAVE;
+      hipLaunchKernelGGL(enum_seq_kernel, dim3((unsigned)((waves + RUA_WAVES_PER_BLOCK - 1) / RUA_WAVES_PER_BLOCK)),
+                         dim3(RUA_BLOCK), 0, (hipStream_t)stream, *lay, n_tokens, batch_ptr, token_ptr, flat);
+      return (int)hipGetLastError();
+    }
     const int64_t per_block = (int64_t)RUA_BLOCK * ENUM_PAIR * ENUM_NCH;
     hipLaunchKernelGGL(enum_flat_kernel, dim3((unsigned)((n_tokens + per_block - 1) / per_block)), dim3(RUA_BLOCK), 0,
                        (hipStream_t)stream, *lay, n_tokens, batch_ptr, token_ptr, flat);
@@ -551,8 +617,9 @@ int rua_mask(const int64_t* lens, int64_t B, int64_t T, void* out, int32_t elem_
     const int64_t nvec = (n - head) / EPV;                                                                       \
     const int64_t threads = nvec + head + (n - head - nvec * EPV);                                               \
     if ((threads + RUA_BLOCK - 1) / RUA_BLOCK > 0x7fffffffLL) return RUA_ERANGE;                                 \
-    hipLaunchKernelGGL(mask_kernel<E>, dim3(grid_for(threads)), blk, 0, s, lens, B, T, (E*)out, (E)zero_bits,    \
-                       (E)one_bits, n, head);                                                                    \
+    constexpr int VPT = sizeof(E) <= 2 ? 4 : 1;                                                                  \
+    hipLaunchKernelGGL((mask_kernel<E, VPT>), dim3(grid_for((threads + VPT - 1) / VPT)), blk, 0, s, lens, B, T,   \
+                       (E*)out, (E)zero_bits, (E)one_bits, n, head);                                             \
   }
   switch (elem_bytes) {
     case 1: RUA_MASK(uint8_t); break;

@@ -21,6 +21,7 @@
 // wave barrier per 64 of them, 8-byte stores) -> 0.42 ms (hist 45 us + scan 19 us + scatter 113 / 146 us per pass,
 // bounds 22 us).  Writing the runs to consecutive addresses instead would only save another 25 us per pass
 // (measured), so what is left is the ranking itself and the size of the launch.
+#include <stdlib.h>
 #include "rua_dev.h"
 
 namespace rua {
@@ -218,6 +219,12 @@ __global__ __launch_bounds__(RUA_BLOCK) void bucket_bounds_kernel(const int64_t*
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + RUA_BLOCK - 1) / RUA_BLOCK); }
 static inline int bits_of(int64_t v) { int b = 1; while (b < 63 && (v >> b) != 0) ++b; return b; }
 
+// rua_bucket_msd.hip: the two-level most-significant-digit-first builder (up to 262 144 destinations, M < 2^31)
+int64_t bucket_msd_ws_bytes(int64_t M);
+bool bucket_msd_applies(int64_t M, int64_t S);
+int bucket_msd(const int64_t* index, int64_t M, int64_t S, int64_t* counts, int64_t* off, int64_t* perm, void* ws,
+               hipStream_t s);
+
 }  // namespace rua
 
 using namespace rua;
@@ -229,7 +236,9 @@ int64_t rua_bucket_ws_elems(int64_t M, int64_t S) {
   if (M < 0 || S < 0) return 0;
   const int64_t nb = (M + SORT_BLOCK - 1) / SORT_BLOCK;
   const int64_t tab = (int64_t)RADIX_MAX * (nb > 0 ? nb : 1);
-  return rua_scan_ws_elems(tab) + tab + 2 * M + 8;
+  const int64_t lsd = rua_scan_ws_elems(tab) + tab + 2 * M + 8;
+  const int64_t msd = (bucket_msd_ws_bytes(M) + 7) / 8 + 2;          // whichever builder the call takes fits
+  return lsd > msd ? lsd : msd;
 }
 
 int rua_index_buckets(const int64_t* index, int64_t M, int64_t S, int64_t* counts, int64_t* off, int64_t* perm,
@@ -243,6 +252,10 @@ int rua_index_buckets(const int64_t* index, int64_t M, int64_t S, int64_t* count
     if (e == hipSuccess) e = hipMemsetAsync(off, 0, sizeof(int64_t) * (size_t)S, s);
     return (int)e;
   }
+  // 513 .. 262 144 destinations: most significant digit first, the second level local to a bin (rua_bucket_msd.hip);
+  // RUA_BUCKET_LSD=1 (a developer knob for A/B runs) keeps the least-significant-digit-first passes below
+  static const bool force_lsd = [] { const char* e = getenv("RUA_BUCKET_LSD"); return e && e[0] == '1'; }();
+  if (!force_lsd && bucket_msd_applies(M, S)) return bucket_msd(index, M, S, counts, off, perm, (void*)ws, s);
   const int64_t nb = (M + SORT_BLOCK - 1) / SORT_BLOCK;
   if (nb > 0x7ffffff0LL) return RUA_ERANGE;
   const int64_t per_xcd = (nb + 7) / 8;

@@ -130,7 +130,11 @@ def bind_rank_to_cpus(local_rank: int, local_world: int, device_index: Optional[
     try:
         gpu_nodes = [_numa_node_of_gpu(_pci_name(torch.cuda.get_device_properties(i)))
                      for i in range(torch.cuda.device_count())]
-        if device_index is not None and local_rank < len(gpu_nodes):
+        if device_index is not None and device_index < len(gpu_nodes) and len(gpu_nodes) < local_world:
+            # a rehearsal with every rank on ONE card (bench.py RUA_BENCH_DEVICE): all ranks sit on that card's node
+            # and split its CPUs, which is what the ranks of one NUMA node of a multi-GPU host do
+            gpu_nodes = [gpu_nodes[device_index]] * local_world
+        elif device_index is not None and local_rank < len(gpu_nodes):
             gpu_nodes[local_rank] = gpu_nodes[device_index]
         node_cpus = {}
         base = '/sys/devices/system/node'
