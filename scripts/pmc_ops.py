@@ -7,8 +7,8 @@ over-fetch of narrow rows and pads).
     python3 scripts/pmc_ops.py run --time > gpurun_out/pmcops_time.json          # HIP-event times, no profiler
     python3 scripts/pmc_ops.py summarize r04                                     # -> profiles/r04_pmc_ops.json
 
-`run` executes a fixed list of operator groups; every group is `REPS` launches of one operator, and a tiny byte-mask
-launch (rua::mask_kernel<unsigned long, 1>: get_mask of a two-sequence batch, used by none of the operators measured) separates the groups, so the counter
+`run` executes a fixed list of operator groups; every group is one uncounted warm-up and `REPS` counted launches of one
+operator, and a tiny mask launch (rua::mask_kernel<unsigned long, 1>: get_mask of a two-sequence batch, used by none of the operators measured) separates the groups, so the counter
 rows — one per dispatch, in dispatch order — can be cut into groups without naming kernels.  Counter unit: KiB.
 gfx950: FETCH_SIZE reports half of the bytes of a wide coalesced read stream (MI355X_MICROARCH.md, HBM section), so
 reads are doubled; other access widths are uncalibrated in absolute terms — the `calib.*` groups (a streaming copy
@@ -99,9 +99,10 @@ def run(timed: bool):
     times = {}
     order = []
     for name, nbytes, fn in groups():
-        fn()                                     # untimed, uncounted warm-up BEFORE the marker
+        ta.get_mask(tiny)                        # marker: what follows is this group's WARM-UP (not counted) ...
+        fn()
         torch.cuda.synchronize()
-        ta.get_mask(tiny)                        # the marker: everything up to the next marker is this group
+        ta.get_mask(tiny)                        # ... marker: everything up to the next marker is this group
         e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
         e0.record()
         for _ in range(REPS):
@@ -137,8 +138,8 @@ def cut(rows, order):
     out, cur, gi = {}, None, -1
     for name, v in rows:
         if MARK in name:
-            gi += 1
-            cur = order[gi] if gi < len(order) else None
+            gi += 1                                  # even marker: a warm-up follows; odd marker: the counted launches
+            cur = order[gi // 2] if gi % 2 == 1 and gi // 2 < len(order) else None
             if cur is not None:
                 out[cur] = collections.defaultdict(float)
             continue

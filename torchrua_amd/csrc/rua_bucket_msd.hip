@@ -30,7 +30,10 @@ constexpr int MSD_RADIX_BITS = 9;
 constexpr int MSD_RADIX = 1 << MSD_RADIX_BITS;
 constexpr int MSD_WAVES = 8;
 constexpr int MSD_THREADS = MSD_WAVES * RUA_WAVE;        // 512 >= MSD_RADIX: one thread per digit / per bin
-constexpr int MSD_ITEMS = 16;
+#ifndef RUA_MSD_ITEMS        // developer knob for A/B builds
+#define RUA_MSD_ITEMS 8
+#endif
+constexpr int MSD_ITEMS = RUA_MSD_ITEMS;
 constexpr int MSD_BLOCK = MSD_THREADS * MSD_ITEMS;       // 8 192 entries per workgroup / per segment
 static_assert(MSD_THREADS >= MSD_RADIX, "one thread per digit");
 
@@ -185,11 +188,13 @@ __global__ __launch_bounds__(RUA_BLOCK) void msd_scan_rows_kernel(unsigned int* 
 // ---- stable ranking of a block's entries by digit and staging in block-sorted order (the scheme of rua_scatter.hip).
 // On return: `stage[q]` holds the q-th entry of the block in (digit, input order); dstart[d] = first slot of digit d.
 // OUT: what is staged (the level-1 word, or the level-2 row).
+// `side` (may be NULL): side[q] = digit >> 1 of the entry staged at slot q, for outputs that have no room for the digit.
 template <typename OUT>
 __device__ __forceinline__ void msd_rank_and_stage(const int (&digit)[MSD_ITEMS], const bool (&live)[MSD_ITEMS],
                                                    const OUT (&val)[MSD_ITEMS], int width, OUT* __restrict__ stage,
                                                    unsigned short (*__restrict__ wcnt)[MSD_RADIX],
-                                                   unsigned short* __restrict__ dstart, unsigned int* __restrict__ wave_tot) {
+                                                   unsigned short* __restrict__ dstart, unsigned int* __restrict__ wave_tot,
+                                                   unsigned char* __restrict__ side = nullptr) {
   const int tid = threadIdx.x, lane = tid & (RUA_WAVE - 1), wave = tid >> 6;
   const int radix = 1 << width;
   for (int i = tid; i < MSD_WAVES * MSD_RADIX / 2; i += MSD_THREADS) reinterpret_cast<unsigned int*>(&wcnt[0][0])[i] = 0;
@@ -230,7 +235,11 @@ __device__ __forceinline__ void msd_rank_and_stage(const int (&digit)[MSD_ITEMS]
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < MSD_ITEMS; ++u)
-    if (live[u]) stage[dstart[digit[u]] + wcnt[wave][digit[u]] + before[u]] = val[u];
+    if (live[u]) {
+      const int q = dstart[digit[u]] + wcnt[wave][digit[u]] + before[u];
+      stage[q] = val[u];
+      if (side) side[q] = (unsigned char)(digit[u] >> 1);
+    }
   __syncthreads();
 }
 
@@ -244,6 +253,7 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_scatter1_kernel(const int64_t
   __shared__ unsigned short wcnt[MSD_WAVES][MSD_RADIX];
   __shared__ unsigned short dstart[MSD_RADIX];
   __shared__ unsigned int delta[MSD_RADIX];            // bin: global first slot - first slot inside the block
+  __shared__ unsigned char sbin[MSD_BLOCK];            // bin >> 1 of every staged slot (a 32-bit word has no room for it)
   __shared__ unsigned int wave_tot[MSD_WAVES];
   const int tid = threadIdx.x;
   const int64_t block = msd_block(per_xcd);
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_scatter1_kernel(const int64_t
     digit[u] = live[u] ? (int)(v >> G.lo_bits) : 0;
     val[u] = (W)(((uint64_t)(v & lo_mask) << G.row_bits) | (uint64_t)i);
   }
-  msd_rank_and_stage<W>(digit, live, val, width, stage, wcnt, dstart, wave_tot);
+  msd_rank_and_stage<W>(digit, live, val, width, stage, wcnt, dstart, wave_tot, sbin);
   if (tid < G.n_bins) delta[tid] = bin_base + table1[(int64_t)tid * G.n_blocks + block] - (unsigned int)dstart[tid];
   __syncthreads();
   // the block's live entries occupy slots [0, total); consecutive threads write consecutive words, and a slot's bin is
@@ -285,12 +295,9 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_scatter1_kernel(const int64_t
   __syncthreads();
   const int total = s_total;
   for (int q = tid; q < total; q += MSD_THREADS) {
-    int lo = 0, hi = G.n_bins;                        // last bin with dstart <= q (bins without entries share a start:
-    while (hi - lo > 1) {                             //  the LAST of them is the one that owns slot q)
-      const int mid = (lo + hi) >> 1;
-      if ((int)dstart[mid] <= q) lo = mid; else hi = mid;
-    }
-    words[(int64_t)(unsigned int)(delta[lo] + (unsigned int)q)] = stage[q];      // (delta wraps: mod 2^32 arithmetic)
+    int bin = (int)sbin[q] << 1;                      // the even bin of the pair; the odd one starts at dstart[bin + 1]
+    if (bin + 1 < G.n_bins && (int)dstart[bin + 1] <= q) ++bin;
+    words[(int64_t)(unsigned int)(delta[bin] + (unsigned int)q)] = stage[q];     // (delta wraps: mod 2^32 arithmetic)
   }
 }
 
@@ -388,7 +395,7 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_scatter2_kernel(const W* __re
                                                                   const unsigned int* __restrict__ rowtot,
                                                                   const unsigned int* __restrict__ table2,
                                                                   int64_t* __restrict__ perm) {
-  __shared__ unsigned int stage[MSD_BLOCK];            // rows (M < 2^31 on this path)
+  __shared__ W stage[MSD_BLOCK];                       // the words themselves: the digit rides in their high bits
   __shared__ unsigned short wcnt[MSD_WAVES][MSD_RADIX];
   __shared__ unsigned short dstart[MSD_RADIX];
   __shared__ unsigned int delta[MSD_RADIX];
@@ -407,25 +414,20 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_scatter2_kernel(const W* __re
   const int off = (tid >> 6) * (RUA_WAVE * MSD_ITEMS) + (tid & (RUA_WAVE - 1));
   int digit[MSD_ITEMS];
   bool live[MSD_ITEMS];
-  unsigned int val[MSD_ITEMS];
+  W val[MSD_ITEMS];
 #pragma unroll
   for (int u = 0; u < MSD_ITEMS; ++u) {
     const int q = off + u * RUA_WAVE;
     live[u] = q < n_here;
-    const uint64_t wd = live[u] ? (uint64_t)words[first + q] : 0ull;
-    digit[u] = (int)(wd >> G.row_bits);
-    val[u] = (unsigned int)(wd & row_mask);
+    val[u] = live[u] ? words[first + q] : (W)0;
+    digit[u] = (int)((uint64_t)val[u] >> G.row_bits);
   }
-  msd_rank_and_stage<unsigned int>(digit, live, val, G.lo_bits, stage, wcnt, dstart, wave_tot);
+  msd_rank_and_stage<W>(digit, live, val, G.lo_bits, stage, wcnt, dstart, wave_tot);
   if (tid < radix) delta[tid] = table2[((int64_t)s_seg[bin] << G.lo_bits) + (int64_t)tid * nseg + j] - (unsigned int)dstart[tid];
   __syncthreads();
   for (int q = tid; q < n_here; q += MSD_THREADS) {
-    int lo = 0, hi = radix;
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if ((int)dstart[mid] <= q) lo = mid; else hi = mid;
-    }
-    perm[(int64_t)(unsigned int)(delta[lo] + (unsigned int)q)] = (int64_t)stage[q];
+    const uint64_t wd = (uint64_t)stage[q];
+    perm[(int64_t)(unsigned int)(delta[(int)(wd >> G.row_bits)] + (unsigned int)q)] = (int64_t)(wd & row_mask);
   }
 }
 
