@@ -109,9 +109,9 @@ def run(timed: bool):
             fn()
         e1.record()
         torch.cuda.synchronize()
+        ta.get_mask(tiny)                        # ... marker: what follows (the next group's set-up) is not counted
         order.append(name)
         times[name] = {'algorithmic_bytes': nbytes, 'ms_per_call': e0.elapsed_time(e1) / REPS}
-    ta.get_mask(tiny)
     torch.cuda.synchronize()
     if timed:
         print(json.dumps({'order': order, 'ops': times}, indent=1))
@@ -138,8 +138,8 @@ def cut(rows, order):
     out, cur, gi = {}, None, -1
     for name, v in rows:
         if MARK in name:
-            gi += 1                                  # even marker: a warm-up follows; odd marker: the counted launches
-            cur = order[gi // 2] if gi % 2 == 1 and gi // 2 < len(order) else None
+            gi += 1                                  # three markers per group: warm-up | the counted launches | set-up
+            cur = order[gi // 3] if gi % 3 == 1 and gi // 3 < len(order) else None
             if cur is not None:
                 out[cur] = collections.defaultdict(float)
             continue

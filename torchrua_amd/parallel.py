@@ -109,7 +109,9 @@ def plan_rank_cpus(local_rank: int, local_world: int, allowed: List[int], gpu_no
             # SMT siblings are usually listed in the second half of a node's cpulist: deal the first half (one thread
             # per core) out first, then the siblings, so that every rank gets whole cores
             half = len(mine) // 2
-            if half >= len(peers) and half % len(peers) == 0:
+            if half >= len(peers):
+                # (a rank count that does not divide the cores leaves the remainder idle rather than splitting a
+                # core's two threads between two ranks: six ranks on a 64-core node take 10 cores each)
                 per = half // len(peers)
                 return sorted(mine[k * per:(k + 1) * per] + mine[half + k * per:half + (k + 1) * per])
             return mine[k * share:(k + 1) * share]
