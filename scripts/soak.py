@@ -118,6 +118,34 @@ while time.time() < t_end:
                 r = data.clone().to(DEV).requires_grad_(True)
                 torch.stack([t_.logsumexp(0) for t_ in torch.split(r, lens.tolist())]).backward(cot)
                 torch.testing.assert_close(x.grad, r.grad, rtol=1e-4, atol=1e-5)
+        if dtype == torch.int64 and N * H < 4e6:
+            # scatter_* on integer tensors (reduce.py:6-23), bit-exact against the oracle's restatement of ATen's fold
+            idt = [torch.int64, torch.int32, torch.int16, torch.int8, torch.uint8][int(rng.randint(0, 5))]
+            info = torch.iinfo(idt)
+            ten = torch.randint(max(info.min, -50), min(info.max, 50) + 1, (B, H), generator=g).to(idt)
+            index = torch.repeat_interleave(torch.arange(B), lens)
+            perm = torch.randperm(N, generator=g)
+            src = data.clamp(info.min, info.max).to(idt)[perm]
+            for name in ('sum', 'max', 'min', 'prod', 'mean'):
+                for inc in (False, True):
+                    ref = getattr(orc, f'scatter_{name}')(ten.numpy(), index[perm].numpy(), src.numpy(), include_self=inc)
+                    got = getattr(ta, f'scatter_{name}')(ten.to(DEV), index[perm].to(DEV), src.to(DEV), include_self=inc)
+                    assert np.array_equal(to_np(got), ref), f'integer scatter_{name} {idt} include_self={inc}'
+        # the bucket builder itself against a stable sort, at destination counts on both sides of every path switch
+        # (one LSD pass up to 512, the two-level MSD builder up to 262 144, LSD passes beyond), out-of-range entries too
+        from torchrua_amd import _ops as O
+        S2 = int(rng.choice([1, 2, 300, 512, 513, 4096, 65536, 70000, 262144, 262145, 300000]))
+        M2 = int(rng.choice([1, 100, 4095, 4097, 8193, 50000, 400000]))
+        idx2 = torch.randint(-1, S2 + 1, (M2,), generator=g)
+        if rng.randint(0, 3) == 0:
+            idx2[::3] = int(rng.randint(0, S2))            # a heavy destination
+        idx2 = idx2.to(DEV)
+        counts2, perm2 = O.index_buckets(idx2, S2)
+        ok2 = (idx2 >= 0) & (idx2 < S2)
+        order2 = torch.sort(torch.where(ok2, idx2, torch.full_like(idx2, S2)), stable=True)[1]
+        n_ok2 = int(ok2.sum())
+        assert torch.equal(perm2[:n_ok2], order2[:n_ok2]), f'index_buckets perm S={S2} M={M2}'
+        assert torch.equal(counts2, torch.bincount(idx2[ok2], minlength=S2)), f'index_buckets counts S={S2} M={M2}'
     except Exception:
         print('FAILED at', tag)
         raise

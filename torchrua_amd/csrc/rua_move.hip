@@ -27,7 +27,11 @@ constexpr int MOVE_TILE = MOVE_BLOCK;               // one lane per row in phase
 constexpr int TILE_ROWS = 256;                      // the (rank x time) tile of pack_tile_kernel: 16 x 16
 constexpr int UNROLL = RUA_MOVE_UNROLL;             // row groups in flight per wave in phase 2
 constexpr int64_t MOVE_TILE_BYTES = 16 << 10;       // destination bytes one workgroup takes (rows: a power of two, 4..256)
-constexpr int64_t MOVE_SPAN_MIN_TILES = 2048;       // launches at least this large give every XCD one contiguous span
+constexpr int64_t MOVE_SPAN_MIN_TILES = 2048;       // launches at least this large give every XCD one contiguous span ...
+constexpr int64_t MOVE_SPAN_MIN_TILES_DENSE = 1 << 19;   // ... when the destination is padded (two thirds of a pad's
+// traffic is stores, and a span per XCD is worth 11-13 % to them at every size measured); a gather into a dense
+// destination (C / P) only draws level from ~8 GB up and LOSES 2-5 % below (cfg2's 0.5 GB: 183 -> 173 us with plain
+// blockIdx order; gpurun_out/r4j/midsize_ab.txt, r4k/span_ab.txt -> profiles/r04_span_ab.txt)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -564,7 +568,8 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
   const bool tail8 = vec == 8 && (row_bytes & 15) == 8 && row_bytes >= 24 && !(flags & RUA_MOVE_NO_TAIL8);
   if (vec != 16) tile_rows = tile_rows <= 16 ? 16 : tile_rows <= 64 ? 64 : MOVE_TILE;
   const int64_t nr = dst->n_rows;
-  bool xcd_span = (nr + tile_rows - 1) / tile_rows >= MOVE_SPAN_MIN_TILES;
+  const bool padded_dst = dst->kind == RUA_LEFT || dst->kind == RUA_RIGHT;
+  bool xcd_span = (nr + tile_rows - 1) / tile_rows >= (padded_dst ? MOVE_SPAN_MIN_TILES : MOVE_SPAN_MIN_TILES_DENSE);
   if (flags & RUA_MOVE_XCD_SPAN_ON) xcd_span = true;
   if (flags & RUA_MOVE_XCD_SPAN_OFF) xcd_span = false;
   if (flags & RUA_MOVE_SCATTER)
