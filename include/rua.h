@@ -285,6 +285,12 @@ int rua_index_buckets(const int64_t* index, int64_t M, int64_t S, int64_t* count
  * on different threads (n_threads >= 1, the caller included).  The Python layer verifies the equality against
  * torch.sort itself at first use and otherwise keeps making the reference's call. */
 int rua_host_sort_desc(const int64_t* keys, int64_t n, int64_t* sorted_indices, int32_t n_threads);
+/* The same sort on a helper thread (ABI 4): `begin` returns at once, `end` waits for the job and returns its code;
+ * keys / sorted_indices must stay valid in between, one job at a time (RUA_EINVAL if one is already posted, or if `end`
+ * finds none).  pack() with device-only lengths uses the interval for the rest of its host work (core/view.py:47-58:
+ * batch_sizes, the offset scans), because the GPU idles until the order is known. */
+int rua_host_sort_desc_begin(const int64_t* keys, int64_t n, int64_t* sorted_indices, int32_t n_threads);
+int rua_host_sort_desc_end(void);
 /* diagnostics for the tests: how many segments, over all calls so far, exhausted the introsort's depth budget and
  * were heap-sorted (the branch a random input never reaches; tests/golden/sort_killer.npy does) */
 int64_t rua_host_sort_heap_segments(void);
@@ -292,6 +298,13 @@ int64_t rua_host_sort_heap_segments(void);
 /* batch_sizes[t] = #{b : lens[b] > t}, t < T — the CPU tensor PackedSequence mandates
  * (core/view.py:55: get_mask(self).sum(dim=0).cpu()), from the host copy of the lengths. */
 int rua_host_batch_sizes(const int64_t* lens, int64_t B, int64_t T, int64_t* batch_sizes);
+
+/* The two exclusive scans pack() needs next to batch_sizes (layout/pack.py:43-45 `offsets()`, utils.py:16-19), on the
+ * host: boff[t] = sum of batch_sizes[< t], off[b] = sum of lens[< b] (either may be NULL).  With device-only lengths
+ * the host computes them while the order is being sorted and uploads them with it (one launch less in front of the
+ * mover); with a host mirror of the lengths they are derived on the device (rua_pack_prepare). */
+int rua_host_pack_scans(const int64_t* lens, int64_t B, const int64_t* batch_sizes, int64_t T, int64_t* boff,
+                        int64_t* off);
 
 /* Introspection: ABI version and the gfx target the code objects were built for. */
 int rua_abi_version(void);

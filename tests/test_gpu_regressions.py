@@ -445,7 +445,8 @@ def test_two_host_threads_share_one_stream():
         lens = torch.randint(0, 9, (1500 + 700 * k,), generator=g)          # a third of the segments empty-ish
         lens[::3] = 0
         data = torch.randn(int(lens.sum()), 16, generator=g)
-        pl = torch.randint(1, 40, (1200 + 900 * k,), generator=g)          # >= 1 024 lengths: the side-stream upload
+        pl = torch.randint(1, 40, (1200 + 4900 * k,), generator=g)         # >= 1 024 lengths: the side-stream upload;
+                                                                            # the second case >= 4 096: the sort on the helper thread
         pd = torch.randn(int(pl.sum()), 8, generator=g)
         exp_max = orc.segment_max(data.numpy(), lens.numpy())
         exp_pack = orc.to_pack(orc.C(pd.numpy(), pl.numpy()), host_sort(pl))
@@ -471,3 +472,31 @@ def test_two_host_threads_share_one_stream():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_pack_with_device_only_lengths_overlaps_the_host_sort():
+    """C(data, token_sizes_on_device).pack() with >= 4 096 sequences sorts on the library's helper thread while the
+    calling thread derives batch_sizes and both offset scans on the host (core._pack_meta_overlapped): the same
+    PackedSequence, bit for bit, as with host-known lengths and as the oracle's; ties beyond the 16-element leaf; zero
+    lengths; a second pack() of the same container is served from the memo; the next op (P -> C, reduce) sees the
+    metadata the overlapped path uploaded."""
+    g = torch.Generator().manual_seed(77)
+    for B, hi in ((4096, 3), (5000, 40), (70001, 9)):
+        lens = torch.randint(0, hi + 1, (B,), generator=g)
+        lens[B // 2] = hi
+        N = int(lens.sum())
+        data = torch.randn(N, 4, generator=g)
+        want = orc.to_pack(orc.C(data.numpy(), lens.numpy()), host_sort(lens))
+        c = ta.C(data.to(DEV), lens.to(DEV))
+        p = c.pack()
+        assert_same_seq(p, want, f'pack B={B}')
+        assert c.pack().data is not p.data and torch.equal(c.pack().data, p.data)
+        assert torch.equal(c.pack().sorted_indices, p.sorted_indices)            # memo: the same tensors
+        ref = ta.with_host_sizes(data.to(DEV), lens).pack()
+        assert torch.equal(ref.data, p.data) and torch.equal(ref.unsorted_indices, p.unsorted_indices)
+        assert torch.equal(ref.batch_sizes, p.batch_sizes)
+        assert torch.equal(p.cat().data.cpu(), data)
+        np.testing.assert_allclose(ta.reduce_sum(p).cpu().numpy(), orc.segment_sum(data.numpy(), lens.numpy()), rtol=1e-5, atol=1e-5)
+        # a container whose lengths are a strided view (not contiguous int64): normalised first, offsets not memoised on it
+        wide = torch.stack([lens, lens], 1).to(DEV)[:, 0]
+        assert_same_seq(ta.C(data.to(DEV), wide).pack(), want, f'pack strided lens B={B}')

@@ -134,3 +134,33 @@ def test_host_sort_under_sanitizers(tmp_path, sanitizer):
     assert out.returncode == 0 and 'mismatches 0' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
     assert 'WARNING: ThreadSanitizer' not in out.stderr and 'ERROR: AddressSanitizer' not in out.stderr \
         and 'runtime error' not in out.stderr, out.stderr[-4000:]
+
+
+def test_async_sort_is_the_same_sort():
+    """rua_host_sort_desc_begin / _end (the sort on the library's helper thread, so that pack() with device-only lengths
+    can do the rest of its host work meanwhile): the same permutation as the synchronous call and as torch.sort, one job
+    at a time, and rua_host_pack_scans next to it."""
+    from torchrua_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(9)
+    assert lib.rua_host_sort_desc_end() == -1                              # no job posted
+    for n, hi in ((1, 5), (17, 2), (5000, 3), (65536, 512), (100000, 1 << 40)):
+        keys = torch.randint(0, hi + 1, (n,), generator=g)
+        out = torch.empty_like(keys)
+        assert lib.rua_host_sort_desc_begin(keys.data_ptr(), n, out.data_ptr(), 4) == 0
+        assert lib.rua_host_sort_desc_begin(keys.data_ptr(), n, out.data_ptr(), 4) == -1      # busy
+        # the caller's share of the interval: batch_sizes and the two scans
+        T = int(keys.max()) if hi < 100000 else 0
+        bsz = torch.empty(T, dtype=torch.long)
+        boff, off = torch.empty(T, dtype=torch.long), torch.empty(n, dtype=torch.long)
+        if T:
+            assert lib.rua_host_batch_sizes(keys.data_ptr(), n, T, bsz.data_ptr()) == 0
+        assert lib.rua_host_pack_scans(keys.data_ptr(), n, bsz.data_ptr() if T else None, T, boff.data_ptr() if T else None,
+                                       off.data_ptr()) == 0
+        assert lib.rua_host_sort_desc_end() == 0
+        assert torch.equal(out, torch.sort(keys, descending=True)[1]), n
+        assert torch.equal(off, torch.cumsum(keys, 0) - keys)
+        if T:
+            assert torch.equal(bsz, (keys[None, :] > torch.arange(T)[:, None]).sum(1))
+            assert torch.equal(boff, torch.cumsum(bsz, 0) - bsz)
+    assert lib.rua_host_sort_desc_end() == -1

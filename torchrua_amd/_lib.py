@@ -79,8 +79,11 @@ SYMBOLS = {
     'rua_bucket_ws_elems': (c_int64, [c_int64, c_int64]),
     'rua_index_buckets': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rua_host_sort_desc': (c_int, [c_void_p, c_int64, c_void_p, c_int32]),
+    'rua_host_sort_desc_begin': (c_int, [c_void_p, c_int64, c_void_p, c_int32]),
+    'rua_host_sort_desc_end': (c_int, []),
     'rua_host_sort_heap_segments': (c_int64, []),
     'rua_host_batch_sizes': (c_int, [c_void_p, c_int64, c_int64, c_void_p]),
+    'rua_host_pack_scans': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     'rua_abi_version': (c_int, []),
     'rua_build_target': (c_char_p, []),
 }

@@ -324,6 +324,18 @@ def _host_sort_decide() -> int:
         return best
 
 
+def host_sort_threads() -> int:
+    """Threads the library's reproduction of the host sort runs on (0: the reference's own torch.sort is kept)."""
+    global _host_sort_threads
+    if _host_sort_threads is None:
+        _host_sort_threads = _host_sort_decide()
+    return _host_sort_threads
+
+
+def host_sort_is_native() -> bool:
+    return host_sort_threads() >= 1
+
+
 def host_sort_desc(host: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """sorted_indices = torch.sort(host, descending=True)[1] (core/view.py:48) — the same permutation, tie order
     included — into `out` if given (e.g. a pinned staging slot)."""

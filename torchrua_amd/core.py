@@ -6,6 +6,7 @@ destination rows are enumerated in storage order, each row finds its source row 
 padding is written in the same pass (the reference pre-fills with new_full and then scatters:
 core/view.py:34-38 + core/cast.py:19-23).
 """
+import threading
 from numbers import Number
 from typing import Any, List, Tuple, Union
 
@@ -78,6 +79,11 @@ def _pack_meta(token_sizes: Tensor, dev: torch.device):
     read_back = token_sizes.is_cuda and M._memo_get(token_sizes, 'host') is None      # device-only lengths: a sync now
     host = M.host_lens(token_sizes)
     B = lens.numel()
+    if read_back and B >= 4096 and M.host_sort_is_native():
+        meta = _pack_meta_overlapped(token_sizes, lens, host, dev)
+        M._memo_put(token_sizes, key, (meta, tuple(M._version(t) for t in meta)))
+        M._memo_put(meta[0], 'reference_order', True)
+        return (lens,) + meta
     sorted_indices = M.sorted_indices_to_device(host, dev, stream_idle=read_back)
     T = M.max_len(token_sizes)
     batch_sizes = M.batch_sizes_from_host_lens(host, T)
@@ -98,6 +104,54 @@ def _pack_meta(token_sizes: Tensor, dev: torch.device):
     M._memo_put(token_sizes, key, (meta, tuple(M._version(t) for t in meta)))
     M._memo_put(sorted_indices, 'reference_order', True)        # (pack_reference_order below)
     return (lens,) + meta
+
+
+_sort_job = threading.Lock()
+
+
+def _pack_meta_overlapped(token_sizes: Tensor, lens: Tensor, host: Tensor, dev: torch.device):
+    """_pack_meta for DEVICE-ONLY lengths (the reference's own constructor signature: C(data, token_sizes_on_device)).
+    The read-back has just synchronised the stream and the GPU idles until the mover is launched, so every host
+    microsecond from here to that launch shows (profiles/r03_devlens_probe.txt: 0.41 ms per pack(), the sort 0.22 of
+    them).  The sort therefore runs on the library's helper thread (rua_host_sort_desc_begin) WHILE this thread does the
+    rest — batch_sizes, both offset scans (on the host here: the order is not needed for them, so the device-side
+    rua_pack_prepare launch disappears from the critical path), the allocations — and everything goes up in two async
+    copies; only the inverse permutation is left to a (tiny) launch."""
+    lib = K.load()
+    B = lens.numel()
+    staged_order = torch.empty(B, dtype=torch.long, pin_memory=True)
+    _sort_job.acquire()            # the helper takes one job at a time (ctypes drops the GIL: another host thread may be here)
+    try:
+        K.check(lib.rua_host_sort_desc_begin(host.data_ptr(), B, staged_order.data_ptr(), M.host_sort_threads()),
+                'rua_host_sort_desc_begin')
+    except BaseException:
+        _sort_job.release()
+        raise
+    try:
+        T = M.max_len(token_sizes)
+        batch_sizes = M.batch_sizes_from_host_lens(host, T)
+        need_off = M._memo_get(token_sizes, 'off') is None and lens is token_sizes
+        staged = torch.empty(2 * T + B, dtype=torch.long, pin_memory=True)      # batch_sizes | their offsets | offsets of the lengths
+        staged[:T].copy_(batch_sizes)
+        K.check(lib.rua_host_pack_scans(host.data_ptr(), B, batch_sizes.data_ptr(), T, staged.data_ptr() + 8 * T,
+                                        staged.data_ptr() + 16 * T if need_off else None), 'rua_host_pack_scans')
+        unsorted = torch.empty(B, dtype=torch.long, device=dev)
+        sorted_indices = torch.empty(B, dtype=torch.long, device=dev)
+        buf = torch.empty(2 * T + B, dtype=torch.long, device=dev)
+    finally:
+        rc = lib.rua_host_sort_desc_end()          # (always: the helper must be idle again whatever happened above)
+        _sort_job.release()
+    K.check(rc, 'rua_host_sort_desc_end')
+    sorted_indices.copy_(staged_order, non_blocking=True)
+    if need_off:
+        buf.copy_(staged, non_blocking=True)
+    else:
+        buf[:2 * T].copy_(staged[:2 * T], non_blocking=True)
+    bsz_dev, boff, off = buf[:T], buf[T:2 * T], buf[2 * T:]
+    K.check(lib.rua_pack_meta(None, K.ptr(sorted_indices), B, 0, K.ptr(unsorted), None, K.stream_ptr(dev)), 'rua_pack_meta')
+    if need_off:
+        M._memo_put(token_sizes, 'off', off)
+    return (sorted_indices, unsorted, batch_sizes, bsz_dev, boff)
 
 
 def pack_reference_order(p: P):

@@ -46,7 +46,8 @@ struct KV8 { int32_t key; uint32_t idx; };
 template <typename KV> inline bool before(const KV& a, const KV& b) { return a.key > b.key; }   // descending, key only
 
 constexpr int64_t LEAF = 16;          // segments up to this size are left to the insertion sort
-constexpr int64_t SPAWN_MIN = 4096;   // right halves at least this long become tasks of their own
+// right halves at least this long become tasks of their own (RUA_HOST_SORT_SPAWN_MIN: developer knob for A/B runs)
+const int64_t SPAWN_MIN = [] { const char* e = std::getenv("RUA_HOST_SORT_SPAWN_MIN"); const int64_t v = e ? atoll(e) : 0; return v >= 64 ? v : (int64_t)4096; }();
 
 inline int64_t floor_log2(int64_t n) { int64_t l = 0; while (n > 1) { n >>= 1; ++l; } return l; }
 
@@ -414,6 +415,89 @@ int rua_host_sort_desc(const int64_t* keys, int64_t n, int64_t* sorted_indices, 
 
 int64_t rua_host_sort_heap_segments(void) { return g_heap_segments.load(); }
 
+}  // extern "C"
+
+namespace {
+// rua_host_sort_desc on a helper thread: pack() with device-only lengths leaves the GPU idle from the read-back of the
+// lengths until the mover is launched, and the sort is half of that interval — so everything else the host has to do in
+// it (batch_sizes, the offset scans, allocations, descriptors) runs on the calling thread WHILE the pool sorts.
+// One job at a time; the helper sleeps between jobs.
+class AsyncSort {
+ public:
+  static AsyncSort& get() {
+    static AsyncSort* a = new AsyncSort();    // never destroyed: no join at process exit
+    return *a;
+  }
+  int begin(const int64_t* keys, int64_t n, int64_t* out, int32_t threads) {
+    std::unique_lock<std::mutex> g(m_);
+    if (state_.load(std::memory_order_acquire) != IDLE) return RUA_EINVAL;     // a job is already posted
+    if (!started_) {
+      std::thread([this] { loop(); }).detach();
+      started_ = true;
+    }
+    keys_ = keys; n_ = n; out_ = out; threads_ = threads;
+    state_.store(POSTED, std::memory_order_release);
+    cv_.notify_all();
+    return 0;
+  }
+  int end() {
+    if (state_.load(std::memory_order_acquire) == IDLE) return RUA_EINVAL;
+    // the job lasts ~0.2 ms and the caller arrives towards its end: spin briefly, then give the core away
+    for (int spins = 0; state_.load(std::memory_order_acquire) != DONE; ++spins) {
+      if (spins < 20000) {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+      } else {
+        std::this_thread::yield();
+      }
+    }
+    const int rc = rc_;
+    state_.store(IDLE, std::memory_order_release);
+    return rc;
+  }
+  void forget_after_fork() {
+    new (&m_) std::mutex();
+    new (&cv_) std::condition_variable();
+    started_ = false;
+    state_.store(IDLE);
+  }
+
+ private:
+  enum { IDLE = 0, POSTED = 1, RUNNING = 2, DONE = 3 };
+  AsyncSort() { pthread_atfork(nullptr, nullptr, [] { AsyncSort::get().forget_after_fork(); }); }
+  void loop() {
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return state_.load(std::memory_order_acquire) == POSTED; });
+        state_.store(RUNNING, std::memory_order_release);
+      }
+      rc_ = rua_host_sort_desc(keys_, n_, out_, threads_);
+      state_.store(DONE, std::memory_order_release);
+    }
+  }
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::atomic<int> state_{IDLE};
+  bool started_ = false;
+  const int64_t* keys_ = nullptr;
+  int64_t n_ = 0;
+  int64_t* out_ = nullptr;
+  int32_t threads_ = 1;
+  int rc_ = 0;
+};
+}  // namespace
+
+extern "C" {
+
+int rua_host_sort_desc_begin(const int64_t* keys, int64_t n, int64_t* sorted_indices, int32_t n_threads) {
+  if (n < 0 || (n > 0 && (!keys || !sorted_indices))) return RUA_EINVAL;
+  return AsyncSort::get().begin(keys, n, sorted_indices, n_threads);
+}
+
+int rua_host_sort_desc_end(void) { return AsyncSort::get().end(); }
+
 int rua_host_batch_sizes(const int64_t* lens, int64_t B, int64_t T, int64_t* batch_sizes) {
   if (B < 0 || T < 0 || (B > 0 && !lens) || (T > 0 && !batch_sizes)) return RUA_EINVAL;
   if (T == 0) return 0;
@@ -431,6 +515,18 @@ int rua_host_batch_sizes(const int64_t* lens, int64_t B, int64_t T, int64_t* bat
     at_most += batch_sizes[t];
     batch_sizes[t] = B - at_most;
   }
+  return 0;
+}
+
+int rua_host_pack_scans(const int64_t* lens, int64_t B, const int64_t* batch_sizes, int64_t T, int64_t* boff,
+                        int64_t* off) {
+  if (B < 0 || T < 0 || (B > 0 && !lens) || (T > 0 && !batch_sizes)) return RUA_EINVAL;
+  int64_t run = 0;
+  if (boff)
+    for (int64_t t = 0; t < T; ++t) { boff[t] = run; run += batch_sizes[t]; }
+  run = 0;
+  if (off)
+    for (int64_t b = 0; b < B; ++b) { off[b] = run; run += lens[b]; }
   return 0;
 }
 
