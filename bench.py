@@ -475,6 +475,7 @@ def main():
                        'cpus_of_rank0': len(my_cpus), 'torch_threads_rank0': torch.get_num_threads(),
                        'numa_node_of_rank0_gpu': _gpu_numa_node(dev),
                        'host_sort': os.environ.get('RUA_HOST_SORT', 'self-tuned'),
+                       'host_sort_threads_rank0': _meta.host_sort_threads(),
                        'backend': (os.environ.get('RUA_BENCH_BACKEND', 'nccl') + (' (RCCL)' if os.environ.get('RUA_BENCH_BACKEND', 'nccl') == 'nccl' else '')) if use_dist else None},
             'per_rank': [{'rank': r, 'rows': int(row[0]), 'ms_per_step': round(row[1] / args.steps * 1e3, 4),
                           'pack_kernel_GBps': round((2.0 * row[0] * H * e + 8.0 * (3 * B + T)) / (row[2] * 1e-3) / 1e9, 1) if row[2] else None,

@@ -270,10 +270,13 @@ int rua_fill_empty(const rua_layout* lay, void* out, int64_t H, int32_t dtype, i
                    void* extreme, const void* data, const int64_t* perm, void* stream);
 
 /* Bucket `index` (values in [0,S); others are ignored): counts[S], off[S] (exclusive scan) and perm[M] such that
- * perm[off[s] .. off[s]+counts[s]) are the rows i with index[i] == s IN ASCENDING ORDER — a stable LSD radix sort
- * of packed (destination, row) words on the destination (<= 9-bit digits), deterministic for any fan-in;
- * needs bits(S) + bits(M) <= 62 (RUA_ERANGE otherwise).  `ws` holds rua_bucket_ws_elems(M, S) int64.
- * Feeds rua_segment_reduce(perm=..) for scatter_* (reduce.py:6-31). */
+ * perm[off[s] .. off[s]+counts[s]) are the rows i with index[i] == s IN ASCENDING ORDER — a stable radix sort on the
+ * destination, deterministic for any fan-in.  513 .. 262 144 destinations with M < 2^31 (ABI 4): most significant
+ * digit first in two levels, the second local to a bin, 32-bit words where (low digit, row) fit them
+ * (rua_bucket_msd.hip; entries whose index is out of range are dropped and the tail of `perm` behind the valid
+ * entries is left unwritten); otherwise least significant digit first over packed (destination, row) words with
+ * <= 9-bit digits (rua_scatter.hip; needs bits(S) + bits(M) <= 62, RUA_ERANGE otherwise).  `ws` holds
+ * rua_bucket_ws_elems(M, S) int64.  Feeds rua_segment_reduce(perm=..) for scatter_* (reduce.py:6-31). */
 int64_t rua_bucket_ws_elems(int64_t M, int64_t S);
 int rua_index_buckets(const int64_t* index, int64_t M, int64_t S, int64_t* counts, int64_t* off,
                       int64_t* perm, int64_t* ws, void* stream);

@@ -354,7 +354,7 @@ __device__ __forceinline__ void tile_phase1(const rua_layout& Pk, const rua_layo
 // rows: pack 3.5 -> 4.0 TB/s against a 4x4 sub-tile walk without staging).  Rows of 128 B and more take the generic
 // mover: since round 2 (16 KiB tiles, cooperative row resolution) it is the faster one there — 5.5 / 5.8 TB/s for
 // C->P / P->C at 128 B against 5.3 / 5.2 for the tile kernels; at 64 B the tiles win 4.8 to 3.2, at 32 B 3.9 to 1.6
-// (scripts/narrow_ab.py).
+// (a round-2 A/B, profiles/r02_width_sweep.txt).
 template <int VEC, bool TO_PACK>
 __global__ __launch_bounds__(RUA_BLOCK) void pack_tile_lds_kernel(rua_layout Pk, rua_layout Ot, char* __restrict__ dst,
                                                               const char* __restrict__ src, int64_t row_bytes,
