@@ -48,7 +48,8 @@ enum rua_kind { RUA_CAT = 0, RUA_LEFT = 1, RUA_PACK = 2, RUA_RIGHT = 3, RUA_LIST
 
 typedef struct rua_layout {
   int32_t kind;            /* enum rua_kind */
-  int32_t reserved;
+  int32_t tile_t_log2;     /* PACK with a tile table (below): bits 0-7 log2 of the time steps per tile (4 .. 6),
+                              bits 8-15 log2 of the ranks per tile (4); a zero field = 4 (ABI <= 3: 16 x 16) */
   int64_t n_rows;          /* storage rows: CAT/PACK: sum(len); LEFT/RIGHT: B*T_phys; LIST: M */
   int64_t B;               /* number of sequences */
   int64_t T_phys;          /* LEFT/RIGHT: rows per sequence in storage (data.size(1)) */
@@ -69,8 +70,8 @@ typedef struct rua_layout {
   /* PACK, optional: a (rank x time) tile table that lets narrow-row C/L/R <-> P transposes move
    * multi-row runs on BOTH sides (rua_move_rows picks it up when rows are <= 64 bytes) .        */
   const int64_t* bsz;        /* device copy of batch_sizes [T]                                   */
-  const int64_t* tile_start; /* [n_tchunks + 1]: tile_start[c] = sum_{c'<c} ceil(batch_sizes[16c']/16) */
-  int64_t n_tchunks;         /* ceil(T / 16)                                                     */
+  const int64_t* tile_start; /* [n_tchunks + 1]: tile_start[c] = sum_{c'<c} ceil(batch_sizes[TT*c']/TR) (TT time steps, TR ranks per tile) */
+  int64_t n_tchunks;         /* ceil(T / TT)                                                     */
   int64_t n_tiles;           /* tile_start[n_tchunks] (the caller knows it: batch_sizes is a host tensor) */
 } rua_layout;
 

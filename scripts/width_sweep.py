@@ -25,7 +25,7 @@ def timeit(fn, iters=5):
 
 
 print(f'{"H":>6} {"row B":>6} {"B":>8} {"N":>10} | {"pack ms":>8} {"TB/s":>6} | {"P.cat ms":>8} {"TB/s":>6} | {"reduce(P)":>9} {"TB/s":>6} | {"seg_sum":>8} {"TB/s":>6} | {"roll(P)":>8} {"TB/s":>6}')
-for H in (16, 32, 64, 128, 256, 512, 1024, 2048):
+for H in ([int(a) for a in sys.argv[1:]] or (16, 32, 64, 128, 256, 512, 1024, 2048)):
     rows = int(8e9 / (H * 2))
     B = max(1024, rows // 260)
     g = torch.Generator().manual_seed(H)

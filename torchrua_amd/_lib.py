@@ -38,7 +38,7 @@ INT_DTYPES = {torch.int64: I64, torch.int32: I32, torch.int16: I16, torch.int8: 
 class RuaLayout(Structure):
     """struct rua_layout (include/rua.h)."""
     _fields_ = [
-        ('kind', c_int32), ('reserved', c_int32),
+        ('kind', c_int32), ('tile_t_log2', c_int32),
         ('n_rows', c_int64), ('B', c_int64), ('T_phys', c_int64), ('T_log', c_int64),
         ('lens', c_void_p), ('len_add', c_int64), ('off', c_void_p),
         ('boff', c_void_p), ('T', c_int64), ('sorted', c_void_p), ('unsorted', c_void_p),

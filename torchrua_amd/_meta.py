@@ -425,34 +425,44 @@ def lay_padded(kind: int, lens: Optional[Tensor], B: int, T_phys: int, T_log: in
     return lay
 
 
-TILE_R, TILE_T = 16, 16     # (rank x time) tile of the narrow-row pack kernel
 NARROW_ROW_BYTES = 64      # rows up to this get the tile table (rua_move.hip: TILE_MAX_ROW_BYTES)
+
+
+def tile_shape_log2(row_bytes: int) -> Tuple[int, int]:
+    """(log2 time steps, log2 ranks) of a (rank x time) tile by row width (rua_move.hip: pack_tile_lds_kernel)."""
+    knob = os.environ.get('RUA_TILE_LOG2')            # developer A/B: "<ttl>,<trl>" for every narrow row width
+    if knob:
+        ttl, trl = knob.split(',')
+        return int(ttl), int(trl)
+    return (6 if row_bytes <= 16 else 5 if row_bytes <= 32 else 4), 4
 
 
 class PackTiling:
     """Tile table for the narrow-row C/L/R <-> P kernel, derived on the host from batch_sizes (a CPU tensor by
-    PackedSequence's contract): tile_start[c] = number of 16-rank tiles before time chunk c."""
-    __slots__ = ('bsz', 'tile_start', 'n_tchunks', 'n_tiles')
+    PackedSequence's contract): tile_start[c] = number of rank tiles before time chunk c (chunks of 1 << ttl steps,
+    tiles of 1 << trl ranks)."""
+    __slots__ = ('bsz', 'tile_start', 'n_tchunks', 'n_tiles', 'code')
 
-    def __init__(self, batch_sizes: Tensor, bsz_dev: Tensor, dev: torch.device):
+    def __init__(self, batch_sizes: Tensor, bsz_dev: Tensor, dev: torch.device, ttl: int, trl: int):
         # numpy on the (CPU, by PackedSequence's contract) batch_sizes: a handful of torch CPU ops on a few dozen
         # elements cost ~30 us EACH on the GPU box's 128-thread host build
-        counts = (batch_sizes.numpy()[::TILE_T] + (TILE_R - 1)) // TILE_R
+        counts = (batch_sizes.numpy()[::1 << ttl] + ((1 << trl) - 1)) >> trl
         start = np.zeros(counts.size + 1, dtype=np.int64)
         np.cumsum(counts, out=start[1:])
         self.n_tchunks = int(counts.size)
         self.n_tiles = int(start[-1])
         self.tile_start = to_device_async(torch.from_numpy(start), dev)
         self.bsz = bsz_dev
+        self.code = ttl | (trl << 8)
 
 
-def pack_tiling(p) -> 'PackTiling':
+def pack_tiling(p, ttl: int, trl: int) -> 'PackTiling':
     dev = p.data.device
-    key = f'tiling:{dev}'
+    key = f'tiling:{dev}:{ttl}:{trl}'
     hit = _memo_get(p.batch_sizes, key)
     if hit is not None:
         return hit
-    return _memo_put(p.batch_sizes, key, PackTiling(p.batch_sizes, pack_bsz_dev(p), dev))
+    return _memo_put(p.batch_sizes, key, PackTiling(p.batch_sizes, pack_bsz_dev(p), dev, ttl, trl))
 
 
 def lay_pack(p, lens: Optional[Tensor] = None, len_add: int = 0, boff: Optional[Tensor] = None,
@@ -468,9 +478,10 @@ def lay_pack(p, lens: Optional[Tensor] = None, len_add: int = 0, boff: Optional[
         keep.append(bsz)
         extra['bsz'] = L.ptr(bsz)
     if row_bytes is not None and 0 < row_bytes <= NARROW_ROW_BYTES and T == p.batch_sizes.numel() and len_add == 0:
-        t = pack_tiling(p)       # narrow rows: hand the (rank x time) tile table to the mover
+        t = pack_tiling(p, *tile_shape_log2(row_bytes))       # narrow rows: hand the (rank x time) tile table to the mover
         keep += [t.bsz, t.tile_start]
-        extra.update(bsz=L.ptr(t.bsz), tile_start=L.ptr(t.tile_start), n_tchunks=t.n_tchunks, n_tiles=t.n_tiles)
+        extra.update(bsz=L.ptr(t.bsz), tile_start=L.ptr(t.tile_start), n_tchunks=t.n_tchunks, n_tiles=t.n_tiles,
+                     tile_t_log2=t.code)
     lay = Lay(keep, max_len=T, kind=L.PACK, n_rows=n_rows, B=pack_nseq(p),
               lens=L.ptr(lens), len_add=len_add, boff=L.ptr(boff), T=T, sorted=L.ptr(p.sorted_indices),
               unsorted=L.ptr(p.unsorted_indices), **extra)

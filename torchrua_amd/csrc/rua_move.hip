@@ -12,6 +12,7 @@
 // Tiles are contiguous in the DESTINATION storage, so stores are perfectly coalesced and every
 // tile carries the same number of bytes (no ragged load imbalance); loads are row-granular
 // gathers (>= 128 B lines, 1 KiB at the north-star shape).
+#include <stdlib.h>
 #include "rua_dev.h"
 
 namespace rua {
@@ -24,7 +25,6 @@ namespace rua {
 #endif
 constexpr int MOVE_BLOCK = RUA_MOVE_BLOCK;          // threads per workgroup of the generic mover
 constexpr int MOVE_TILE = MOVE_BLOCK;               // one lane per row in phase 1
-constexpr int TILE_ROWS = 256;                      // the (rank x time) tile of pack_tile_kernel: 16 x 16
 constexpr int UNROLL = RUA_MOVE_UNROLL;             // row groups in flight per wave in phase 2
 constexpr int64_t MOVE_TILE_BYTES = 16 << 10;       // destination bytes one workgroup takes (rows: a power of two, 4..256)
 constexpr int64_t MOVE_SPAN_MIN_TILES = 2048;       // launches at least this large give every XCD one contiguous span ...
@@ -310,17 +310,32 @@ __global__ __launch_bounds__(BLOCK) void move_rows_kernel(rua_layout D, rua_layo
 // Here a tile is TR ranks x TT time steps, so BOTH sides move 16-row runs, and phase 2 walks it in 4x4
 // sub-tiles.  (At >= 1 KiB rows the same tiling changes nothing — a row already fills whole lines — so
 // wide rows keep the generic kernel.)  Phase 1 needs no search: rank r is live at time t iff r < bsz[t].
-constexpr int TR = 16, TT = 16;   // TR * TT == TILE_ROWS
+constexpr int TR_MAX = 32;        // a tile is (1 << TRL) ranks x (1 << TTL) time steps, TRL = 4 .. 5, TTL = 4 .. 6 (rua_layout::tile_t_log2)
 constexpr int64_t TILE_MAX_ROW_BYTES = 64;       // rows up to this take the tile kernel (pack_tile_lds_kernel)
 
-// phase 1 of both tile kernels (closed form, no search): thread i = (rank << 4) | time of the tile fills the
-// source / destination row of its token, or -1
-template <bool TO_PACK>
-__device__ __forceinline__ void tile_phase1(const rua_layout& Pk, const rua_layout& Ot, int64_t* s_ld, int64_t* s_st,
-                                            int64_t tile) {
+// [r4] A tile's life is one chain of dependent loads in front of its payload, and eight resident workgroups per CU
+// cannot feed the HBM through it when the chain carries 8 KiB (32-byte rows, 16 x 16 tiles: 4.3 TB/s for the pack, 3.6
+// for P.cat).  Two changes.  (1) Phase 1 no longer resolves every (rank, time) cell by itself (five loads per cell,
+// three of them dependent): a cell's rows are AFFINE in the tile — batch-major row = base[rank] + time, PackedSequence
+// row = boff[time] + rank — so sixteen lanes fetch their rank's sequence (sorted -> offset / length) and TT lanes their
+// time step's (boff, bsz), and phase 2 computes every row from those two small tables.  (2) The tile grows ALONG TIME
+// as rows get narrower (1 << TTL steps, chosen by the host: 64 at <= 16 B, 32 at <= 32 B, 16 at 64 B — 16 KiB of payload
+// per chain, eight workgroups per CU), which also makes the batch-major side's runs 1 KiB instead of 512 / 256 B.
+// Measured (8 GB payloads, profiles/r04_tile_ab.txt): pack 4.33 -> 5.08 TB/s at 32-byte rows, 3.26 -> 4.68 at 16,
+// 5.0 -> 5.5 at 64; P.cat 3.64 -> 4.2, 3.14 -> 4.06, 4.6 -> 4.9.  32 KiB tiles and 32 ranks per tile: slower.
+struct TileTables {
+  int64_t obase[TR_MAX];  // batch-major storage row of the rank's sequence at the tile's first time step
+  int64_t olen[TR_MAX];   // its length (0: no such sequence)
+  int64_t pboff[64];      // first PackedSequence row of the time step
+  int64_t pbsz[64];       // sequences alive at the time step (0 past T)
+};
+
+template <int TTL, int TRL>
+__device__ __forceinline__ void tile_tables(const rua_layout& Pk, const rua_layout& Ot, int64_t tile, TileTables& tb,
+                                            int64_t& r0_out) {
+  constexpr int TT = 1 << TTL, TR = 1 << TRL;
   // which time chunk does this tile belong to?  largest c with tile_start[c] <= tile.  Up to 64 chunks
-  // (T <= 1 024) every lane loads one entry and a ballot counts them: ONE load instead of a six-step chain of
-  // dependent ones — an 8-KiB tile lives for ~8 us, most of it waiting on such chains.
+  // every lane loads one entry and a ballot counts them: ONE load instead of a six-step chain of dependent ones
   int64_t lo = 0, hi = Pk.n_tchunks;
   if (Pk.n_tchunks <= RUA_WAVE) {
     const int lane = threadIdx.x & (RUA_WAVE - 1);
@@ -335,19 +350,27 @@ __device__ __forceinline__ void tile_phase1(const rua_layout& Pk, const rua_layo
   }
   const int64_t t0 = lo * TT;
   const int64_t r0 = (tile - Pk.tile_start[lo]) * TR;
+  r0_out = r0;
   const int i = threadIdx.x;
-  const int64_t r = r0 + (i >> 4), t = t0 + (i & 15);
-  int64_t prow = -1, orow = -1;
-  if (t < Pk.T && r < Pk.bsz[t] && r < Pk.B) {
-    int64_t b = Pk.sorted ? Pk.sorted[r] : r;
-    if (b >= 0 && b < Ot.B) {
-      prow = Pk.boff[t] + r;
-      orow = token_to_row(Ot, b, t, seq_len(Ot, b));
-      if (prow >= Pk.n_rows || orow >= Ot.n_rows) { prow = -1; orow = -1; }
+  if (i < TR) {                                   // wave 0, lanes 0..15: the ranks
+    const int64_t r = r0 + i;
+    int64_t base = 0, len = 0;
+    if (r < Pk.B) {
+      const int64_t b = Pk.sorted ? Pk.sorted[r] : r;
+      if (b >= 0 && b < Ot.B) {
+        len = seq_len(Ot, b);
+        base = token_to_row(Ot, b, 0, len);
+      }
     }
+    tb.obase[i] = base + t0;                      // batch-major row of the sequence's token at the tile's first time step
+    tb.olen[i] = len - t0;                        // tokens of the sequence from that step on
+  } else if (i >= RUA_WAVE && i < RUA_WAVE + TT) {   // wave 1 (and 2): the time steps
+    const int j = i - RUA_WAVE;
+    const int64_t t = t0 + j;
+    const bool ok = t < Pk.T;
+    tb.pboff[j] = ok ? Pk.boff[t] : 0;
+    tb.pbsz[j] = ok ? Pk.bsz[t] : 0;
   }
-  s_ld[i] = TO_PACK ? orow : prow;
-  s_st[i] = TO_PACK ? prow : orow;
 }
 
 // The tile goes through LDS: read in the source's contiguous order, written in the destination's (measured at 32-byte
@@ -355,48 +378,133 @@ __device__ __forceinline__ void tile_phase1(const rua_layout& Pk, const rua_layo
 // mover: since round 2 (16 KiB tiles, cooperative row resolution) it is the faster one there — 5.5 / 5.8 TB/s for
 // C->P / P->C at 128 B against 5.3 / 5.2 for the tile kernels; at 64 B the tiles win 4.8 to 3.2, at 32 B 3.9 to 1.6
 // (a round-2 A/B, profiles/r02_width_sweep.txt).
-template <int VEC, bool TO_PACK>
+template <int VEC, bool TO_PACK, int TTL, int TRL>
 __global__ __launch_bounds__(RUA_BLOCK) void pack_tile_lds_kernel(rua_layout Pk, rua_layout Ot, char* __restrict__ dst,
                                                               const char* __restrict__ src, int64_t row_bytes,
                                                               int64_t lpr, int64_t tiles_per_xcd) {
   using V = typename vec_of<VEC>::type;
-  __shared__ int64_t s_ld[TILE_ROWS];
-  __shared__ int64_t s_st[TILE_ROWS];
+  constexpr int TT = 1 << TTL, TR = 1 << TRL, TILE = TR * TT;
+  static_assert(TT <= 64 && TR <= TR_MAX && RUA_BLOCK >= RUA_WAVE + TT, "one lane per rank in wave 0, per time step in waves 1..");
+  __shared__ TileTables tb;
 
   int64_t tile = blockIdx.x;                  // (block-uniform) one contiguous span of tiles per XCD, as in the row mover
   if (tiles_per_xcd > 0) {
     tile = (int64_t)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
     if ((int64_t)(blockIdx.x >> 3) >= tiles_per_xcd || tile >= Pk.n_tiles) return;
   }
-  tile_phase1<TO_PACK>(Pk, Ot, s_ld, s_st, tile);
+  int64_t r0;
+  tile_tables<TTL, TRL>(Pk, Ot, tile, tb, r0);
   __syncthreads();
 
   // ---- phase 2: the tile goes through LDS.  It is read in the SOURCE's contiguous order (consecutive lanes =
   // consecutive 16-byte pieces of consecutive rows of one run) and written in the DESTINATION's contiguous order,
-  // so both sides see whole 16-row runs (512 B at 32-byte rows) per wave instruction instead of 4-row / 1-row
-  // pieces.  Tile index i = (rank << 4) | time is the C-side order; the P-side order visits (time, rank).
+  // so both sides see whole runs per wave instruction (16 ranks on the PackedSequence's side, TT time steps on the
+  // batch-major side).  Cell (rank, time): batch-major row obase[rank] + time, PackedSequence row pboff[time] + r0 + rank;
+  // live iff the sequence still has a token there (time < olen[rank]) and the rank is alive (r0 + rank < pbsz[time]).
   extern __shared__ __attribute__((aligned(16))) unsigned char s_stage_raw[];
   V* stage = reinterpret_cast<V*>(s_stage_raw);
-  const int n_pieces = TILE_ROWS * (int)lpr;
-  // one padding slot per 16 rows: the transposed order strides over 16 * lpr slots, which would otherwise
-  // land every lane of a group on the same LDS banks
-#define RUA_SLOT(i, piece) ((i) * (int)lpr + (piece) + ((i) >> 4))
+  const int n_pieces = TILE * (int)lpr;
+  // one padding slot per RANK: the transposed order strides over TT * lpr slots, which would otherwise
+  // land the sixteen ranks of a time step on the same LDS banks
+#define RUA_SLOT(rank, time, piece) ((((rank) << TTL) | (time)) * (int)lpr + (piece) + (rank))
+#define RUA_CELL(rank, time, orow, prow, live)                                                           \
+  const int64_t orow = tb.obase[rank] + (time), prow = tb.pboff[time] + r0 + (rank);                      \
+  const bool live = (time) < tb.olen[rank] && r0 + (rank) < tb.pbsz[time] && orow < Ot.n_rows && prow < Pk.n_rows
 #pragma unroll 4
   for (int idx = threadIdx.x; idx < n_pieces; idx += RUA_BLOCK) {
     const int pos = idx / (int)lpr, piece = idx - pos * (int)lpr;
-    const int i = TO_PACK ? pos : (((pos & 15) << 4) | (pos >> 4));
-    const int64_t ld = s_ld[i];
-    if (ld >= 0 && s_st[i] >= 0) stage[RUA_SLOT(i, piece)] = ld_row<V, false>(src + ld * row_bytes + (int64_t)piece * VEC);
+    const int rank = TO_PACK ? pos >> TTL : pos & (TR - 1), time = TO_PACK ? pos & (TT - 1) : pos >> TRL;
+    RUA_CELL(rank, time, orow, prow, live);
+    if (live) stage[RUA_SLOT(rank, time, piece)] = ld_row<V, false>(src + (TO_PACK ? orow : prow) * row_bytes + (int64_t)piece * VEC);
   }
   __syncthreads();
 #pragma unroll 4
   for (int idx = threadIdx.x; idx < n_pieces; idx += RUA_BLOCK) {
     const int pos = idx / (int)lpr, piece = idx - pos * (int)lpr;
-    const int i = TO_PACK ? (((pos & 15) << 4) | (pos >> 4)) : pos;
-    const int64_t st = s_st[i];
-    if (st >= 0 && s_ld[i] >= 0) st_row<V, false>(dst + st * row_bytes + (int64_t)piece * VEC, stage[RUA_SLOT(i, piece)]);
+    const int rank = TO_PACK ? pos & (TR - 1) : pos >> TTL, time = TO_PACK ? pos >> TRL : pos & (TT - 1);
+    RUA_CELL(rank, time, orow, prow, live);
+    if (live) st_row<V, false>(dst + (TO_PACK ? prow : orow) * row_bytes + (int64_t)piece * VEC, stage[RUA_SLOT(rank, time, piece)]);
   }
+#undef RUA_CELL
 #undef RUA_SLOT
+}
+
+// roll / rev INSIDE one PackedSequence at rows of <= 32 bytes, on the same (rank x time) tiles: both sides are in the
+// PackedSequence's own order (runs of sixteen ranks), so nothing is transposed and nothing is staged — a cell's source
+// row is boff[t'] + rank with t' = the token map of t under the rank's length.  The generic mover's variant for these
+// rows (four rows per lane, two 10-step binary searches in lockstep) spends its life in ~20 dependent loads per tile;
+// here the chain is tile_start -> (sorted -> lens | boff, bsz of the tile's steps) -> boff[t'] -> payload.
+template <int VEC, int TTL>
+__global__ __launch_bounds__(RUA_BLOCK) void pack_roll_tile_kernel(rua_layout Pk, int32_t tmap, int64_t targ,
+                                                               char* __restrict__ dst, const char* __restrict__ src,
+                                                               int64_t row_bytes, int64_t lpr, uint4 fillpat,
+                                                               int64_t tiles_per_xcd) {
+  using V = typename vec_of<VEC>::type;
+  constexpr int TT = 1 << TTL, TR = 16, TILE = TR * TT;
+  __shared__ TileTables tb;
+  int64_t tile = blockIdx.x;
+  if (tiles_per_xcd > 0) {
+    tile = (int64_t)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= tiles_per_xcd || tile >= Pk.n_tiles) return;
+  }
+  int64_t r0;
+  tile_tables<TTL, 4>(Pk, Pk, tile, tb, r0);      // olen[rank] = tokens of the rank's sequence from the tile's first step on
+  __syncthreads();
+  // first time step of the tile = (length - what is left from there on) of any live rank; recomputed from the tables:
+  // pboff / pbsz are indexed by the step inside the tile, the token map needs the absolute step
+  int64_t lo = 0;
+  {
+    // (the same chunk search as tile_tables: block-uniform, one load + ballot)
+    if (Pk.n_tchunks <= RUA_WAVE) {
+      const int lane = threadIdx.x & (RUA_WAVE - 1);
+      const int64_t v = lane < Pk.n_tchunks ? Pk.tile_start[lane] : 0x7fffffffffffffffLL;
+      lo = (int64_t)__popcll(__ballot(v <= tile)) - 1;
+      if (lo < 0) lo = 0;
+    } else {
+      int64_t hi = Pk.n_tchunks;
+      while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (Pk.tile_start[mid] <= tile) lo = mid; else hi = mid;
+      }
+    }
+  }
+  const int64_t t0 = lo * TT;
+  const V fillv = fill_of<VEC>(fillpat);
+  const int n_pieces = TILE * (int)lpr;
+#pragma unroll 4
+  for (int idx = threadIdx.x; idx < n_pieces; idx += RUA_BLOCK) {
+    const int pos = idx / (int)lpr, piece = idx - pos * (int)lpr;
+    const int rank = pos & (TR - 1), time = pos >> 4;
+    const int64_t left = tb.olen[rank];                   // len - t0
+    if (time < left && r0 + rank < tb.pbsz[time]) {
+      const int64_t len = left + t0, t = t0 + time;
+      const int64_t ts = apply_tmap(tmap, targ, t, len, len);
+      const int64_t drow = tb.pboff[time] + r0 + rank;
+      V val = fillv;
+      if (ts >= 0 && ts < len) {
+        const int64_t srow = Pk.boff[ts] + r0 + rank;
+        if (srow < Pk.n_rows) val = ld_row<V, false>(src + srow * row_bytes + (int64_t)piece * VEC);
+      }
+      if (drow < Pk.n_rows) st_row<V, false>(dst + drow * row_bytes + (int64_t)piece * VEC, val);
+    }
+  }
+}
+
+static int launch_roll_tiles(int vec, hipStream_t s, const rua_layout& Pk, int32_t tmap, int64_t targ, char* dst,
+                             const char* src, int64_t row_bytes, uint4 fp, bool xcd_span) {
+  const int64_t per_xcd = xcd_span ? (Pk.n_tiles + 7) / 8 : 0;
+  const int64_t grid = xcd_span ? per_xcd * 8 : Pk.n_tiles;
+  if (grid > 0x7fffffffLL) return RUA_ERANGE;
+  const int64_t lpr = (row_bytes + vec - 1) / vec;
+  const int ttl = (Pk.tile_t_log2 & 0xff) == 0 ? 4 : (Pk.tile_t_log2 & 0xff);
+  if (ttl < 4 || ttl > 6 || vec != 16) return RUA_EINVAL;
+  const dim3 g((unsigned)grid), b(RUA_BLOCK);
+  switch (ttl) {
+    case 4: hipLaunchKernelGGL((pack_roll_tile_kernel<16, 4>), g, b, 0, s, Pk, tmap, targ, dst, src, row_bytes, lpr, fp, per_xcd); break;
+    case 5: hipLaunchKernelGGL((pack_roll_tile_kernel<16, 5>), g, b, 0, s, Pk, tmap, targ, dst, src, row_bytes, lpr, fp, per_xcd); break;
+    default: hipLaunchKernelGGL((pack_roll_tile_kernel<16, 6>), g, b, 0, s, Pk, tmap, targ, dst, src, row_bytes, lpr, fp, per_xcd); break;
+  }
+  return (int)hipGetLastError();
 }
 
 template <bool TO_PACK>
@@ -407,9 +515,19 @@ static int launch_pack_tiles(int vec, hipStream_t s, const rua_layout& Pk, const
   if (grid > 0x7fffffffLL) return RUA_ERANGE;
   const int64_t lpr = (row_bytes + vec - 1) / vec;
   const dim3 g((unsigned)grid), b(RUA_BLOCK);
-  const size_t lds = (size_t)(TILE_ROWS * lpr + TILE_ROWS / 16) * vec;   // the staged tile + its padding slots
-#define RUA_LAUNCH(VEC) \
-  hipLaunchKernelGGL((pack_tile_lds_kernel<VEC, TO_PACK>), g, b, lds, s, Pk, Ot, dst, src, row_bytes, lpr, per_xcd)
+  const int ttl = (Pk.tile_t_log2 & 0xff) == 0 ? 4 : (Pk.tile_t_log2 & 0xff);      // (0: a caller of ABI <= 3, 16 x 16 tiles)
+  const int trl = ((Pk.tile_t_log2 >> 8) & 0xff) == 0 ? 4 : ((Pk.tile_t_log2 >> 8) & 0xff);
+  if (ttl < 4 || ttl > 6 || trl != 4) return RUA_EINVAL;
+  const size_t lds = (size_t)(((int64_t)1 << (ttl + trl)) * lpr + ((int64_t)1 << trl)) * vec;   // the staged tile + its padding slots
+  if (lds > (48u << 10)) return RUA_EINVAL;                            // (the host picks the tile by row width: 32 KiB staged at most)
+#define RUA_LAUNCH_T(VEC, TTLV, TRLV) \
+  hipLaunchKernelGGL((pack_tile_lds_kernel<VEC, TO_PACK, TTLV, TRLV>), g, b, lds, s, Pk, Ot, dst, src, row_bytes, lpr, per_xcd)
+#define RUA_LAUNCH(VEC)                                                             \
+  switch (ttl) {             /* (32 ranks per tile were measured too: slower at every width, not instantiated) */ \
+    case 4: RUA_LAUNCH_T(VEC, 4, 4); break;                                         \
+    case 5: RUA_LAUNCH_T(VEC, 5, 4); break;                                         \
+    default: RUA_LAUNCH_T(VEC, 6, 4); break;                                        \
+  }
   switch (vec) {
     case 16: RUA_LAUNCH(16); break;
     case 8:  RUA_LAUNCH(8); break;
@@ -418,6 +536,7 @@ static int launch_pack_tiles(int vec, hipStream_t s, const rua_layout& Pk, const
     default: RUA_LAUNCH(1); break;
   }
 #undef RUA_LAUNCH
+#undef RUA_LAUNCH_T
   return (int)hipGetLastError();
 }
 
@@ -579,6 +698,16 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
   const bool narrow_same_pack = vec == 16 && row_bytes <= 32 && dst->kind == RUA_PACK && src->kind == RUA_PACK &&
                                 dst->bsz && dst->boff && dst->boff == src->boff && dst->sorted == src->sorted &&
                                 dst->len_add == 0 && src->len_add == 0 && dst->T == src->T && dst->T > 0;
+  // ... and on the (rank x time) tiles when the caller handed the tile table over (pack_roll_tile_kernel)
+  static const bool no_roll_tiles = [] { const char* e = getenv("RUA_NO_ROLL_TILES"); return e && e[0] == '1'; }();   // developer A/B
+  if (narrow_same_pack && !no_roll_tiles && dst->tile_start && dst->n_tiles > 0 && dst->lens && dst->sorted &&
+      pad_row < 0 && (flags & ~(RUA_MOVE_XCD_SPAN_ON | RUA_MOVE_XCD_SPAN_OFF)) == 0 &&
+      (tmap == RUA_T_ROLL || tmap == RUA_T_REV_S || tmap == RUA_T_REV_D || tmap == RUA_T_SHIFT)) {
+    bool span = dst->n_tiles >= MOVE_SPAN_MIN_TILES_DENSE;
+    if (flags & RUA_MOVE_XCD_SPAN_ON) span = true;
+    if (flags & RUA_MOVE_XCD_SPAN_OFF) span = false;
+    return launch_roll_tiles(vec, s, *dst, tmap, tmap_arg, d, c, row_bytes, fp, span);
+  }
   return nt ? launch_move<false, true>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, narrow_same_pack, tile_rows, xcd_span, tail8)
             : launch_move<false, false>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, narrow_same_pack, tile_rows, xcd_span, tail8);
 }
