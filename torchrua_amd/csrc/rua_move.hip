@@ -321,8 +321,9 @@ constexpr int64_t TILE_MAX_ROW_BYTES = 64;       // rows up to this take the til
 // time step's (boff, bsz), and phase 2 computes every row from those two small tables.  (2) The tile grows ALONG TIME
 // as rows get narrower (1 << TTL steps, chosen by the host: 64 at <= 16 B, 32 at <= 32 B, 16 at 64 B — 16 KiB of payload
 // per chain, eight workgroups per CU), which also makes the batch-major side's runs 1 KiB instead of 512 / 256 B.
-// Measured (8 GB payloads, profiles/r04_tile_ab.txt): pack 4.33 -> 5.08 TB/s at 32-byte rows, 3.26 -> 4.68 at 16,
-// 5.0 -> 5.5 at 64; P.cat 3.64 -> 4.2, 3.14 -> 4.06, 4.6 -> 4.9.  32 KiB tiles and 32 ranks per tile: slower.
+// Measured (8 GB payloads, profiles/r04_tile_ab.txt, r03_width_sweep.txt): pack 4.0-4.3 -> 4.9 TB/s at 32-byte rows,
+// 3.3 -> 4.9 at 16; P.cat 3.3-3.6 -> 3.9, 3.1 -> 4.2; 64-byte rows unchanged (5.2 / 4.4).  32 KiB tiles and 32 ranks
+// per tile: slower.
 struct TileTables {
   int64_t obase[TR_MAX];  // batch-major storage row of the rank's sequence at the tile's first time step
   int64_t olen[TR_MAX];   // its length (0: no such sequence)
