@@ -2,7 +2,8 @@
  * thousand sequences (some of them empty), host entry points included — the reference's host sort
  * (rua_host_sort_desc) and batch_sizes (rua_host_batch_sizes), then rua_pack_prepare, rua_move_rows,
  * rua_segment_reduce (sum; max with the reference's global `initial` through rua_fill_empty), the scatter_sum form
- * (rua_index_buckets + the row indirection) and the fused backward of max.  Everything is checked on the host with
+ * (rua_index_buckets + the row indirection), its integer twin (ABI 4: scatter_mean on int8), the host sort on the
+ * helper thread, and the fused backward of max.  Everything is checked on the host with
  * loops written from the formulas in include/rua.h.  No Python, no torch in the process.
  * Built and run by tests/test_c_abi.py on the GPU box. */
 #include <hip/hip_runtime_api.h>
@@ -104,6 +105,23 @@ int main(void) {
   memset(&buckets, 0, sizeof buckets);
   buckets.kind = RUA_CAT; buckets.n_rows = N; buckets.B = B; buckets.lens = d_counts; buckets.off = d_boffs;
   CHECK(rua_segment_reduce(&buckets, d_perm, d_sh, d_scat, H, RUA_F32, RUA_SUM, 0, 0, NULL, 0, NULL, NULL, s));
+
+  /* ---- ABI 4: the same buckets over an INTEGER payload (scatter_mean on int8 with include_self, reduce.py:18-19):
+   * sums wrap in int8 and ATen divides by a count OF THAT TYPE, rounding towards minus infinity */
+  enum { HI = 16 };
+  int8_t* i_src = malloc((size_t)N * HI), *i_ten = malloc((size_t)B * HI);
+  for (int64_t i = 0; i < N * HI; ++i) i_src[i] = (int8_t)((int)(rng() % 41) - 20);
+  for (int64_t i = 0; i < (int64_t)B * HI; ++i) i_ten[i] = (int8_t)((int)(rng() % 255) - 127);
+  int8_t* d_isrc = upload(i_src, (size_t)N * HI);
+  int8_t* d_iout = upload(i_ten, (size_t)B * HI);            /* include_self: the call folds into the old rows */
+  CHECK(rua_segment_reduce(&buckets, d_perm, d_isrc, d_iout, HI, RUA_I8, RUA_MEAN, 1, 0, NULL, 0, NULL, NULL, s));
+  if (rua_segment_reduce(&buckets, d_perm, d_isrc, d_iout, HI, RUA_I8, RUA_LOGSUMEXP, 1, 0, NULL, 0, NULL, NULL, s) != RUA_EINVAL) return 1;
+
+  /* ---- ABI 4: the host sort on the helper thread gives the same order; the two host scans next to it */
+  int64_t* sorted2 = malloc(B * sizeof *sorted2), *h_boff = malloc((size_t)T * 8), *h_off = malloc(B * 8);
+  CHECK(rua_host_sort_desc_begin(lens, B, sorted2, 3));
+  CHECK(rua_host_pack_scans(lens, B, bsz, T, h_boff, h_off));
+  CHECK(rua_host_sort_desc_end());
   CHECK(hipStreamSynchronize(s));
 
   /* ---- checks */
@@ -159,6 +177,32 @@ int main(void) {
         bad += i < 0 || i >= N || sh_index[i] != b || (k && perm[boffs[b] + k - 1] >= i);
       }
     }
+  }
+  /* integer scatter_mean (include_self) against ATen's steps written out */
+  {
+    int8_t* iout = malloc((size_t)B * HI);
+    CHECK(hipMemcpy(iout, d_iout, (size_t)B * HI, hipMemcpyDeviceToHost));
+    int8_t* acc8 = malloc((size_t)B * HI);
+    memcpy(acc8, i_ten, (size_t)B * HI);
+    for (int64_t i = 0; i < N; ++i)                        /* index_add in source order, wrapping */
+      for (int h = 0; h < HI; ++h) {
+        int8_t* a = acc8 + sh_index[i] * HI + h;
+        *a = (int8_t)(uint8_t)((uint8_t)*a + (uint8_t)i_src[i * HI + h]);
+      }
+    for (int b = 0; b < B; ++b)
+      for (int h = 0; h < HI; ++h) {
+        const int8_t accv = acc8[b * HI + h];
+        int8_t cnt = (int8_t)(uint8_t)(uint64_t)(lens[b] + 1);
+        if (cnt == 0) cnt = 1;
+        int q = (int)accv / (int)cnt;
+        if ((((int)accv < 0) != ((int)cnt < 0)) && (int)accv % (int)cnt != 0) --q;
+        bad += iout[b * HI + h] != (int8_t)q;
+      }
+    for (int b = 0; b < B; ++b) bad += sorted2[b] != sorted[b];
+    int64_t run = 0;
+    for (int64_t t = 0; t < T; ++t) { bad += h_boff[t] != run; run += bsz[t]; }
+    run = 0;
+    for (int b = 0; b < B; ++b) { bad += h_off[b] != run; run += lens[b]; }
   }
   printf("abi_pipeline: target %s, %d sequences, %lld rows, %d mismatches\n", rua_build_target(), (int)B, (long long)N, bad);
   return bad ? 2 : 0;
