@@ -9,7 +9,6 @@ from typing import Callable, Optional, Sequence, Tuple
 
 import torch
 from torch import Tensor
-from torch.autograd.function import once_differentiable
 
 from torchrua_amd import _lib as L
 from torchrua_amd import _meta as M
@@ -109,12 +108,12 @@ class _ListGather(torch.autograd.Function):
         return launch_move(plan, src_data)
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, grad: Tensor):
         """d/d src = the rows of `grad` summed into the storage rows they were gathered from.  Rows may repeat, so this
         is a scatter-sum: bucket the flat row numbers (stable radix sort, rua_index_buckets) and fold every bucket in
         ascending entry order with the segmented reducer — no float atomics, bitwise reproducible (torch's index_add_
-        is neither)."""
+        is neither).  [r4] Twice differentiable, like the reference's `data[key]`: the scatter-sum's own adjoint is the
+        gather again (_ScatterSumRows / _GatherRows)."""
         flat = ctx.flat_fn().reshape(-1)
         grad = grad.contiguous()
         hidden = tuple(ctx.src_shape[ctx.lead:])
@@ -122,7 +121,7 @@ class _ListGather(torch.autograd.Function):
         for d in ctx.src_shape[:ctx.lead]:
             n_rows *= d
         flat = torch.where(flat < 0, flat + n_rows, flat)          # negative rows wrapped in the forward (like torch)
-        g = scatter_sum_rows(grad.reshape((flat.numel(),) + hidden), flat, n_rows)
+        g = scatter_sum(grad.reshape((flat.numel(),) + hidden), flat, n_rows)
         return g.reshape(ctx.src_shape), None, None, None
 
 
@@ -236,12 +235,21 @@ class _Reduce(torch.autograd.Function):
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, grad: Tensor):
-        """One fused kernel (rua_segment_reduce_backward): reads the payload once (max/min: the forward already
-        counted the ties), writes the gradient once — no [N, H] temporaries."""
         data, out = ctx.saved_tensors
-        lay, op = ctx.lay, ctx.op
+        return _ReduceBwd.apply(grad, data, out, ctx.lay, ctx.op, ctx.ties), None, None, None, None
+
+
+class _ReduceBwd(torch.autograd.Function):
+    """The backward of a segmented reduce as a function of the cotangent.  One fused kernel
+    (rua_segment_reduce_backward): reads the payload once (max/min: the forward already counted the ties), writes the
+    gradient once — no [N, H] temporaries.  [r4] For SUM and MEAN the map cotangent -> gradient is linear (a broadcast
+    of every segment's row over the segment's rows, divided by the length for MEAN) and its adjoint is the reduction
+    itself, so these two are differentiable any number of times, like the reference's (torch.segment_reduce,
+    reduce.py:44-49); the others differentiate once."""
+
+    @staticmethod
+    def forward(ctx, grad: Tensor, data: Tensor, out: Tensor, lay: M.Lay, op: int, ties: Optional[Tensor]):
         dev = L.require_device(data)
         lib = L.load()
         grad = grad.contiguous()
@@ -250,15 +258,23 @@ class _Reduce(torch.autograd.Function):
         for d in out.shape[1:]:
             H *= d
         split, ws = split_workspace(lay, H, data.dtype, dev, team_ok=False)      # (the backward walk has no wave teams)
-        ties = ctx.ties                        # max/min: counted by the forward -> apply only (TIES_FINAL)
-        # segment_max/min are torch.segment_reduce in the reference (reduce.py:34-41), whose backward lets tied extrema
-        # share a positive gradient and hands each of them a non-positive one whole (BWD_TIES_POSITIVE)
+        # max/min: `ties` counted by the forward -> apply only (TIES_FINAL).  segment_max/min are torch.segment_reduce in
+        # the reference (reduce.py:34-41), whose backward lets tied extrema share a positive gradient and hands each of
+        # them a non-positive one whole (BWD_TIES_POSITIVE)
         L.check(lib.rua_segment_reduce_backward(lay.ref(), None, L.ptr(data), L.ptr(out), L.ptr(grad), L.ptr(g), H,
                                                 L.DTYPES[data.dtype], op,
                                                 (L.TIES_FINAL if ties is not None else 0) | L.BWD_FILL_PADDING | L.BWD_TIES_POSITIVE,
                                                 split, L.ptr(ws), L.ptr(ties), None, L.stream_ptr(dev)),
                 'rua_segment_reduce_backward')
-        return g, None, None, None, None
+        ctx.lay, ctx.op, ctx.hidden = lay, op, tuple(out.shape[1:])
+        return g
+
+    @staticmethod
+    def backward(ctx, gg: Tensor):
+        if ctx.op not in (L.SUM, L.MEAN):
+            raise RuntimeError('torchrua_amd: the reductions max / min / prod / logsumexp differentiate once; second-order '
+                               'gradients exist for sum and mean (and for every cast, select and gather)')
+        return reduce(gg.contiguous(), ctx.lay, ctx.op, ctx.hidden, None), None, None, None, None, None
 
 
 def reduce(data: Tensor, lay: M.Lay, op: int, hidden, lens: Optional[Tensor]) -> Tensor:
@@ -283,6 +299,52 @@ def index_buckets(index: Tensor, S: int) -> Tuple[Tensor, Tensor]:
                                   L.stream_ptr(dev)), 'rua_index_buckets')
     M._memo_put(counts, 'off', off)
     return counts, perm
+
+
+class _ScatterSumRows(torch.autograd.Function):
+    """out[s] = sum of rows[i] over index[i] == s; adjoint: the gather rows[index]."""
+
+    @staticmethod
+    def forward(ctx, rows: Tensor, index: Tensor, n_out: int):
+        ctx.index = index
+        return scatter_sum_rows(rows.detach(), index, n_out)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        return gather_rows(g.contiguous(), ctx.index), None, None
+
+
+class _GatherRows(torch.autograd.Function):
+    """out[i] = rows[index[i]] (zeros where index[i] is out of range); adjoint: the scatter-sum."""
+
+    @staticmethod
+    def forward(ctx, rows: Tensor, index: Tensor):
+        ctx.index, ctx.n = index, int(rows.size(0))
+        plan = MovePlan(M.lay_list(None, index), M.lay_flat(ctx.n), (index.numel(),) + tuple(rows.shape[1:]), fill=0,
+                        name='gather_rows')
+        return launch_move(plan, rows.detach())
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        return scatter_sum(g.contiguous(), ctx.index, ctx.n), None
+
+
+def gather_rows(rows: Tensor, index: Tensor) -> Tensor:
+    """rows[index] through the mover; recorded by autograd when `rows` carries a graph (second-order gradients)."""
+    if rows.requires_grad and torch.is_grad_enabled():
+        return _GatherRows.apply(rows, index)
+    return _GatherRows.forward(_NoCtx(), rows, index)
+
+
+def scatter_sum(rows: Tensor, index: Tensor, n_out: int) -> Tensor:
+    """scatter_sum_rows, recorded by autograd when `rows` carries a graph (second-order gradients)."""
+    if rows.requires_grad and torch.is_grad_enabled():
+        return _ScatterSumRows.apply(rows, index, n_out)
+    return scatter_sum_rows(rows, index, n_out)
+
+
+class _NoCtx:
+    """Stands in for an autograd context when a Function's forward is run for its value only."""
 
 
 def scatter_sum_rows(rows: Tensor, index: Tensor, n_out: int) -> Tensor:

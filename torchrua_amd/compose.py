@@ -12,7 +12,6 @@ from typing import List
 
 import numpy as np
 import torch
-from torch.autograd.function import once_differentiable
 
 from torchrua_amd import _lib as K
 from torchrua_amd import _meta as M
@@ -58,16 +57,16 @@ class _ComposeRows(torch.autograd.Function):
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, grad: torch.Tensor):
+        # (a gather per container; [r4] through the differentiable gather, so compose is twice differentiable like the
+        # reference's, which is casts and a cat)
         grad = grad.contiguous()
         outs = []
         for part, shape in zip(ctx.parts, ctx.shapes):
             if shape[0] == 0:
                 outs.append(grad.new_zeros(shape))
                 continue
-            plan = O.MovePlan(M.lay_list(None, part), M.lay_flat(ctx.n_out), shape, fill=0, name='compose_bwd')
-            outs.append(O.launch_move(plan, grad))
+            outs.append(O.gather_rows(grad, part).reshape(shape))
         return (None, None) + tuple(outs)
 
 

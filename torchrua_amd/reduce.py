@@ -137,8 +137,19 @@ class _Scatter(torch.autograd.Function):
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, grad: T):
+        if ctx.op == K.SUM and torch.is_grad_enabled() and grad.requires_grad:
+            # [r4] a graph of the backward is being recorded (create_graph=True): scatter_sum is linear, its gradient
+            # w.r.t. the source rows is the gather grad[index] — spelled with the differentiable gather, whose adjoint is
+            # the scatter-sum again (the reference's index_add is twice differentiable the same way)
+            tensor, index, source, out, counts = ctx.saved_tensors
+            g_src = O.gather_rows(grad.contiguous(), M._as_lens(index)) if ctx.needs_input_grad[2] else None
+            g_ten = grad if (ctx.include_self and ctx.needs_input_grad[0]) else None
+            return g_ten, None, g_src, None, None
+        return _Scatter._backward_once(ctx, grad)
+
+    @staticmethod
+    def _backward_impl(ctx, grad: T):
         """Gradient w.r.t. the source rows: the fused kernel walking every destination's bucket
         (rua_segment_reduce_backward with the row indirection; the old destination row `tensor` rides along as
         `self_in`: one more tie candidate for max/min, one more factor for prod with include_self).  Gradient w.r.t.
@@ -189,6 +200,9 @@ class _Scatter(torch.autograd.Function):
                                                   K.ptr(aux), K.ptr(g_ten), dt, op, 1 if inc else 0,
                                                   K.stream_ptr(dev)), 'rua_scatter_self_grad')
         return g_ten, None, g_src, None, None
+
+
+_Scatter._backward_once = staticmethod(once_differentiable(_Scatter._backward_impl))      # every op but the one above
 
 
 def _scatter(tensor: T, index: T, source: T, op: int, include_self: bool, dim: int) -> T:
