@@ -500,3 +500,6 @@ def test_pack_with_device_only_lengths_overlaps_the_host_sort():
         # a container whose lengths are a strided view (not contiguous int64): normalised first, offsets not memoised on it
         wide = torch.stack([lens, lens], 1).to(DEV)[:, 0]
         assert_same_seq(ta.C(data.to(DEV), wide).pack(), want, f'pack strided lens B={B}')
+        narrow = ta.C(data.to(DEV), lens.to(DEV).int()).pack()           # int32 lengths on the device
+        assert torch.equal(narrow.data, p.data) and torch.equal(narrow.sorted_indices, p.sorted_indices)
+        assert torch.equal(narrow.batch_sizes, p.batch_sizes)

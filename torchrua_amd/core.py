@@ -119,6 +119,7 @@ def _pack_meta_overlapped(token_sizes: Tensor, lens: Tensor, host: Tensor, dev: 
     copies; only the inverse permutation is left to a (tiny) launch."""
     lib = K.load()
     B = lens.numel()
+    host = M._as_lens(host.detach())          # (int32 / strided lengths: the C side reads contiguous int64)
     staged_order = torch.empty(B, dtype=torch.long, pin_memory=True)
     _sort_job.acquire()            # the helper takes one job at a time (ctypes drops the GIL: another host thread may be here)
     try:

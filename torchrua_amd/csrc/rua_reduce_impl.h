@@ -10,6 +10,7 @@
 // Row addressing per layout (include/rua.h): CAT off[b]+t (contiguous), PACK boff[t]+rank[b]
 // (stride varies with t), LEFT/RIGHT b*T+t(+pad), and CAT+perm for the bucketed scatter_*.
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 #include "rua_dev.h"
@@ -513,8 +514,8 @@ __device__ __forceinline__ void store_partial(void* partials, int64_t slot, int 
   }
 }
 
-template <typename T, int EPL, int OP, bool NT, bool COPY, bool SPLIT, int CPW>
-__global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, const int64_t* __restrict__ perm,
+template <typename T, int EPL, int OP, bool NT, bool COPY, bool SPLIT, int CPW, int WPB = 1>
+__global__ __launch_bounds__(RUA_WAVE * WPB) void seg_reduce_kernel(rua_layout L, const int64_t* __restrict__ perm,
                                                               const T* __restrict__ data, T* __restrict__ out,
                                                               int64_t H, int lp_log2, int64_t n_chunks,
                                                               int include_self, T empty_val,
@@ -522,9 +523,10 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_kernel(rua_layout L, cons
                                                               rua_layout CD, T* __restrict__ copy, SplitWs W) {
   using A = typename elem<T>::acc;
   // ONE wave per workgroup: sequences differ in length, and a multi-wave workgroup would hold
-  // its CU slots until its longest sequence is done.
-  const int lane = threadIdx.x;
-  const int64_t wid = blockIdx.x;
+  // its CU slots until its longest sequence is done.  (WPB > 1: that many INDEPENDENT waves per workgroup, each with a
+  // unit of its own — no barrier, no LDS: launch_reduce says where that pays.)
+  const int lane = threadIdx.x & (RUA_WAVE - 1);
+  const int64_t wid = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
   const int64_t q = wid / n_chunks;          // sequence slot
   if (q >= L.B) return;
   constexpr int NE = EPL * CPW;
@@ -1391,6 +1393,13 @@ static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout&
   }
   W.ties = ties;
   unsigned long long* ext = (unsigned long long*)extreme;
+  // Two INDEPENDENT waves per workgroup over the batch-major layouts (C / L / R): neighbouring sequences are
+  // neighbouring storage, and halving the number of workgroups is worth 6-9 % there (cfg3 segment_sum 108.8 -> 101.3 us,
+  // north-star segment_sum(c) 2.86 -> 2.70 ms); four are no better, and over a PackedSequence — walked longest sequence
+  // first, every rank its own slot — two LOSE 7 % (2.64 -> 2.84 ms): one wave per workgroup stays there
+  // (profiles/r04_reduce_wpb_ab.txt; RUA_REDUCE_WPB=1|2|4 is the developer knob of that A/B).
+  static const int wpb_knob = [] { const char* e = getenv("RUA_REDUCE_WPB"); return e ? atoi(e) : 0; }();
+  const int wpb = (COPY || CPW != 1) ? 1 : wpb_knob > 0 ? wpb_knob : (L.kind != RUA_PACK ? 2 : 1);
 #define RUA_LAUNCH(OP)                                                                                              \
   if (do_split) {                                                                                                   \
     hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY, true, CPW>), g, b, 0, s, L, perm, (const T*)data,   \
@@ -1401,6 +1410,12 @@ static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout&
                        dim3((unsigned)(max_u < COMBINE_GRID ? max_u : COMBINE_GRID)),                               \
                        dim3(RUA_WAVE * (COMBINE_WAVES_MAX / CPW)), 0, s, L, perm, (T*)out,                          \
                        H, lp_log2, include_self, ev, CD, COPY ? 1 : 0, W);                                          \
+  } else if (wpb == 2) {                                                                                            \
+    hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY, false, CPW, 2>), dim3((grid + 1) / 2), dim3(RUA_WAVE * 2), \
+                       0, s, L, perm, (const T*)data, (T*)out, H, lp_log2, n_chunks, include_self, ev, ext, CD, (T*)copy, W); \
+  } else if (wpb == 4) {                                                                                            \
+    hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY, false, CPW, 4>), dim3((grid + 3) / 4), dim3(RUA_WAVE * 4), \
+                       0, s, L, perm, (const T*)data, (T*)out, H, lp_log2, n_chunks, include_self, ev, ext, CD, (T*)copy, W); \
   } else {                                                                                                          \
     hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY, false, CPW>), g, b, 0, s, L, perm, (const T*)data,  \
                        (T*)out, H, lp_log2, n_chunks, include_self, ev, ext, CD, (T*)copy, W);                      \
