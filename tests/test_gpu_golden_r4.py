@@ -52,6 +52,31 @@ def test_integer_scatter_against_the_oracle(dtype, H):
             np.testing.assert_array_equal(to_np(got), want, err_msg=f'{dtype} H={H} {name} {inc}')
 
 
+@pytest.mark.parametrize('dtype', [torch.int64, torch.int32, torch.int16, torch.int8, torch.uint8])
+def test_integer_scatter_against_the_calls_the_reference_makes(dtype):
+    """reduce.py:6-23 ARE torch.index_reduce / torch.index_add: the same calls on the CPU of this box, on the same inputs
+    (wrapping sums and products, counts beyond the type's range for int8 / uint8, 3-d targets along dim 1)."""
+    import warnings
+    g = torch.Generator().manual_seed(31)
+    info = torch.iinfo(dtype)
+    for S, Mn, shape_t, dim in ((5, 1500, (5, 6), 0), (64, 3000, (3, 64, 5), 1), (1, 40, (1,), 0)):
+        idx = torch.randint(0, S, (Mn,), generator=g)
+        shape_s = tuple(Mn if d == dim else n for d, n in enumerate(shape_t))
+        ten = torch.randint(max(info.min, -7), min(info.max, 7) + 1, shape_t, generator=g).to(dtype)
+        src = torch.randint(max(info.min, -7), min(info.max, 7) + 1, shape_s, generator=g).to(dtype)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            for name, red in (('max', 'amax'), ('min', 'amin'), ('mean', 'mean'), ('prod', 'prod')):
+                for inc in (False, True):
+                    want = torch.index_reduce(ten, dim, idx, src, red, include_self=inc)
+                    got = getattr(ta, f'scatter_{name}')(ten.to(DEV), idx.to(DEV), src.to(DEV), include_self=inc, dim=dim)
+                    assert torch.equal(got.cpu(), want), f'{dtype} scatter_{name} include_self={inc} dim={dim}'
+            for inc in (False, True):
+                want = torch.index_add(ten if inc else torch.zeros_like(ten), dim, idx, src)
+                got = ta.scatter_sum(ten.to(DEV), idx.to(DEV), src.to(DEV), include_self=inc, dim=dim)
+                assert torch.equal(got.cpu(), want), f'{dtype} scatter_sum include_self={inc} dim={dim}'
+
+
 def test_integer_scatter_counts_tokens_at_scale():
     """The ordinary use: tokens per bucket = scatter_sum of ones on a long tensor; 4 M entries."""
     g = torch.Generator().manual_seed(7)

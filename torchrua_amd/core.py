@@ -19,6 +19,9 @@ from torchrua_amd import _ops as O
 from torchrua_amd.layout import C, L, P, R, T, Z, describe, lens_of
 
 __all__ = ['get_mask']
+# NOTE: _namespace.py gives this module the attributes `cast`, `get`, `set`, `view` (the reference's submodules of
+# torchrua.core) — which shadow the builtin `set` here, as they do in the reference's own core/__init__.py.  Spell a set
+# literal {..} / builtins.set if this file ever needs one.
 
 Key = Union[int, Tensor, Tuple[Tensor, Tensor], Z]
 
