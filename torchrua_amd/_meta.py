@@ -285,7 +285,8 @@ def _host_sort_decide() -> int:
     battery of inputs (tie-heavy, sorted, reversed, constant, organ-pipe, sizes around the 16-element leaf, a median-of-3 killer
     that drives it into the heap-sort branch) —
     a mismatch (another C++ runtime behind torch, say) silently keeps the reference's call.  The thread count is the
-    fastest of {1, 2, 4, 8} on a 64 Ki-element sample, so a host that serialises threads is not made slower."""
+    smallest of {1, 2, 4, 8} within 5 % of the fastest on a 64 Ki-element sample (best of five runs each), so a host that
+    serialises threads is not made slower."""
     env = os.environ.get('RUA_HOST_SORT', '').strip().lower()
     if env == 'torch':
         return 0
@@ -310,18 +311,22 @@ def _host_sort_decide() -> int:
         # literal), so that eight ranks do not each conclude that eight threads are free
         cpus = max(1, cpus // max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1)))
         sample = torch.randint(8, 513, (65536,), generator=torch.Generator().manual_seed(1))
-        best, best_t = 1, None
+        # the best of five runs per candidate (a sum of three let one preempted run decide: a box of round 4 settled on
+        # 2 threads, 0.24 ms, where 4 take 0.19), then the SMALLEST thread count within 5 % of the fastest
+        times = {}
         for threads in (1, 2, 4, 8):
             if threads > max(1, cpus):
                 break
             ours(sample, threads)
-            t0 = time.perf_counter()
-            for _ in range(3):
+            best_run = None
+            for _ in range(5):
+                t0 = time.perf_counter()
                 ours(sample, threads)
-            dt = time.perf_counter() - t0
-            if best_t is None or dt < 0.9 * best_t:
-                best, best_t = threads, dt
-        return best
+                dt = time.perf_counter() - t0
+                best_run = dt if best_run is None or dt < best_run else best_run
+            times[threads] = best_run
+        fastest = min(times.values())
+        return min(t for t, dt in times.items() if dt <= 1.05 * fastest)
 
 
 def host_sort_threads() -> int:
