@@ -1,4 +1,7 @@
-"""Developer A/B: independent waves per workgroup in seg_reduce_kernel (RUA_REDUCE_WPB=0|2|4) at cfg3, cfg2 and the
+"""Developer A/B: independent waves per workgroup in seg_reduce_kernel at cfg3, cfg2 and the north-star shape.  The numbers in
+profiles/r04_reduce_wpb_ab.txt came from a build with a temporary RUA_REDUCE_WPB=0|2|4 knob (the rule it found is now
+fixed in launch_reduce); against HEAD the script times the shipped rule and labels the row with whatever the variable says.
+(RUA_REDUCE_WPB=0|2|4) at cfg3, cfg2 and the
 north-star shape; bursts of 8, HIP events."""
 import os
 import sys

@@ -1,3 +1,5 @@
+# rua_host_sort_desc of 65 536 lengths by thread count (profiles/r04_host_sort_scaling.txt; its spawn_min column came from a
+# build with a temporary RUA_HOST_SORT_SPAWN_MIN knob: 4 096 stayed)
 import time, torch, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from torchrua_amd import _lib as L

@@ -435,10 +435,6 @@ NARROW_ROW_BYTES = 64      # rows up to this get the tile table (rua_move.hip: T
 
 def tile_shape_log2(row_bytes: int) -> Tuple[int, int]:
     """(log2 time steps, log2 ranks) of a (rank x time) tile by row width (rua_move.hip: pack_tile_lds_kernel)."""
-    knob = os.environ.get('RUA_TILE_LOG2')            # developer A/B: "<ttl>,<trl>" for every narrow row width
-    if knob:
-        ttl, trl = knob.split(',')
-        return int(ttl), int(trl)
     return (6 if row_bytes <= 16 else 5 if row_bytes <= 32 else 4), 4
 
 

@@ -46,8 +46,9 @@ struct KV8 { int32_t key; uint32_t idx; };
 template <typename KV> inline bool before(const KV& a, const KV& b) { return a.key > b.key; }   // descending, key only
 
 constexpr int64_t LEAF = 16;          // segments up to this size are left to the insertion sort
-// right halves at least this long become tasks of their own (RUA_HOST_SORT_SPAWN_MIN: developer knob for A/B runs)
-const int64_t SPAWN_MIN = [] { const char* e = std::getenv("RUA_HOST_SORT_SPAWN_MIN"); const int64_t v = e ? atoll(e) : 0; return v >= 64 ? v : (int64_t)4096; }();
+// right halves at least this long become tasks of their own (2 048, 1 024 and 512 measured slower on 4-16 threads:
+// profiles/r04_host_sort_scaling.txt)
+constexpr int64_t SPAWN_MIN = 4096;
 
 inline int64_t floor_log2(int64_t n) { int64_t l = 0; while (n > 1) { n >>= 1; ++l; } return l; }
 

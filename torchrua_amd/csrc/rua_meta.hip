@@ -581,9 +581,8 @@ int rua_enum_rows(const rua_layout* lay, int64_t n_tokens, int64_t* batch_ptr, i
   }
   // the batch-major layouts with ragged lengths (C.idx() alone stays an iota)
   if (lay->kind != RUA_PACK && lay->off && lay->lens && (batch_ptr || token_ptr || lay->kind != RUA_CAT)) {
-    static const int seq_knob = [] { const char* e = getenv("RUA_ENUM_SEQ"); return e ? atoi(e) : -1; }();   // developer A/B
     const int64_t min_avg = (batch_ptr || token_ptr) ? ENUM_SEQ_MIN_AVG_PTR : ENUM_SEQ_MIN_AVG_FLAT;
-    const bool by_seq = seq_knob >= 0 ? seq_knob != 0 : n_tokens >= lay->B * min_avg;
+    const bool by_seq = n_tokens >= lay->B * min_avg;
     if (by_seq && lay->len_add == 0) {
       const int64_t waves = (lay->B + ENUM_SEQ_PER_WAVE - 1) / ENUM_SEQ_PER_WAVE;
       hipLaunchKernelGGL(enum_seq_kernel, dim3((unsigned)((waves + RUA_WAVES_PER_BLOCK - 1) / RUA_WAVES_PER_BLOCK)),

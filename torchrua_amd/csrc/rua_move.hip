@@ -700,8 +700,7 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
                                 dst->bsz && dst->boff && dst->boff == src->boff && dst->sorted == src->sorted &&
                                 dst->len_add == 0 && src->len_add == 0 && dst->T == src->T && dst->T > 0;
   // ... and on the (rank x time) tiles when the caller handed the tile table over (pack_roll_tile_kernel)
-  static const bool no_roll_tiles = [] { const char* e = getenv("RUA_NO_ROLL_TILES"); return e && e[0] == '1'; }();   // developer A/B
-  if (narrow_same_pack && !no_roll_tiles && dst->tile_start && dst->n_tiles > 0 && dst->lens && dst->sorted &&
+  if (narrow_same_pack && dst->tile_start && dst->n_tiles > 0 && dst->lens && dst->sorted &&
       pad_row < 0 && (flags & ~(RUA_MOVE_XCD_SPAN_ON | RUA_MOVE_XCD_SPAN_OFF)) == 0 &&
       (tmap == RUA_T_ROLL || tmap == RUA_T_REV_S || tmap == RUA_T_REV_D || tmap == RUA_T_SHIFT)) {
     bool span = dst->n_tiles >= MOVE_SPAN_MIN_TILES_DENSE;

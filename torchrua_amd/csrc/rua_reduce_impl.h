@@ -1397,9 +1397,8 @@ static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout&
   // neighbouring storage, and halving the number of workgroups is worth 6-9 % there (cfg3 segment_sum 108.8 -> 101.3 us,
   // north-star segment_sum(c) 2.86 -> 2.70 ms); four are no better, and over a PackedSequence — walked longest sequence
   // first, every rank its own slot — two LOSE 7 % (2.64 -> 2.84 ms): one wave per workgroup stays there
-  // (profiles/r04_reduce_wpb_ab.txt; RUA_REDUCE_WPB=1|2|4 is the developer knob of that A/B).
-  static const int wpb_knob = [] { const char* e = getenv("RUA_REDUCE_WPB"); return e ? atoi(e) : 0; }();
-  const int wpb = (COPY || CPW != 1) ? 1 : wpb_knob > 0 ? wpb_knob : (L.kind != RUA_PACK ? 2 : 1);
+  // (profiles/r04_reduce_wpb_ab.txt, measured with a temporary environment knob).
+  const int wpb = (COPY || CPW != 1) ? 1 : (L.kind != RUA_PACK ? 2 : 1);
 #define RUA_LAUNCH(OP)                                                                                              \
   if (do_split) {                                                                                                   \
     hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY, true, CPW>), g, b, 0, s, L, perm, (const T*)data,   \
@@ -1412,9 +1411,6 @@ static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout&
                        H, lp_log2, include_self, ev, CD, COPY ? 1 : 0, W);                                          \
   } else if (wpb == 2) {                                                                                            \
     hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY, false, CPW, 2>), dim3((grid + 1) / 2), dim3(RUA_WAVE * 2), \
-                       0, s, L, perm, (const T*)data, (T*)out, H, lp_log2, n_chunks, include_self, ev, ext, CD, (T*)copy, W); \
-  } else if (wpb == 4) {                                                                                            \
-    hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY, false, CPW, 4>), dim3((grid + 3) / 4), dim3(RUA_WAVE * 4), \
                        0, s, L, perm, (const T*)data, (T*)out, H, lp_log2, n_chunks, include_self, ev, ext, CD, (T*)copy, W); \
   } else {                                                                                                          \
     hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY, false, CPW>), g, b, 0, s, L, perm, (const T*)data,  \

@@ -252,10 +252,8 @@ int rua_index_buckets(const int64_t* index, int64_t M, int64_t S, int64_t* count
     if (e == hipSuccess) e = hipMemsetAsync(off, 0, sizeof(int64_t) * (size_t)S, s);
     return (int)e;
   }
-  // 513 .. 262 144 destinations: most significant digit first, the second level local to a bin (rua_bucket_msd.hip);
-  // RUA_BUCKET_LSD=1 (a developer knob for A/B runs) keeps the least-significant-digit-first passes below
-  static const bool force_lsd = [] { const char* e = getenv("RUA_BUCKET_LSD"); return e && e[0] == '1'; }();
-  if (!force_lsd && bucket_msd_applies(M, S)) return bucket_msd(index, M, S, counts, off, perm, (void*)ws, s);
+  // 513 .. 262 144 destinations: most significant digit first, the second level local to a bin (rua_bucket_msd.hip)
+  if (bucket_msd_applies(M, S)) return bucket_msd(index, M, S, counts, off, perm, (void*)ws, s);
   const int64_t nb = (M + SORT_BLOCK - 1) / SORT_BLOCK;
   if (nb > 0x7ffffff0LL) return RUA_ERANGE;
   const int64_t per_xcd = (nb + 7) / 8;
