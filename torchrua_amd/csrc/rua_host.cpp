@@ -237,7 +237,7 @@ inline void leaf_sort_fast(KV8* first, KV8* last, bool small_keys) {
 }
 inline void leaf_sort_fast(KV16* first, KV16* last, bool) { leaf_sort(first, last); }
 
-struct Task { void* first; void* last; int64_t depth; bool narrow; bool small_keys; };
+struct Task { void* first; void* last; int64_t depth; bool narrow; bool small_keys; const void* base; int64_t* out; };
 
 std::atomic<int64_t> g_heap_segments{0};   // diagnostics: segments that ran out of depth budget, all calls so far
 
@@ -249,12 +249,18 @@ class Pool {
   }
 
   // sort [first, last) with up to `threads` threads (the caller is one of them)
+  // `out`: sorted_indices.  Every finished piece of the array — a leaf, a heap-sorted segment — writes its own slice
+  // of it (its elements are in their final places, and the piece is hot in that thread's cache): the closing pass over
+  // the whole array (65 536 elements: ~20 us on one thread, after everything else) is gone.
   template <typename KV>
-  void sort(KV* first, KV* last, int threads, bool small_keys = false) {
+  void sort(KV* first, KV* last, int threads, int64_t* out, bool small_keys = false) {
     const int64_t n = last - first;
-    if (n < 2) return;
+    if (n < 2) {
+      if (n == 1) out[0] = (int64_t)first->idx;
+      return;
+    }
     const int64_t depth = 2 * floor_log2(n);
-    const Task root{first, last, depth, sizeof(KV) == sizeof(KV8), small_keys};
+    const Task root{first, last, depth, sizeof(KV) == sizeof(KV8), small_keys, first, out};
     if (threads <= 1 || n < 2 * SPAWN_MIN) {
       run(root, false);
       return;
@@ -363,15 +369,23 @@ class Pool {
         g_heap_segments.fetch_add(1, std::memory_order_relaxed);
         std::make_heap(first, last, before<KV>);
         std::sort_heap(first, last, before<KV>);
+        write_out(first, last, t);
         return;
       }
       --depth;
       KV* cut = last - first >= BRANCHLESS_MIN ? partition_pivot_lists(first, last) : partition_pivot(first, last);
-      if (spawn && last - cut >= SPAWN_MIN) push(Task{cut, last, depth, t.narrow, t.small_keys});
-      else run_t<KV>(Task{cut, last, depth, t.narrow, t.small_keys}, spawn);
+      if (spawn && last - cut >= SPAWN_MIN) push(Task{cut, last, depth, t.narrow, t.small_keys, t.base, t.out});
+      else run_t<KV>(Task{cut, last, depth, t.narrow, t.small_keys, t.base, t.out}, spawn);
       last = cut;
     }
     leaf_sort_fast(first, last, t.small_keys);
+    write_out(first, last, t);
+  }
+
+  template <typename KV>
+  static inline void write_out(const KV* first, const KV* last, const Task& t) {
+    int64_t* __restrict__ o = t.out + (first - static_cast<const KV*>(t.base));
+    for (const KV* p = first; p != last; ++p) *o++ = (int64_t)p->idx;
   }
 
   std::mutex m_, entry_;
@@ -398,19 +412,26 @@ int rua_host_sort_desc(const int64_t* keys, int64_t n, int64_t* sorted_indices, 
   std::vector<KV16>& v = scratch();
   if ((int64_t)v.size() < n + 16) v.resize((size_t)n + 16);
   const int threads = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
-  int64_t lo = keys[0], hi = keys[0];
-  for (int64_t i = 1; i < n; ++i) { lo = keys[i] < lo ? keys[i] : lo; hi = keys[i] > hi ? keys[i] : hi; }
-  if (lo >= INT32_MIN && hi <= INT32_MAX && n <= 0xffffffffLL) {
+  // the narrow elements are filled optimistically while the key range is taken in the same pass (sequence lengths
+  // always fit: a second, wide fill happens only for keys beyond 32 bits)
+  if (n <= 0xffffffffLL) {
     KV8* a = reinterpret_cast<KV8*>(v.data());       // (the scratch is sized for the wide elements)
-    for (int64_t i = 0; i < n; ++i) { a[i].key = (int32_t)keys[i]; a[i].idx = (uint32_t)i; }
-    Pool::get().sort(a, a + n, threads, lo >= 0 && hi < (1 << 27));
-    for (int64_t i = 0; i < n; ++i) sorted_indices[i] = (int64_t)a[i].idx;
-    return 0;
+    int64_t lo = keys[0], hi = keys[0];
+    for (int64_t i = 0; i < n; ++i) {
+      const int64_t k = keys[i];
+      lo = k < lo ? k : lo;
+      hi = k > hi ? k : hi;
+      a[i].key = (int32_t)k;
+      a[i].idx = (uint32_t)i;
+    }
+    if (lo >= INT32_MIN && hi <= INT32_MAX) {
+      Pool::get().sort(a, a + n, threads, sorted_indices, lo >= 0 && hi < (1 << 27));
+      return 0;
+    }
   }
   KV16* a = v.data();
   for (int64_t i = 0; i < n; ++i) { a[i].key = keys[i]; a[i].idx = i; }
-  Pool::get().sort(a, a + n, threads);
-  for (int64_t i = 0; i < n; ++i) sorted_indices[i] = a[i].idx;
+  Pool::get().sort(a, a + n, threads, sorted_indices);
   return 0;
 }
 
