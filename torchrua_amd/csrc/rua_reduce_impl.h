@@ -1398,7 +1398,9 @@ static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout&
   // north-star segment_sum(c) 2.86 -> 2.70 ms); four are no better, and over a PackedSequence — walked longest sequence
   // first, every rank its own slot — two LOSE 7 % (2.64 -> 2.84 ms): one wave per workgroup stays there
   // (profiles/r04_reduce_wpb_ab.txt, measured with a temporary environment knob).
-  const int wpb = (COPY || CPW != 1) ? 1 : (L.kind != RUA_PACK ? 2 : 1);
+  // Rows of at least 512 bytes only: at 16 / 32-byte rows (a whole short sequence per wave instruction) two waves per
+  // workgroup lose 7-10 % (final width sweep of round 4: 2.36 -> 2.20, 4.40 -> 3.95 TB/s).
+  const int wpb = (COPY || CPW != 1) ? 1 : ((L.kind != RUA_PACK && H * (int64_t)sizeof(T) >= 512) ? 2 : 1);
 #define RUA_LAUNCH(OP)                                                                                              \
   if (do_split) {                                                                                                   \
     hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY, true, CPW>), g, b, 0, s, L, perm, (const T*)data,   \
