@@ -333,7 +333,7 @@ struct TileTables {
 
 template <int TTL, int TRL>
 __device__ __forceinline__ void tile_tables(const rua_layout& Pk, const rua_layout& Ot, int64_t tile, TileTables& tb,
-                                            int64_t& r0_out) {
+                                            int64_t& r0_out, int64_t& t0_out) {
   constexpr int TT = 1 << TTL, TR = 1 << TRL;
   // which time chunk does this tile belong to?  largest c with tile_start[c] <= tile.  Up to 64 chunks
   // every lane loads one entry and a ballot counts them: ONE load instead of a six-step chain of dependent ones
@@ -352,6 +352,7 @@ __device__ __forceinline__ void tile_tables(const rua_layout& Pk, const rua_layo
   const int64_t t0 = lo * TT;
   const int64_t r0 = (tile - Pk.tile_start[lo]) * TR;
   r0_out = r0;
+  t0_out = t0;
   const int i = threadIdx.x;
   if (i < TR) {                                   // wave 0, lanes 0..15: the ranks
     const int64_t r = r0 + i;
@@ -393,8 +394,9 @@ __global__ __launch_bounds__(RUA_BLOCK) void pack_tile_lds_kernel(rua_layout Pk,
     tile = (int64_t)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
     if ((int64_t)(blockIdx.x >> 3) >= tiles_per_xcd || tile >= Pk.n_tiles) return;
   }
-  int64_t r0;
-  tile_tables<TTL, TRL>(Pk, Ot, tile, tb, r0);
+  int64_t r0, t0;
+  tile_tables<TTL, TRL>(Pk, Ot, tile, tb, r0, t0);
+  (void)t0;
   __syncthreads();
 
   // ---- phase 2: the tile goes through LDS.  It is read in the SOURCE's contiguous order (consecutive lanes =
@@ -448,28 +450,9 @@ __global__ __launch_bounds__(RUA_BLOCK) void pack_roll_tile_kernel(rua_layout Pk
     tile = (int64_t)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
     if ((int64_t)(blockIdx.x >> 3) >= tiles_per_xcd || tile >= Pk.n_tiles) return;
   }
-  int64_t r0;
-  tile_tables<TTL, 4>(Pk, Pk, tile, tb, r0);      // olen[rank] = tokens of the rank's sequence from the tile's first step on
+  int64_t r0, t0;                                  // olen[rank] = tokens of the rank's sequence from the tile's first step
+  tile_tables<TTL, 4>(Pk, Pk, tile, tb, r0, t0);   // (t0) on; the token map needs the absolute step t0 + time
   __syncthreads();
-  // first time step of the tile = (length - what is left from there on) of any live rank; recomputed from the tables:
-  // pboff / pbsz are indexed by the step inside the tile, the token map needs the absolute step
-  int64_t lo = 0;
-  {
-    // (the same chunk search as tile_tables: block-uniform, one load + ballot)
-    if (Pk.n_tchunks <= RUA_WAVE) {
-      const int lane = threadIdx.x & (RUA_WAVE - 1);
-      const int64_t v = lane < Pk.n_tchunks ? Pk.tile_start[lane] : 0x7fffffffffffffffLL;
-      lo = (int64_t)__popcll(__ballot(v <= tile)) - 1;
-      if (lo < 0) lo = 0;
-    } else {
-      int64_t hi = Pk.n_tchunks;
-      while (hi - lo > 1) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (Pk.tile_start[mid] <= tile) lo = mid; else hi = mid;
-      }
-    }
-  }
-  const int64_t t0 = lo * TT;
   const V fillv = fill_of<VEC>(fillpat);
   const int n_pieces = TILE * (int)lpr;
 #pragma unroll 4
