@@ -77,6 +77,28 @@ def test_integer_scatter_against_the_calls_the_reference_makes(dtype):
                 assert torch.equal(got.cpu(), want), f'{dtype} scatter_sum include_self={inc} dim={dim}'
 
 
+def test_integer_scatter_edge_shapes():
+    """No entries at all, one destination, empty rows, a 3-d target: what torch's own calls return on the CPU."""
+    import warnings
+    for shape_t, Mn in (((4, 3), 0), ((1, 5), 17), ((6, 0), 9), ((3, 2, 2), 8), ((5,), 0)):
+        g = torch.Generator().manual_seed(len(shape_t) * 100 + Mn)
+        S = shape_t[0]
+        idx = torch.randint(0, S, (Mn,), generator=g)
+        ten = torch.randint(-9, 10, shape_t, generator=g)
+        src = torch.randint(-9, 10, (Mn,) + shape_t[1:], generator=g)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            for name, red in (('max', 'amax'), ('min', 'amin'), ('mean', 'mean'), ('prod', 'prod')):
+                for inc in (False, True):
+                    want = torch.index_reduce(ten, 0, idx, src, red, include_self=inc)
+                    got = getattr(ta, f'scatter_{name}')(ten.to(DEV), idx.to(DEV), src.to(DEV), include_self=inc)
+                    assert got.shape == want.shape and torch.equal(got.cpu(), want), (shape_t, Mn, name, inc)
+            for inc in (False, True):
+                want = torch.index_add(ten if inc else torch.zeros_like(ten), 0, idx, src)
+                got = ta.scatter_sum(ten.to(DEV), idx.to(DEV), src.to(DEV), include_self=inc)
+                assert got.shape == want.shape and torch.equal(got.cpu(), want), (shape_t, Mn, 'sum', inc)
+
+
 def test_integer_scatter_counts_tokens_at_scale():
     """The ordinary use: tokens per bucket = scatter_sum of ones on a long tensor; 4 M entries."""
     g = torch.Generator().manual_seed(7)
