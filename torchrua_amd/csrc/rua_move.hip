@@ -407,9 +407,11 @@ __global__ __launch_bounds__(RUA_BLOCK) void pack_tile_lds_kernel(rua_layout Pk,
   extern __shared__ __attribute__((aligned(16))) unsigned char s_stage_raw[];
   V* stage = reinterpret_cast<V*>(s_stage_raw);
   const int n_pieces = TILE * (int)lpr;
-  // one padding slot per RANK: the transposed order strides over TT * lpr slots, which would otherwise
-  // land the sixteen ranks of a time step on the same LDS banks
-#define RUA_SLOT(rank, time, piece) ((((rank) << TTL) | (time)) * (int)lpr + (piece) + (rank))
+  // one padding ROW (lpr slots) per rank: the transposed order strides over TT * lpr slots, which would otherwise land
+  // the sixteen ranks of a time step on the same LDS banks; with (TT + 1) * lpr the sixteen lanes of a 128-bit LDS
+  // pass — ranks x pieces — fall on sixteen different bank groups (a single slot of padding left piece 1 of rank r
+  // on the banks of piece 0 of rank r + 1)
+#define RUA_SLOT(rank, time, piece) (((((rank) << TTL) | (time)) + (rank)) * (int)lpr + (piece))
 #define RUA_CELL(rank, time, orow, prow, live)                                                           \
   const int64_t orow = tb.obase[rank] + (time), prow = tb.pboff[time] + r0 + (rank);                      \
   const bool live = (time) < tb.olen[rank] && r0 + (rank) < tb.pbsz[time] && orow < Ot.n_rows && prow < Pk.n_rows
@@ -502,7 +504,7 @@ static int launch_pack_tiles(int vec, hipStream_t s, const rua_layout& Pk, const
   const int ttl = (Pk.tile_t_log2 & 0xff) == 0 ? 4 : (Pk.tile_t_log2 & 0xff);      // (0: a caller of ABI <= 3, 16 x 16 tiles)
   const int trl = ((Pk.tile_t_log2 >> 8) & 0xff) == 0 ? 4 : ((Pk.tile_t_log2 >> 8) & 0xff);
   if (ttl < 4 || ttl > 6 || trl != 4) return RUA_EINVAL;
-  const size_t lds = (size_t)(((int64_t)1 << (ttl + trl)) * lpr + ((int64_t)1 << trl)) * vec;   // the staged tile + its padding slots
+  const size_t lds = (size_t)((((int64_t)1 << (ttl + trl)) + ((int64_t)1 << trl)) * lpr) * vec;   // the staged tile + one padding row per rank
   if (lds > (48u << 10)) return RUA_EINVAL;                            // (the host picks the tile by row width: 32 KiB staged at most)
 #define RUA_LAUNCH_T(VEC, TTLV, TRLV) \
   hipLaunchKernelGGL((pack_tile_lds_kernel<VEC, TO_PACK, TTLV, TRLV>), g, b, lds, s, Pk, Ot, dst, src, row_bytes, lpr, per_xcd)
