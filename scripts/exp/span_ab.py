@@ -29,7 +29,7 @@ def med(fn, reps, rounds=7):
     return sorted(ts)[len(ts) // 2] * 1e3
 
 
-for B, H in ((8192, 512), (16384, 512), (32768, 512), (65536, 512), (32768, 1024)):
+for B, H in ([(int(sys.argv[1]), int(sys.argv[2]))] if len(sys.argv) > 2 else ((8192, 512), (16384, 512), (32768, 512), (65536, 512), (32768, 1024))):
     g = torch.Generator().manual_seed(2)
     lens = torch.randint(8, 513, (B,), generator=g)
     N = int(lens.sum())
