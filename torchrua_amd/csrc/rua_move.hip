@@ -32,6 +32,11 @@ constexpr int64_t MOVE_SPAN_MIN_TILES_DENSE = 1 << 19;   // ... when the destina
 // traffic is stores, and a span per XCD is worth 11-13 % to them at every size measured); a gather into a dense
 // destination (C / P) only draws level from ~8 GB up and LOSES 2-5 % below (cfg2's 0.5 GB: 183 -> 173 us with plain
 // blockIdx order; gpurun_out/r4j/midsize_ab.txt, r4k/span_ab.txt -> profiles/r04_span_ab.txt)
+// The (rank x time) tiles of narrow rows have their own rule (profiles/r04_narrow_span_ab.txt): neighbouring tiles share
+// the 128-byte lines their 512-byte runs straddle, and only a span keeps the two on one XCD's L2.  Pack and the roll
+// tiles gain at every size (16-byte rows: 3.0 -> 4.5 and 3.7 -> 4.4-4.6 TB/s; 32: 3.7 -> 4.9 and 4.5 -> 5.0); P.cat,
+// whose stores are whole 1-KiB runs either way, gains from ~8 GB (4-9 %) and loses 2-8 % at 1-3 GB.
+constexpr int64_t TILE_SPAN_MIN_TILES_FROM_PACK = 1 << 18;
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -645,7 +650,7 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
     const bool from_pack = src->kind == RUA_PACK && dst->kind == RUA_CAT;   // padded destinations need the fill pass
     const rua_layout* pk = to_pack ? dst : src;
     if ((to_pack || from_pack) && pk->tile_start && pk->bsz && pk->n_tiles > 0 && pk->boff) {
-      bool span = pk->n_tiles >= MOVE_SPAN_MIN_TILES;
+      bool span = pk->n_tiles >= (to_pack ? MOVE_SPAN_MIN_TILES : TILE_SPAN_MIN_TILES_FROM_PACK);
       if (flags & RUA_MOVE_XCD_SPAN_ON) span = true;
       if (flags & RUA_MOVE_XCD_SPAN_OFF) span = false;
       return to_pack ? launch_pack_tiles<true>(vec, s, *dst, *src, (char*)dst_data, (const char*)src_data, row_bytes, span)
@@ -688,7 +693,7 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
   if (narrow_same_pack && dst->tile_start && dst->n_tiles > 0 && dst->lens && dst->sorted &&
       pad_row < 0 && (flags & ~(RUA_MOVE_XCD_SPAN_ON | RUA_MOVE_XCD_SPAN_OFF)) == 0 &&
       (tmap == RUA_T_ROLL || tmap == RUA_T_REV_S || tmap == RUA_T_REV_D || tmap == RUA_T_SHIFT)) {
-    bool span = dst->n_tiles >= MOVE_SPAN_MIN_TILES_DENSE;
+    bool span = dst->n_tiles >= MOVE_SPAN_MIN_TILES;
     if (flags & RUA_MOVE_XCD_SPAN_ON) span = true;
     if (flags & RUA_MOVE_XCD_SPAN_OFF) span = false;
     return launch_roll_tiles(vec, s, *dst, tmap, tmap_arg, d, c, row_bytes, fp, span);
