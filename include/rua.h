@@ -188,6 +188,9 @@ enum rua_op {
  * split_rows > 0 (with `ws` of rua_reduce_ws_bytes(lay->n_rows, H, dtype, split_rows) bytes) cuts sequences
  * longer than split_rows into parts handled by separate waves (published through a device-side work list,
  * fp32 partials folded in part order: deterministic); 0 = one wave streams each sequence.
+ * Integer dtypes (RUA_I64 .. RUA_U8; CAT only, SUM / MEAN / MAX / MIN / PROD in the element type, as ATen's
+ * index_reduce / index_add do): the same two arguments cut buckets longer than split_rows by POSITION into ranges of
+ * split_rows, int64 partials in `ws` (exact in any order; two small launches when no bucket is long).
  * ties_out (MAX/MIN; may be NULL): [B, H] f32 (f64 for RUA_F64) that receives, per output element, how many elements
  * of the sequence equal it (with include_self == 1 the old row is folded into the result but not counted; rows that
  * include_self == 2 leaves untouched are not written: pre-zero the buffer) — what the backward needs, for free in the pass that

@@ -116,6 +116,15 @@ def test_reducer_split_policy():
     blind = M.reduce_split_rows(FakeLay(1_070_000, 4096, None), 512)           # cfg2 with device-only lengths:
     assert blind > 512                                                         # armed, but nothing of cfg2 is cut
     assert M.reduce_split_rows(FakeLay(200, 3, 150), 1024) == 0
+    # the buckets of a scatter_* (sizes on the device, one hot bucket is ordinary): always armed from 64 MB of payload
+    hot = FakeLay(4_000_000, 100_000, None)
+    assert M.reduce_split_rows(hot, 128) == 0
+    assert M.reduce_split_rows(FakeLay(17_046_960, 100_000, None), 128) > 0      # 2 GB with device-only lengths: armed too
+    hot.heavy_tail = True
+    assert M.reduce_split_rows(hot, 128) > 0 and M.reduce_split_rows(hot, 1024, team_ok=False) > 0
+    small = FakeLay(20_000, 5_000, None)
+    small.heavy_tail = True
+    assert M.reduce_split_rows(small, 128) == 0
     # the wave-team rule the planner prices with IS the launcher's (rua_reduce_team_waves): a few fixed points
     lib = _lib.load()
     assert lib.rua_reduce_team_waves(133_000, 512, 1024) == 4 and lib.rua_reduce_team_waves(133_000, 512, 1000) == 4

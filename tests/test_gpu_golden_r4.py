@@ -112,6 +112,50 @@ def test_integer_scatter_counts_tokens_at_scale():
     assert torch.equal(wide[:, 0].long(), last) and torch.equal(wide[:, 3].long(), last)
 
 
+@pytest.mark.parametrize('dtype', [torch.int64, torch.int8, torch.uint8])
+@pytest.mark.parametrize('H', [1, 5, 32, 130])
+def test_integer_scatter_long_buckets(dtype, H):
+    """Buckets longer than the reducer's part (1 024 rows below a million entries) are cut by position
+    (rua_reduce_int.hip): neighbouring long buckets, one of exactly the part size (not long), one that starts on a cut,
+    empty ones in between, everything in one bucket — against torch's own calls on the CPU."""
+    import warnings
+    info = torch.iinfo(dtype)
+    for counts in ([3077, 0, 1, 1025, 1024, 7, 2048, 1, 1030, 0], [1024, 2049, 1025], [0, 0, 5000], [4099], [1] * 50 + [4050]):
+        S = len(counts)
+        g = torch.Generator().manual_seed(S * 1000 + H)
+        idx = torch.repeat_interleave(torch.arange(S), torch.tensor(counts))
+        idx = idx[torch.randperm(idx.numel(), generator=g)]
+        Mn = idx.numel()
+        ten = torch.randint(max(info.min, -3), min(info.max, 3) + 1, (S, H), generator=g).to(dtype)
+        src = torch.randint(max(info.min, -3), min(info.max, 3) + 1, (Mn, H), generator=g).to(dtype)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            for name, red in (('max', 'amax'), ('min', 'amin'), ('mean', 'mean'), ('prod', 'prod')):
+                for inc in (False, True):
+                    want = torch.index_reduce(ten, 0, idx, src, red, include_self=inc)
+                    got = getattr(ta, f'scatter_{name}')(ten.to(DEV), idx.to(DEV), src.to(DEV), include_self=inc)
+                    assert torch.equal(got.cpu(), want), f'{dtype} H={H} {counts[:4]} scatter_{name} include_self={inc}'
+            for inc in (False, True):
+                want = torch.index_add(ten if inc else torch.zeros_like(ten), 0, idx, src)
+                got = ta.scatter_sum(ten.to(DEV), idx.to(DEV), src.to(DEV), include_self=inc)
+                assert torch.equal(got.cpu(), want), f'{dtype} H={H} {counts[:4]} scatter_sum include_self={inc}'
+
+
+def test_integer_scatter_skewed_histogram_at_scale():
+    """A third of 4 M tokens in ONE bucket, a Zipf tail over the rest: counts == bincount, and the maximum row index per
+    bucket (a 4-column int32 payload) == scatter_reduce's."""
+    g = torch.Generator().manual_seed(11)
+    S, Mn = 50000, 1 << 22
+    u = torch.rand(Mn, generator=g)
+    idx = torch.where(u < 0.33, torch.full((Mn,), 17), (torch.rand(Mn, generator=g) ** 4 * S).long().clamp_(0, S - 1)).to(DEV)
+    got = ta.scatter_sum(torch.zeros(S, dtype=torch.long, device=DEV), idx, torch.ones(Mn, dtype=torch.long, device=DEV))
+    assert torch.equal(got, torch.bincount(idx, minlength=S))
+    wide = ta.scatter_max(torch.full((S, 4), -1, dtype=torch.int32, device=DEV), idx,
+                          torch.arange(Mn, device=DEV, dtype=torch.int32)[:, None].expand(Mn, 4).contiguous(), include_self=True)
+    last = torch.full((S,), -1, dtype=torch.long, device=DEV).scatter_reduce_(0, idx, torch.arange(Mn, device=DEV), 'amax')
+    assert torch.equal(wide[:, 0].long(), last) and torch.equal(wide[:, 3].long(), last)
+
+
 def test_integer_scatter_rejects_what_it_cannot_do():
     ten = torch.zeros(4, 2, dtype=torch.long, device=DEV)
     idx = torch.tensor([0, 1], device=DEV)

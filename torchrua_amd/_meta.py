@@ -377,7 +377,7 @@ def known_max_len(token_sizes: Optional[Tensor]) -> Optional[int]:
 
 class Lay:
     """A rua_layout plus the tensors its pointers borrow (kept alive with it)."""
-    __slots__ = ('c', 'keep', 'kind', 'n_rows', 'B', 'max_len', '_no_empty')
+    __slots__ = ('c', 'keep', 'kind', 'n_rows', 'B', 'max_len', '_no_empty', 'heavy_tail')
 
     def __init__(self, keep: List[Optional[Tensor]], max_len: Optional[int] = None, **fields):
         self.c = L.RuaLayout(**fields)
@@ -387,6 +387,7 @@ class Lay:
         self.B = fields['B']
         self.max_len = max_len      # longest sequence, when the host knows it for free
         self._no_empty = False      # bool, or a callable that decides on first use (set by the lay_* builders)
+        self.heavy_tail = False     # the buckets of a scatter_*: sizes counted on the device, ONE hot bucket is ordinary
 
     def ref(self):
         return ctypes.byref(self.c)
@@ -673,6 +674,8 @@ ENOUGH_UNITS = 4096          # (sequence, column chunk) units that keep every SI
 WAVE_RATE = 4e9              # bytes/s ONE wave streams (8 KiB in flight / ~2 us; profiles/r01_skew.txt)
 STREAM_RATE = 5e12           # bytes/s the whole chip reads through the reducer
 SPLIT_FIXED_S = 30e-6        # what arming costs: one memset, a tail and a combine launch
+ARM_ALWAYS_BYTES_PLAIN = 1 << 30
+ARM_ALWAYS_BYTES = 64 << 20  # scatter_* payloads from here on always arm the split (bucket sizes live on the device)
 
 
 def reduce_split_rows(lay: Lay, row_bytes: int = 1024, team_ok: bool = True, tail_ok: bool = True) -> int:
@@ -684,8 +687,8 @@ def reduce_split_rows(lay: Lay, row_bytes: int = 1024, team_ok: bool = True, tai
     machinery (`fixed_rows`).  Measured on the mid-size BASELINE shapes (profiles/r01_mid_sizes.txt): splitting sequences that
     do not need it halves the rate.  The part size fills the chip (n_rows / 8192) when there are few units, and is
     raised to that threshold when there are plenty, so that only real outliers are cut.  When the host does not know
-    the longest sequence (device-only lengths) the machinery is armed only where a tail could matter: long average
-    sequences or few of them.  team_ok=False: the caller's kernel has no wave teams (the backward walk, the fused
+    the longest sequence (device-only lengths) the machinery is armed where a tail could matter: long average
+    sequences, few of them, or the buckets of a scatter_* (`lay.heavy_tail`) from 64 MB of payload on.  team_ok=False: the caller's kernel has no wave teams (the backward walk, the fused
     pack + reduce), so a unit streams at the single-wave rate.  tail_ok=False: rows of 8 (mod 16) bytes will NOT take
     the 16-byte-lane path there (include_self == 1, or a payload that is not 8-byte aligned: the launcher's `tail_ok`),
     so no team either."""
@@ -710,4 +713,12 @@ def reduce_split_rows(lay: Lay, row_bytes: int = 1024, team_ok: bool = True, tai
     if lay.max_len is not None:
         # worth it when the longest walk exceeds what remains after splitting (a part, or the balanced time) + the fixed cost
         return part if lay.max_len > max(part, ideal_rows) + fixed_rows else 0
-    return part if (n >= 256 * max(lay.B, 1) or lay.B < 1024) else 0
+    # (the buckets of a scatter_* — `heavy_tail` — are counted on the device and a skewed histogram with ONE hot bucket
+    # is the ordinary case there; an unsplit hot bucket is a cliff, not a slope — a third of 17 M rows in one of 100 000
+    # buckets: 171 ms / 1.15 s at 128-byte / 1-KiB rows against 0.9 / 3.5 ms split — while arming costs 5-7 us when
+    # nothing is long (profiles/r04_skew.txt): from 64 MB of payload on they always arm the machinery)
+    armed = n >= 256 * max(lay.B, 1) or lay.B < 1024
+    # (any other layout with device-only lengths: from 1 GB on, where the 5-7 us are below 3 % of the call)
+    if n * max(1, int(row_bytes)) >= (ARM_ALWAYS_BYTES if getattr(lay, 'heavy_tail', False) else ARM_ALWAYS_BYTES_PLAIN):
+        armed = True
+    return part if armed else 0

@@ -171,6 +171,18 @@ def split_workspace(lay: M.Lay, H: int, dtype: torch.dtype, dev, team_ok: bool =
     return split, torch.empty(nbytes, dtype=torch.uint8, device=dev)
 
 
+def int_split_workspace(n_rows: int, H: int, dtype: torch.dtype, dev) -> Tuple[int, Optional[Tensor]]:
+    """(split_rows, workspace) of the INTEGER reducer's long-bucket split (rua_reduce_int.hip).  Always armed from a few
+    thousand rows on: the bucket sizes live on the device, a skewed histogram is the ordinary case, and when no bucket
+    is long the machinery costs two launches of at most ~1 024 waves that find nothing to do."""
+    if n_rows < 4096:
+        return 0, None
+    # about a thousand parts, but no part beyond ~2 MB of payload: a part is ONE wave's walk (profiles/r04_int_skew.txt)
+    split = max(1024, min(n_rows // 1024, (2 << 20) // max(1, H * dtype.itemsize)))
+    nbytes = L.load().rua_reduce_ws_bytes(n_rows, H, L.INT_DTYPES[dtype], split)
+    return split, torch.empty(nbytes, dtype=torch.uint8, device=dev)
+
+
 def launch_reduce(lay: M.Lay, data: Tensor, op: int, out: Optional[Tensor] = None, include_self: int = 0,
                   perm: Optional[Tensor] = None, hidden: Tuple[int, ...] = (), reference_initial: bool = True,
                   name: str = 'reduce', ties_out: Optional[Tensor] = None) -> Tensor:
@@ -352,13 +364,15 @@ def scatter_sum_rows(rows: Tensor, index: Tensor, n_out: int) -> Tensor:
     hidden = tuple(rows.shape[1:])
     counts, perm = index_buckets(index, n_out)
     lay = M.lay_cat(counts, n_out, int(rows.size(0)))
+    lay.heavy_tail = True
     if rows.dtype in L.INT_DTYPES:        # (integer payloads carry no gradient: the integer reducer, for completeness)
         out = torch.empty((n_out,) + hidden, dtype=rows.dtype, device=rows.device)
         H = 1
         for d in hidden:
             H *= d
+        split, ws = int_split_workspace(int(rows.size(0)), H, rows.dtype, rows.device)
         L.check(L.load().rua_segment_reduce(lay.ref(), L.ptr(perm), L.ptr(rows.contiguous()), L.ptr(out), H,
-                                            L.INT_DTYPES[rows.dtype], L.SUM, 0, 0, None, 0, None, None,
+                                            L.INT_DTYPES[rows.dtype], L.SUM, 0, 0, None, split, L.ptr(ws), None,
                                             L.stream_ptr(rows.device)), 'rua_segment_reduce')
         return out
     return launch_reduce(lay, rows, L.SUM, perm=perm, hidden=hidden, reference_initial=False, name='scatter')

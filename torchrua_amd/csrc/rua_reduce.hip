@@ -27,7 +27,8 @@ RUA_DECL(f32) RUA_DECL(bf16) RUA_DECL(f16) RUA_DECL(f64)
 #undef RUA_DECL
 // integer element types (rua_reduce_int.hip)
 int reduce_int(int dtype, int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data, void* out,
-               int64_t H, int include_self);
+               int64_t H, int include_self, int64_t split, void* ws);
+int64_t reduce_int_ws_bytes(int64_t n_rows, int64_t H, int64_t split);
 }  // namespace rua
 
 using namespace rua;
@@ -93,6 +94,7 @@ int rua_scatter_self_grad(const int64_t* counts, int64_t S, int64_t H, const voi
 
 int64_t rua_reduce_ws_bytes(int64_t n_rows, int64_t H, int32_t dtype, int64_t split_rows) {
   if (split_rows <= 0 || n_rows <= 0 || H <= 0) return 0;
+  if (dtype >= RUA_I64 && dtype <= RUA_U8) return reduce_int_ws_bytes(n_rows, H, split_rows);
   const int64_t acc = dtype == RUA_F64 ? 8 : 4;
   const int64_t max_extra = n_rows / split_rows;
   const int64_t chunks_scalar = (H + RUA_WAVE - 1) / RUA_WAVE;              // worst case: one element per lane
@@ -118,7 +120,7 @@ int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* d
   hipStream_t s = (hipStream_t)stream;
   if (dtype >= RUA_I64 && dtype <= RUA_U8) {        // integer tensors: scatter_* only (reduce.py:6-23)
     if (ties || lay->kind != RUA_CAT) return RUA_EINVAL;
-    return reduce_int(dtype, op, s, *lay, perm, data, out, H, include_self);
+    return reduce_int(dtype, op, s, *lay, perm, data, out, H, include_self, split_rows, ws);
   }
   if (extreme && !clean && (op == RUA_MAX || op == RUA_MIN || op == RUA_LOGSUMEXP)) {
     hipLaunchKernelGGL(extreme_init_entry_kernel, dim3(1), dim3(128), 0, s, (unsigned long long*)extreme,

@@ -114,6 +114,7 @@ class _Scatter(torch.autograd.Function):
         S = tensor.size(0)
         counts, perm = _buckets(index, S)
         lay = M.lay_cat(counts, S, int(source.size(0)))
+        lay.heavy_tail = True
         hidden = tuple(tensor.shape[1:])
         # (row-major whatever the strides of `tensor`: the kernel addresses out[s * H + h])
         if op == K.SUM and not include_self:
@@ -255,8 +256,9 @@ def _scatter_int(tensor: T, index: T, source: T, op: int, include_self: bool) ->
     else:
         out, mode = tensor.detach().clone(memory_format=torch.contiguous_format), (1 if include_self else 2)
     source = source.detach().contiguous()
+    split, ws = O.int_split_workspace(int(source.size(0)), H, tensor.dtype, tensor.device)
     K.check(K.load().rua_segment_reduce(lay.ref(), K.ptr(perm), K.ptr(source), K.ptr(out), H, K.INT_DTYPES[tensor.dtype],
-                                        op, mode, 0, None, 0, None, None, K.stream_ptr(tensor.device)),
+                                        op, mode, 0, None, split, K.ptr(ws), None, K.stream_ptr(tensor.device)),
             'rua_segment_reduce')
     return out
 
