@@ -1,0 +1,90 @@
+"""Degenerate length distributions, on the GPU: one giant sequence among thousands of short ones (thousands of time
+chunks for the (rank x time) tile kernels, a PackedSequence whose tail is one row per step), every index of a scatter
+naming ONE bucket.  Values against plain torch restatements of the reference's maps (core/view.py:47-58 pack order,
+core/cast.py:8-38, select/roll.py:26-30, reduce.py:6-61)."""
+import time
+
+import pytest
+import torch
+
+import torchrua_amd as ta
+from gpu_util import DEV
+
+pytestmark = pytest.mark.gpu
+
+
+def _giant(H, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(1, 17, (3000,), generator=g)
+    lens[1234] = 200_000
+    lens[7] = 0
+    N = int(lens.sum())
+    data = torch.randn(N, H, generator=g).to(dtype)
+    return lens, data
+
+
+def _packed_rows(lens, p):
+    """Row of token (b, t) in the PackedSequence: boff[t] + rank[b] (core/view.py:47-58)."""
+    B = lens.numel()
+    off = torch.cumsum(lens, 0) - lens
+    bsz = p.batch_sizes.cpu()
+    boff = torch.cumsum(bsz, 0) - bsz
+    rank = p.unsorted_indices.cpu()
+    b = torch.repeat_interleave(torch.arange(B), lens)
+    t = torch.arange(int(lens.sum())) - off[b]
+    return boff[t] + rank[b], b, t
+
+
+@pytest.mark.parametrize('H,dtype', [(8, torch.bfloat16), (16, torch.bfloat16), (32, torch.float32), (512, torch.bfloat16)])
+def test_one_giant_sequence_among_short_ones(H, dtype):
+    lens, data = _giant(H, dtype, H)
+    c = ta.with_host_sizes(data.to(DEV), lens)
+    p = c.pack()
+    si = p.sorted_indices.cpu()
+    assert torch.equal(si, torch.sort(lens, descending=True)[1])
+    assert torch.equal(p.unsorted_indices.cpu()[si], torch.arange(lens.numel()))
+    rows, b, t = _packed_rows(lens, p)
+    want = torch.empty_like(data)
+    want[rows] = data
+    assert torch.equal(p.data.cpu(), want), 'pack'
+    assert torch.equal(p.cat().data.cpu(), data), 'P.cat'
+    # roll by one inside the PackedSequence (select/roll.py:26-30): token t takes the value of token (t - 1) mod len
+    rolled = p.roll(1)
+    src_t = (t - 1) % lens[b]
+    off = torch.cumsum(lens, 0) - lens
+    want_roll = torch.empty_like(data)
+    want_roll[rows] = data[off[b] + src_t]
+    assert torch.equal(rolled.data.cpu(), want_roll), 'P.roll'
+    # the reductions: the giant sequence through the split (the host knows the lengths) and without it (device lengths)
+    ref = torch.zeros(lens.numel(), H, dtype=torch.float64).index_add_(0, b, data.double())
+    mag = torch.zeros(lens.numel(), H, dtype=torch.float64).index_add_(0, b, data.double().abs())
+    tol = (1e-5 if dtype == torch.float32 else 1e-2) * mag + 1e-6
+    for name, got in (('reduce_sum(p)', ta.reduce_sum(p)), ('reduce_sum(c)', ta.reduce_sum(c)),
+                      ('segment_sum, device lengths', ta.segment_sum(data.to(DEV), lens.to(DEV)))):
+        assert bool(((got.double().cpu() - ref).abs() <= tol).all()), name
+    mx = ta.reduce_max(p).cpu()
+    assert torch.equal(mx[1234], data[off[1234]:off[1234] + 200_000].max(0)[0]), 'max of the giant sequence'
+
+
+def test_every_index_names_one_bucket():
+    """index_buckets / scatter_* when the histogram is ONE spike among 65 536 destinations (the most-significant-digit
+    first bucket builder puts every entry in one bin, the reducers cut the bucket by position / into parts)."""
+    Mn, S, H = 1 << 22, 65536, 16
+    g = torch.Generator().manual_seed(2)
+    idx = torch.full((Mn,), 4242, device=DEV)
+    src = torch.randn(Mn, H, generator=g).to(DEV)
+    ones = torch.ones(Mn, dtype=torch.int32, device=DEV)
+    ta.scatter_sum(torch.zeros(S, H, device=DEV), idx, src)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = ta.scatter_sum(torch.zeros(S, H, device=DEV), idx, src)
+    cnt = ta.scatter_sum(torch.zeros(S, dtype=torch.int32, device=DEV), idx, ones)
+    hi = ta.scatter_max(torch.zeros(S, H, device=DEV), idx, src)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert int(cnt[4242]) == Mn and int(cnt.sum()) == Mn
+    want = src.double().sum(0)
+    assert bool(((got[4242].double() - want).abs() <= 1e-5 * src.double().abs().sum(0)).all())
+    assert int((got != 0).any(1).sum()) == 1
+    assert torch.equal(hi[4242], src.max(0)[0])
+    assert dt < 0.05, f'{dt * 1e3:.1f} ms for three scatters of 4 M entries into one bucket'
