@@ -13,11 +13,13 @@ from gpu_util import DEV
 pytestmark = pytest.mark.gpu
 
 
-def _giant(H, dtype, seed):
+def _giant(H, dtype, seed, few_long=False):
     g = torch.Generator().manual_seed(seed)
     lens = torch.randint(1, 17, (3000,), generator=g)
     lens[1234] = 200_000
     lens[7] = 0
+    if few_long:        # twenty sequences of ~9 000 steps: more than 64 time chunks of FULL tiles (the tile kernels' own
+        lens = torch.cat([torch.randint(1, 17, (2000,), generator=g), torch.randint(8000, 10000, (20,), generator=g)])   # search)
     N = int(lens.sum())
     data = torch.randn(N, H, generator=g).to(dtype)
     return lens, data
@@ -35,9 +37,13 @@ def _packed_rows(lens, p):
     return boff[t] + rank[b], b, t
 
 
+@pytest.mark.parametrize('few_long', [False, True])
 @pytest.mark.parametrize('H,dtype', [(8, torch.bfloat16), (16, torch.bfloat16), (32, torch.float32), (512, torch.bfloat16)])
-def test_one_giant_sequence_among_short_ones(H, dtype):
-    lens, data = _giant(H, dtype, H)
+def test_one_giant_sequence_among_short_ones(H, dtype, few_long):
+    """few_long=False: the tiles would be mostly dead cells, the generic mover takes the narrow rows too
+    (_meta.TILE_MIN_LIVE_INV); few_long=True: thousands of live tiles over more than 64 time chunks."""
+    lens, data = _giant(H, dtype, H, few_long)
+    big = int(lens.argmax())
     c = ta.with_host_sizes(data.to(DEV), lens)
     p = c.pack()
     si = p.sorted_indices.cpu()
@@ -63,7 +69,7 @@ def test_one_giant_sequence_among_short_ones(H, dtype):
                       ('segment_sum, device lengths', ta.segment_sum(data.to(DEV), lens.to(DEV)))):
         assert bool(((got.double().cpu() - ref).abs() <= tol).all()), name
     mx = ta.reduce_max(p).cpu()
-    assert torch.equal(mx[1234], data[off[1234]:off[1234] + 200_000].max(0)[0]), 'max of the giant sequence'
+    assert torch.equal(mx[big], data[off[big]:off[big] + lens[big]].max(0)[0]), 'max of the longest sequence'
 
 
 def test_every_index_names_one_bucket():

@@ -432,6 +432,7 @@ def lay_padded(kind: int, lens: Optional[Tensor], B: int, T_phys: int, T_log: in
 
 
 NARROW_ROW_BYTES = 64      # rows up to this get the tile table (rua_move.hip: TILE_MAX_ROW_BYTES)
+TILE_MIN_LIVE_INV = 4       # ... when at least one cell in this many is a live token
 
 
 def tile_shape_log2(row_bytes: int) -> Tuple[int, int]:
@@ -480,10 +481,15 @@ def lay_pack(p, lens: Optional[Tensor] = None, len_add: int = 0, boff: Optional[
         keep.append(bsz)
         extra['bsz'] = L.ptr(bsz)
     if row_bytes is not None and 0 < row_bytes <= NARROW_ROW_BYTES and T == p.batch_sizes.numel() and len_add == 0:
-        t = pack_tiling(p, *tile_shape_log2(row_bytes))       # narrow rows: hand the (rank x time) tile table to the mover
-        keep += [t.bsz, t.tile_start]
-        extra.update(bsz=L.ptr(t.bsz), tile_start=L.ptr(t.tile_start), n_tchunks=t.n_tchunks, n_tiles=t.n_tiles,
-                     tile_t_log2=t.code)
+        ttl, trl = tile_shape_log2(row_bytes)
+        t = pack_tiling(p, ttl, trl)       # narrow rows: hand the (rank x time) tile table to the mover ...
+        # ... unless the tiles would be mostly dead cells: one giant sequence among short ones (its tail is one live rank
+        # in sixteen), or a batch of singletons (one live step in 16..64).  Below a quarter of live cells the generic
+        # mover — a row per lane, nothing dead — is 2-7 x faster (profiles/r04_shape_cliffs.txt)
+        if n_rows * TILE_MIN_LIVE_INV >= (t.n_tiles << (ttl + trl)):
+            keep += [t.bsz, t.tile_start]
+            extra.update(bsz=L.ptr(t.bsz), tile_start=L.ptr(t.tile_start), n_tchunks=t.n_tchunks, n_tiles=t.n_tiles,
+                         tile_t_log2=t.code)
     lay = Lay(keep, max_len=T, kind=L.PACK, n_rows=n_rows, B=pack_nseq(p),
               lens=L.ptr(lens), len_add=len_add, boff=L.ptr(boff), T=T, sorted=L.ptr(p.sorted_indices),
               unsorted=L.ptr(p.unsorted_indices), **extra)

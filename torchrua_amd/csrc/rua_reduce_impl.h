@@ -1228,16 +1228,36 @@ __device__ __forceinline__ void fill_empty_body(const rua_layout& L, T* __restri
   // only empty sequences (or everything, when a NaN poisoned `initial`) are written.  A lane inspects one sequence,
   // then the wave writes the marked rows together, lanes side by side along H (coalesced stores; the poisoned case
   // rewrites the whole [B, H] output).  Workgroups stride over the batch (the merged kernel's grid is capped).
+  // rows of whole 16-byte pieces at 16-byte addresses are written as such: when the LAST workgroup patches a batch
+  // that is mostly empty by itself (extreme_fill_kernel), element-wide stores made it 14 GB/s — 138 MB of empty rows
+  // took 10 ms where the reduce takes 0.7 (profiles/r04_shape_cliffs.txt)
+  constexpr int VE = 16 / (int)sizeof(T);
+  const bool wide = (H % VE) == 0 && ((uintptr_t)out & 15) == 0;
+  struct alignas(16) Piece { T v[VE]; } piece;
+#pragma unroll
+  for (int e = 0; e < VE; ++e) piece.v[e] = tv;
   for (int64_t base = first_block * RUA_BLOCK; base < L.B; base += n_blocks * RUA_BLOCK) {
     const int64_t b0 = base + (int64_t)(threadIdx.x >> 6) * RUA_WAVE;
     const int64_t b = b0 + lane;
     const bool mine = b < L.B && (poison || seq_len(L, b) <= 0);
+    if (wide && H / VE <= 8) {           // narrow rows: every lane writes its own sequence's row
+      if (mine) {
+        Piece* o16 = reinterpret_cast<Piece*>(out + b * H);
+        for (int64_t h = 0; h < H / VE; ++h) o16[h] = piece;
+      }
+      continue;
+    }
     unsigned long long todo = __ballot(mine);
     while (todo) {
       const int k = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
       T* o = out + (b0 + k) * H;
-      for (int64_t h = lane; h < H; h += RUA_WAVE) o[h] = tv;
+      if (wide) {
+        Piece* o16 = reinterpret_cast<Piece*>(o);
+        for (int64_t h = lane; h < H / VE; h += RUA_WAVE) o16[h] = piece;
+      } else {
+        for (int64_t h = lane; h < H; h += RUA_WAVE) o[h] = tv;
+      }
     }
   }
 }
