@@ -204,6 +204,11 @@ enum rua_op {
  * With both, max / min / logsumexp cost the reduce plus ONE trailing launch instead of three. */
 #define RUA_OP_SCRATCH_CLEAN 0x100
 #define RUA_OP_NO_EMPTY      0x200
+/* rua_segment_reduce over a CattedSequence with rows narrower than 1 KiB: the caller KNOWS the lengths and vouches
+ * that the sequences are short and none is far above the average (torchrua_amd: at most 8 x the average, 16..64 rows
+ * on average by row width).  Adjacent sequences then share a wave, side by side, instead of one wave (= one
+ * workgroup) per sequence, which is bound by the workgroup dispatch rate there.  A hint: results do not depend on it. */
+#define RUA_OP_SHORT_SEQS    0x400
 int64_t rua_reduce_ws_bytes(int64_t n_rows, int64_t H, int32_t dtype, int64_t split_rows);
 /* Waves (1, 2 or 4) that share one sequence in rua_segment_reduce for an aligned payload of `row_bytes`-wide
  * rows (multiples of 16 bytes, or of 8 bytes beyond one vector), B sequences, n_rows rows in all — the launcher's own rule, exported so that a host planner pricing

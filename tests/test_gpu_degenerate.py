@@ -94,3 +94,36 @@ def test_every_index_names_one_bucket():
     assert int((got != 0).any(1).sum()) == 1
     assert torch.equal(hi[4242], src.max(0)[0])
     assert dt < 0.05, f'{dt * 1e3:.1f} ms for three scatters of 4 M entries into one bucket'
+
+
+@pytest.mark.parametrize('H,dtype', [(4, torch.float32), (8, torch.float32), (16, torch.bfloat16), (32, torch.float32),
+                                     (50, torch.float32), (100, torch.bfloat16), (128, torch.float32)])
+def test_short_sequences_side_by_side(H, dtype):
+    """Hundreds of thousands of short sequences whose lengths the host knows: adjacent sequences share a wave
+    (RUA_OP_SHORT_SEQS).  Same values as the one-wave-per-sequence walk (device-only lengths): max / min bit for bit,
+    empty sequences and the reference's `initial` included; the sums to rounding."""
+    from torchrua_amd import _ops as O
+    from torchrua_amd.layout import describe
+    g = torch.Generator().manual_seed(H)
+    B = 300_000
+    lens = torch.randint(0, 9, (B,), generator=g)
+    lens[::5003] = 40
+    N = int(lens.sum())
+    data = (torch.randn(N, H, generator=g) * 0.5).to(dtype).to(DEV)
+    host = ta.with_host_sizes(data, lens)
+    dev = ta.C(data, lens.to(DEV))
+    assert O.short_seqs_hint(describe(host), H * data.element_size()) == ta._lib.OP_SHORT_SEQS
+    assert O.short_seqs_hint(describe(dev), H * data.element_size()) == 0                  # lengths on the device only
+    for name in ('sum', 'mean', 'max', 'min', 'prod', 'logsumexp'):
+        fn = getattr(ta, f'reduce_{name}')
+        a, b = fn(host), fn(dev)
+        if name in ('max', 'min'):
+            assert torch.equal(a, b), name
+        else:
+            tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
+            assert torch.allclose(a.float(), b.float(), rtol=tol, atol=tol, equal_nan=True), name
+    # one long sequence among them: the hint is withdrawn (the wave would walk it with one lane group)
+    lens2 = lens.clone()
+    lens2[77] = 10_000
+    data2 = torch.zeros(int(lens2.sum()), H, dtype=dtype, device=DEV)
+    assert O.short_seqs_hint(describe(ta.with_host_sizes(data2, lens2)), H * data.element_size()) == 0

@@ -24,6 +24,7 @@ BWD_TIES_POSITIVE = 0x200  # ... OR-ed in (max/min): torch.segment_reduce's tie 
 MOVE_SCATTER = 1
 MOVE_NT_ON, MOVE_NT_OFF = 2, 4       # rua.h: force / forbid non-temporal payload accesses
 OP_SCRATCH_CLEAN, OP_NO_EMPTY = 0x100, 0x200     # rua.h: bits OR-ed into `op` (persistent zeroed extreme scratch)
+OP_SHORT_SEQS = 0x400      # rua.h: a CattedSequence of short sequences, none far above the average (a hint)
 # enum rua_dtype / rua_op
 F32, BF16, F16, F64 = 0, 1, 2, 3
 SUM, MEAN, MAX, MIN, PROD, LOGSUMEXP = 0, 1, 2, 3, 4, 5

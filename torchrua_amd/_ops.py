@@ -183,6 +183,22 @@ def int_split_workspace(n_rows: int, H: int, dtype: torch.dtype, dev) -> Tuple[i
     return split, torch.empty(nbytes, dtype=torch.uint8, device=dev)
 
 
+def short_seqs_hint(lay: M.Lay, row_bytes: int) -> int:
+    """RUA_OP_SHORT_SEQS for a reduce over a CattedSequence whose lengths the host knows: many short sequences, none far
+    above the average.  One wave (= one workgroup) per sequence is bound by the workgroup dispatch rate there (4 M
+    singletons: 3 ms at any row width; 500 000 sequences of 16 rows: 0.4 ms where the payload takes 0.06); adjacent
+    sequences side by side in a wave win up to 16 .. 64 rows on average by row width (profiles/r04_cat_ranks_ab.txt).
+    The wave walks to the longest of its sequences, hence the bound on the longest one — and no hint at all when the
+    lengths live on the device only."""
+    if lay.kind != L.CAT or lay.max_len is None or lay.B <= 0 or not 0 < row_bytes <= 512:
+        return 0
+    groups = 64 >> max(0, (-(-row_bytes // 16) - 1).bit_length())      # sequences side by side in a wave
+    avg = lay.n_rows / lay.B
+    if avg <= min(64, max(16, 4 * groups)) and lay.max_len <= max(64, 8 * avg):
+        return L.OP_SHORT_SEQS
+    return 0
+
+
 def launch_reduce(lay: M.Lay, data: Tensor, op: int, out: Optional[Tensor] = None, include_self: int = 0,
                   perm: Optional[Tensor] = None, hidden: Tuple[int, ...] = (), reference_initial: bool = True,
                   name: str = 'reduce', ties_out: Optional[Tensor] = None) -> Tensor:
@@ -204,6 +220,7 @@ def launch_reduce(lay: M.Lay, data: Tensor, op: int, out: Optional[Tensor] = Non
         extreme, op_bits = extreme_scratch(dev, lay)
     tail_ok = include_self != 1 and (data.data_ptr() | out.data_ptr()) % 8 == 0      # the launcher's own condition
     split, ws = split_workspace(lay, H, data.dtype, dev, tail_ok=tail_ok)
+    short = short_seqs_hint(lay, H * data.dtype.itemsize) if perm is None and not split else 0
     if _kernel_hook:
         _kernel_hook(name, True)
     paired = extreme is not None
@@ -213,7 +230,7 @@ def launch_reduce(lay: M.Lay, data: Tensor, op: int, out: Optional[Tensor] = Non
         # (the second walk for the global extreme, should a segment be empty, rides in rua_fill_empty's launch: the
         # reduce is told not to arm it, and fill_empty gets the payload unless the host knows nothing is empty)
         L.check(lib.rua_segment_reduce(lay.ref(), L.ptr(perm), L.ptr(data), L.ptr(out), H, L.DTYPES[data.dtype],
-                                       op | op_bits | (L.OP_NO_EMPTY if extreme is not None else 0), include_self,
+                                       op | op_bits | (L.OP_NO_EMPTY if extreme is not None else 0) | short, include_self,
                                        _bits(_EMPTY[op], data.dtype), L.ptr(extreme), split, L.ptr(ws), L.ptr(ties_out),
                                        L.stream_ptr(dev)), 'rua_segment_reduce')
         if _kernel_hook:

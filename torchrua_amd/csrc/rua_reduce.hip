@@ -15,7 +15,7 @@ __global__ void extreme_init_entry_kernel(unsigned long long* ext, int want_max_
 #define RUA_DECL(NAME)                                                                                              \
   int reduce_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data, void* out,  \
                     int64_t H, int include_self, uint64_t empty_bits, void* extreme, int64_t split, void* ws,     \
-                    const rua_layout* CD, void* copy, void* ties, bool no_empty);                                  \
+                    const rua_layout* CD, void* copy, void* ties, int hints);                                      \
   int backward_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,           \
                       const void* out, const void* gout, void* gin, int64_t H, int extra_count, int64_t split,    \
                       void* ws, void* ties, bool ties_final, const void* self_in, bool fill_padding);              \
@@ -114,7 +114,8 @@ int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* d
   if (perm && lay->kind != RUA_CAT) return RUA_EINVAL;
   if (lay->B == 0 || H == 0) return 0;
   if (!out || (lay->n_rows > 0 && !data)) return RUA_EINVAL;
-  const bool clean = (op & RUA_OP_SCRATCH_CLEAN) != 0, no_empty = (op & RUA_OP_NO_EMPTY) != 0;
+  const bool clean = (op & RUA_OP_SCRATCH_CLEAN) != 0;
+  const int hints = ((op & RUA_OP_NO_EMPTY) ? 1 : 0) | ((op & RUA_OP_SHORT_SEQS) ? 2 : 0);     // dispatch_reduce's hints
   op &= 0xff;
   if (ties && op != RUA_MAX && op != RUA_MIN) return RUA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
@@ -127,10 +128,10 @@ int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* d
                        op == RUA_MIN ? 1 : 0);
   }
   switch (dtype) {
-    case RUA_F32: return reduce_f32(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr, ties, no_empty);
-    case RUA_BF16: return reduce_bf16(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr, ties, no_empty);
-    case RUA_F16: return reduce_f16(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr, ties, no_empty);
-    case RUA_F64: return reduce_f64(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr, ties, no_empty);
+    case RUA_F32: return reduce_f32(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr, ties, hints);
+    case RUA_BF16: return reduce_bf16(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr, ties, hints);
+    case RUA_F16: return reduce_f16(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr, ties, hints);
+    case RUA_F64: return reduce_f64(op, s, *lay, perm, data, out, H, include_self, empty_bits, extreme, split_rows, ws, nullptr, nullptr, ties, hints);
   }
   return RUA_EINVAL;
 }
@@ -145,16 +146,17 @@ int rua_pack_reduce(const rua_layout* src, const rua_layout* pack, const void* d
   if (src->B == 0 || H == 0) return 0;
   if (!out || !pack_data || !data) return RUA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const bool clean = (op & RUA_OP_SCRATCH_CLEAN) != 0, no_empty = (op & RUA_OP_NO_EMPTY) != 0;
+  const bool clean = (op & RUA_OP_SCRATCH_CLEAN) != 0;
+  const int hints = (op & RUA_OP_NO_EMPTY) ? 1 : 0;
   op &= 0xff;
   if (extreme && !clean && (op == RUA_MAX || op == RUA_MIN || op == RUA_LOGSUMEXP))
     hipLaunchKernelGGL(extreme_init_entry_kernel, dim3(1), dim3(128), 0, s, (unsigned long long*)extreme,
                        op == RUA_MIN ? 1 : 0);
   switch (dtype) {
-    case RUA_F32: return reduce_f32(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data, nullptr, no_empty);
-    case RUA_BF16: return reduce_bf16(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data, nullptr, no_empty);
-    case RUA_F16: return reduce_f16(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data, nullptr, no_empty);
-    case RUA_F64: return reduce_f64(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data, nullptr, no_empty);
+    case RUA_F32: return reduce_f32(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data, nullptr, hints);
+    case RUA_BF16: return reduce_bf16(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data, nullptr, hints);
+    case RUA_F16: return reduce_f16(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data, nullptr, hints);
+    case RUA_F64: return reduce_f64(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data, nullptr, hints);
   }
   return RUA_EINVAL;
 }

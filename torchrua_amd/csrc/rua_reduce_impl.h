@@ -664,6 +664,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_tail_kernel(rua_layout L,
 //           [w*per, (w+1)*per) in order, then wave 0 folds the 16 range results in wave order.
 // Either association depends only on the part count, so the result is bitwise reproducible.
 constexpr int COMBINE_WAVES_MAX = 16;
+constexpr int REDUCE_HINT_NO_EMPTY = 1, REDUCE_HINT_SHORT_SEQS = 2;    // dispatch_reduce's `hints`
 constexpr int64_t RANKS_MIN_WAVES = 4096;   // adjacent-rank waves (RANKS) only when B / ranks-per-wave still fills the chip
 constexpr int COMBINE_SOLO = 32;
 constexpr int64_t COMBINE_GRID = 512;   // 2 workgroups per CU
@@ -1192,7 +1193,11 @@ __global__ __launch_bounds__(RUA_BLOCK) void fill_empty_kernel(rua_layout L, T* 
                                                                int want_max_of_data,
                                                                unsigned long long* __restrict__ ext, int reset) {
   const unsigned long long flags = ext[EXTREME_SLOTS];
-  if (flags != 0ull) fill_empty_body<T>(L, out, H, want_max_of_data, ext, flags, blockIdx.x, gridDim.x);   // rare: a NaN or an empty segment
+  // the common case: nothing was raised, so nothing needs patching AND nothing needs resetting — the scratch is still
+  // all zero.  (Every workgroup used to take the reset ticket regardless: B / 256 atomics on ONE address, 0.6 ms after
+  // a reduce over 8 M short sequences, ~1-5 us at the BASELINE shapes: profiles/r04_cat_ranks_ab.txt)
+  if (flags == 0ull) return;
+  fill_empty_body<T>(L, out, H, want_max_of_data, ext, flags, blockIdx.x, gridDim.x);   // rare: a NaN or an empty segment
   if (!reset) return;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1277,7 +1282,8 @@ __global__ __launch_bounds__(RUA_BLOCK) void extreme_fill_kernel(rua_layout L, c
   using A = typename elem<T>::acc;
   constexpr int OP2 = WANT_MAX ? RUA_MAX : RUA_MIN;
   const unsigned long long flags = ext[EXTREME_SLOTS];
-  if (flags != 0ull) {
+  if (flags == 0ull) return;      // nothing raised: nothing to patch, nothing to reset (see fill_empty_kernel)
+  {
     if ((flags & 2ull) != 0ull && (flags & 1ull) == 0ull) {   // grid-uniform: the flags are final
       const int lane = threadIdx.x & (RUA_WAVE - 1);
       const int64_t gw = (int64_t)blockIdx.x * RUA_WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -1459,7 +1465,7 @@ template <typename T>
 static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,
                                 void* out, int64_t H, int include_self, uint64_t empty_bits, void* extreme,
                                 int64_t split, void* ws, const rua_layout* CD = nullptr, void* copy = nullptr,
-                                void* ties = nullptr) {
+                                void* ties = nullptr, bool short_seqs = false) {
   constexpr int FULL = 16 / sizeof(T);
   constexpr int HALF = FULL >= 4 ? FULL / 2 : 1;      // 8-byte loads: hidden sizes that are a multiple of 8 bytes only
   const uintptr_t fptrs = (uintptr_t)data | (uintptr_t)out | (uintptr_t)copy | (uintptr_t)ties;
@@ -1496,11 +1502,17 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
   const rua_layout& cd = copy ? *CD : none;
   if (copy && !aligned_ok) return RUA_EALIGN;   // fused pack + reduce: vector path only (caller falls back to two launches)
   // (only when that still leaves >= 4 waves per SIMD: with fewer sequences one wave per sequence fills the chip better)
-  if (L.kind == RUA_PACK && L.sorted && !copy && !perm && lp_log2 < 6 && !(split > 0 && ws) &&
+  // (RUA_OP_SHORT_SEQS: the caller knows the longest sequence and vouches that none is far above the average — the
+  // wave walks to the longest of its sequences, so ONE long sequence among short ones would be walked by one lane group)
+  const bool cat_ranks = short_seqs && L.kind == RUA_CAT && L.lens && L.len_add == 0;
+  if (((L.kind == RUA_PACK && L.sorted) || cat_ranks) && !copy && !perm && lp_log2 < 6 && !(split > 0 && ws) &&
       (L.B >> (6 - lp_log2)) >= RANKS_MIN_WAVES) {
     // narrow rows of a PackedSequence: adjacent ranks share a wave instruction
-    // (tried for a CattedSequence with 32-byte rows too — groups = adjacent sequences: 4.0 -> 2.8 TB/s, unsorted
-    // neighbours differ too much in length — so C keeps one wave per sequence)
+    // (tried for a CattedSequence with 32-byte rows too — groups = adjacent sequences: 4.0 -> 2.8 TB/s at U(8,512),
+    // unsorted neighbours differ too much in length — so C keeps one wave per sequence, EXCEPT for batches of short
+    // sequences, when the caller says so: there a wave per sequence is bound by the rate at which workgroups can be
+    // dispatched at all — 4 M singletons: 2.98 ms, 1.3 workgroups per ns; 500 000 sequences of 16 rows on average:
+    // 0.40 -> 0.06-0.07 ms at 16 / 32-byte rows, 0.43 -> 0.21 at 128: profiles/r04_cat_ranks_ab.txt)
     const int64_t rpw = RUA_WAVE >> lp_log2;
     const int64_t nblk = (L.B + rpw - 1) / rpw;
     if (nblk > 0x7fffffffLL) return RUA_ERANGE;
@@ -1580,9 +1592,10 @@ template <typename T>
 static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,
                            void* out, int64_t H, int include_self, uint64_t empty_bits, void* extreme,
                            int64_t split, void* ws, const rua_layout* CD = nullptr, void* copy = nullptr,
-                           void* ties = nullptr, bool no_empty = false) {
+                           void* ties = nullptr, int hints = 0) {
+  const bool no_empty = (hints & REDUCE_HINT_NO_EMPTY) != 0;
   const int r = dispatch_reduce_main<T>(op, s, L, perm, data, out, H, include_self, empty_bits, extreme, split, ws, CD,
-                                        copy, ties);
+                                        copy, ties, (hints & REDUCE_HINT_SHORT_SEQS) != 0);
   if (r != 0 || !extreme || !(op == RUA_MAX || op == RUA_MIN || op == RUA_LOGSUMEXP)) return r;
   if (no_empty) return r;     // the caller vouches that no sequence is empty (RUA_OP_NO_EMPTY): no second walk to arm
   // (a PackedSequence may carry zero-length sequences too — C.pack() of lens such as [0,3,0,2] — so PACK takes the
@@ -1783,7 +1796,7 @@ static int launch_extreme_fill(hipStream_t s, const rua_layout& L, const int64_t
 #define RUA_DECLARE_REDUCE_DTYPE(NAME)                                                                              \
   int reduce_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data, void* out,  \
                     int64_t H, int include_self, uint64_t empty_bits, void* extreme, int64_t split, void* ws,     \
-                    const rua_layout* CD, void* copy, void* ties, bool no_empty);                                  \
+                    const rua_layout* CD, void* copy, void* ties, int hints);                                  \
   int backward_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,           \
                       const void* out, const void* gout, void* gin, int64_t H, int extra_count, int64_t split,    \
                       void* ws, void* ties, bool ties_final, const void* self_in, bool fill_padding);              \
@@ -1800,9 +1813,9 @@ RUA_DECLARE_REDUCE_DTYPE(f64)
   namespace rua {                                                                                                   \
   int reduce_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data, void* out,  \
                     int64_t H, int include_self, uint64_t empty_bits, void* extreme, int64_t split, void* ws,     \
-                    const rua_layout* CD, void* copy, void* ties, bool no_empty) {                                 \
+                    const rua_layout* CD, void* copy, void* ties, int hints) {                                 \
     return dispatch_reduce<T>(op, s, L, perm, data, out, H, include_self, empty_bits, extreme, split, ws, CD,      \
-                              copy, ties, no_empty);                                                               \
+                              copy, ties, hints);                                                                  \
   }                                                                                                                 \
   int backward_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,           \
                       const void* out, const void* gout, void* gin, int64_t H, int extra_count, int64_t split,    \
