@@ -1826,7 +1826,8 @@ RUA_DECLARE_REDUCE_DTYPE(f64)
   int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, void* ext,        \
                         int reset, const void* data, const int64_t* perm) {                                      \
     if (data) return launch_extreme_fill<T>(s, L, perm, data, out, H, want_max, ext, reset);                        \
-    hipLaunchKernelGGL(fill_empty_kernel<T>, dim3(grid_for(L.B)), dim3(RUA_BLOCK), 0, s, L, (T*)out, H, want_max,  \
+    /* (the body strides over the batch: a capped grid; in the common case every workgroup reads one flag word) */ \
+    hipLaunchKernelGGL(fill_empty_kernel<T>, dim3(grid_for(L.B) < 2048u ? (grid_for(L.B) ? grid_for(L.B) : 1u) : 2048u), dim3(RUA_BLOCK), 0, s, L, (T*)out, H, want_max,  \
                        (unsigned long long*)ext, reset);                                                           \
     return (int)hipGetLastError();                                                                                  \
   }                                                                                                                 \
