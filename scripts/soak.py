@@ -34,8 +34,8 @@ while time.time() < t_end:
         H = int(rng.choice([3, 8, 64, 130, 512]))
     else:                        # so many short sequences that narrow rows take the adjacent-rank kernels
         B = int(rng.choice([40000, 140000]))
-        hi = int(rng.choice([1, 2, 4]))
-        H = int(rng.choice([1, 2, 4, 8, 16, 24]))
+        hi = int(rng.choice([1, 2, 4, 9, 30]))
+        H = int(rng.choice([1, 2, 4, 8, 16, 24, 64, 128]))
     lo = int(rng.randint(1, hi + 1))
     dtype = [torch.float32, torch.bfloat16, torch.float16, torch.float64, torch.int64][int(rng.randint(0, 5))]
     if B * hi * H > 6e7:
@@ -77,6 +77,8 @@ while time.time() < t_end:
                 ref = getattr(orc, f'segment_{name}')(f, lens.numpy()).astype(np.float64)
                 scale = float(np.abs(f).max()) * (hi if name == 'sum' else 1)
                 outs = [getattr(ta, f'reduce_{name}')(dsq[k]) for k in 'CLPR']
+                # lengths the host knows: short sequences side by side in a wave (RUA_OP_SHORT_SEQS), exact split decisions
+                outs.append(getattr(ta, f'reduce_{name}')(ta.with_host_sizes(dsq['C'].data, lens)))
                 if H % (16 // data.element_size()) == 0:
                     outs.append(ta.pack_reduce(dsq['C'], name)[1])
                 for o in outs:
