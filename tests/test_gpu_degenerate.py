@@ -122,6 +122,18 @@ def test_short_sequences_side_by_side(H, dtype):
         else:
             tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
             assert torch.allclose(a.float(), b.float(), rtol=tol, atol=tol, equal_nan=True), name
+    # with gradients: the forward of max / min also counts the ties (side by side too); same gradients either way
+    if dtype == torch.float32:
+        tied = torch.randint(0, 3, (N, H), generator=g).float().to(DEV)
+        cot = torch.randn(B, H, generator=g).to(DEV)
+        for name in ('max', 'sum', 'logsumexp'):
+            grads = []
+            for lens_arg in (lens, lens.to(DEV)):
+                x = tied.clone().requires_grad_(True)
+                z = ta.with_host_sizes(x, lens_arg) if not lens_arg.is_cuda else ta.C(x, lens_arg)
+                getattr(ta, f'reduce_{name}')(z).backward(cot)
+                grads.append(x.grad)
+            assert torch.allclose(grads[0], grads[1], rtol=1e-5, atol=1e-6), f'grad {name}'
     # one long sequence among them: the hint is withdrawn (the wave would walk it with one lane group)
     lens2 = lens.clone()
     lens2[77] = 10_000
