@@ -125,6 +125,22 @@ def test_reducer_split_policy():
     small = FakeLay(20_000, 5_000, None)
     small.heavy_tail = True
     assert M.reduce_split_rows(small, 128) == 0
+    # RUA_OP_SHORT_SEQS (adjacent sequences of a CattedSequence side by side in a wave): host-known lengths only, short
+    # on average by row width, nothing far above the average
+    from torchrua_amd import _ops as O
+
+    class CatLay(FakeLay):
+        kind = _lib.CAT
+    assert O.short_seqs_hint(CatLay(8_000_000, 500_000, 31), 32) == _lib.OP_SHORT_SEQS      # 16 rows on average, 32-byte rows
+    assert O.short_seqs_hint(CatLay(8_000_000, 500_000, None), 32) == 0                     # lengths on the device only
+    assert O.short_seqs_hint(CatLay(8_000_000, 500_000, 10_000), 32) == 0                   # one long sequence among them
+    assert O.short_seqs_hint(CatLay(8_000_000, 500_000, 31), 1024) == 0                     # rows of a whole wave instruction
+    assert O.short_seqs_hint(CatLay(17_046_960, 65536, 512), 32) == 0                       # 260 rows on average
+    assert O.short_seqs_hint(CatLay(8_000_000, 250_000, 63), 512) == 0                      # 32 on average at 512-byte rows: no
+    assert O.short_seqs_hint(CatLay(8_000_000, 250_000, 63), 64) == _lib.OP_SHORT_SEQS      # ... at 64-byte rows: yes
+    pk = CatLay(8_000_000, 500_000, 31)
+    pk.kind = _lib.PACK
+    assert O.short_seqs_hint(pk, 32) == 0
     # the wave-team rule the planner prices with IS the launcher's (rua_reduce_team_waves): a few fixed points
     lib = _lib.load()
     assert lib.rua_reduce_team_waves(133_000, 512, 1024) == 4 and lib.rua_reduce_team_waves(133_000, 512, 1000) == 4
