@@ -10,7 +10,7 @@
 //            writes is no longer the whole word: the high digit is the bin, so a word is (low digit << row_bits | row)
 //            — 32 bits for up to 2^24..2^25 rows with 65 536 destinations — HALF the bytes written, and read twice by
 //            level 2.  Entries whose destination is out of range are dropped here.
-//   level 2  works bin by bin: a bin is cut into segments of 8 192 words, a workgroup counts its segment's low digits,
+//   level 2  works bin by bin: a bin is cut into segments of 4 096 words, a workgroup counts its segment's low digits,
 //            ONE workgroup per bin scans the bin's (digit, segment) table — which yields, on the side, counts[] and
 //            off[] of the bin's destinations: no bounds kernel — and the segments scatter the rows to their final
 //            places.  All traffic of a bin stays inside the bin's own range (266 KiB on average): stores that the L2
@@ -19,7 +19,7 @@
 // 4 + 4 read + 8 written (perm) = 36 instead of 56.  Stable at both levels, so every destination's rows come out in
 // ascending order: the summation order of scatter_* stays a fixed function of the inputs (bitwise reproducible).
 //
-// gfx950, wave64.  A workgroup of 8 waves owns 8 192 consecutive entries; ranking inside the block is the scheme of
+// gfx950, wave64.  A workgroup of 8 waves owns 4 096 consecutive entries (8 per thread; 16 measured slower); ranking inside the block is the scheme of
 // rua_scatter.hip (ballots find the lanes of a chunk that share a digit, (wave, digit) counters in LDS carry the count
 // across the wave's chunks, the block's words are put in sorted order in LDS and leave as runs).
 #include "rua_dev.h"
@@ -34,7 +34,7 @@ constexpr int MSD_THREADS = MSD_WAVES * RUA_WAVE;        // 512 >= MSD_RADIX: on
 #define RUA_MSD_ITEMS 8
 #endif
 constexpr int MSD_ITEMS = RUA_MSD_ITEMS;
-constexpr int MSD_BLOCK = MSD_THREADS * MSD_ITEMS;       // 8 192 entries per workgroup / per segment
+constexpr int MSD_BLOCK = MSD_THREADS * MSD_ITEMS;       // 4 096 entries per workgroup / per segment
 static_assert(MSD_THREADS >= MSD_RADIX, "one thread per digit");
 
 struct MsdGeom {
