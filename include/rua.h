@@ -49,7 +49,11 @@ enum rua_kind { RUA_CAT = 0, RUA_LEFT = 1, RUA_PACK = 2, RUA_RIGHT = 3, RUA_LIST
 typedef struct rua_layout {
   int32_t kind;            /* enum rua_kind */
   int32_t tile_t_log2;     /* PACK with a tile table (below): bits 0-7 log2 of the time steps per tile (4 .. 6),
-                              bits 8-15 log2 of the ranks per tile (4); a zero field = 4 (ABI <= 3: 16 x 16) */
+                              bits 8-15 log2 of the ranks per tile (4); a zero field = 4 (ABI <= 3: 16 x 16);
+                              bits 16-23: R = 128 / row bytes (2, 4 or 8) when the table was built for windows that
+                              begin up to R - 1 steps early — tile_start[c] counts the ranks alive at step
+                              c * TT - (R - 1), and there are ceil((T + R - 1) / TT) chunks — so that the kernel may
+                              align every rank's batch-major runs to 128-byte lines; 0 = plain windows */
   int64_t n_rows;          /* storage rows: CAT/PACK: sum(len); LEFT/RIGHT: B*T_phys; LIST: M */
   int64_t B;               /* number of sequences */
   int64_t T_phys;          /* LEFT/RIGHT: rows per sequence in storage (data.size(1)) */

@@ -440,32 +440,44 @@ def tile_shape_log2(row_bytes: int) -> Tuple[int, int]:
     return (6 if row_bytes <= 16 else 5 if row_bytes <= 32 else 4), 4
 
 
+def tile_line_rows(row_bytes: int) -> int:
+    """R = rows per 128-byte line when the rows divide one (16 / 32 / 64-byte rows: 8 / 4 / 2), else 1.  With R > 1 the
+    narrow-row tile kernel gives every rank its own time origin so that its runs on the batch-major side are whole
+    lines (rua_move.hip: TileTables); the tile table below is then built for windows shifted by up to R - 1 steps."""
+    return 128 // row_bytes if row_bytes in (16, 32, 64) else 1
+
+
 class PackTiling:
     """Tile table for the narrow-row C/L/R <-> P kernel, derived on the host from batch_sizes (a CPU tensor by
     PackedSequence's contract): tile_start[c] = number of rank tiles before time chunk c (chunks of 1 << ttl steps,
-    tiles of 1 << trl ranks)."""
+    tiles of 1 << trl ranks).  line_rows = R > 1: a rank's window may begin up to R - 1 steps before the chunk, so
+    chunk c takes the ranks alive at step c * TT - (R - 1), and there are ceil((T + R - 1) / TT) chunks."""
     __slots__ = ('bsz', 'tile_start', 'n_tchunks', 'n_tiles', 'code')
 
-    def __init__(self, batch_sizes: Tensor, bsz_dev: Tensor, dev: torch.device, ttl: int, trl: int):
+    def __init__(self, batch_sizes: Tensor, bsz_dev: Tensor, dev: torch.device, ttl: int, trl: int, line_rows: int = 1):
         # numpy on the (CPU, by PackedSequence's contract) batch_sizes: a handful of torch CPU ops on a few dozen
         # elements cost ~30 us EACH on the GPU box's 128-thread host build
-        counts = (batch_sizes.numpy()[::1 << ttl] + ((1 << trl) - 1)) >> trl
+        bs = batch_sizes.numpy()
+        tt, extra = 1 << ttl, max(line_rows, 1) - 1
+        n_chunks = (bs.size + extra + tt - 1) // tt if bs.size else 0
+        first = np.maximum(np.arange(n_chunks, dtype=np.int64) * tt - extra, 0)
+        counts = (bs[first] + ((1 << trl) - 1)) >> trl
         start = np.zeros(counts.size + 1, dtype=np.int64)
         np.cumsum(counts, out=start[1:])
         self.n_tchunks = int(counts.size)
         self.n_tiles = int(start[-1])
         self.tile_start = to_device_async(torch.from_numpy(start), dev)
         self.bsz = bsz_dev
-        self.code = ttl | (trl << 8)
+        self.code = ttl | (trl << 8) | ((line_rows if line_rows > 1 else 0) << 16)
 
 
-def pack_tiling(p, ttl: int, trl: int) -> 'PackTiling':
+def pack_tiling(p, ttl: int, trl: int, line_rows: int = 1) -> 'PackTiling':
     dev = p.data.device
-    key = f'tiling:{dev}:{ttl}:{trl}'
+    key = f'tiling:{dev}:{ttl}:{trl}:{line_rows}'
     hit = _memo_get(p.batch_sizes, key)
     if hit is not None:
         return hit
-    return _memo_put(p.batch_sizes, key, PackTiling(p.batch_sizes, pack_bsz_dev(p), dev, ttl, trl))
+    return _memo_put(p.batch_sizes, key, PackTiling(p.batch_sizes, pack_bsz_dev(p), dev, ttl, trl, line_rows))
 
 
 def lay_pack(p, lens: Optional[Tensor] = None, len_add: int = 0, boff: Optional[Tensor] = None,
@@ -482,7 +494,7 @@ def lay_pack(p, lens: Optional[Tensor] = None, len_add: int = 0, boff: Optional[
         extra['bsz'] = L.ptr(bsz)
     if row_bytes is not None and 0 < row_bytes <= NARROW_ROW_BYTES and T == p.batch_sizes.numel() and len_add == 0:
         ttl, trl = tile_shape_log2(row_bytes)
-        t = pack_tiling(p, ttl, trl)       # narrow rows: hand the (rank x time) tile table to the mover ...
+        t = pack_tiling(p, ttl, trl, tile_line_rows(row_bytes))       # narrow rows: hand the (rank x time) tile table to the mover ...
         # ... unless the tiles would be mostly dead cells: one giant sequence among short ones (its tail is one live rank
         # in sixteen), or a batch of singletons (one live step in 16..64).  Below a quarter of live cells the generic
         # mover — a row per lane, nothing dead — is 2-7 x faster (profiles/r04_shape_cliffs.txt)

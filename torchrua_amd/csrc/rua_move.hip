@@ -329,16 +329,29 @@ constexpr int64_t TILE_MAX_ROW_BYTES = 64;       // rows up to this take the til
 // Measured (8 GB payloads, profiles/r04_tile_ab.txt, r03_width_sweep.txt): pack 4.0-4.3 -> 4.9 TB/s at 32-byte rows,
 // 3.3 -> 4.9 at 16; P.cat 3.3-3.6 -> 3.9, 3.1 -> 4.2; 64-byte rows unchanged (5.2 / 4.4).  32 KiB tiles and 32 ranks
 // per tile: slower.
+// (3) [r4, late] LINE-ALIGNED RUNS ON THE BATCH-MAJOR SIDE (P.cat only: see launch_pack_tiles).  A rank's run in a tile
+// is TT rows = 1 KiB of one sequence, at whatever 32-byte offset the sequence happens to start: both ends of every run
+// were partial 128-byte lines, shared with the neighbouring time chunk's tile — which runs much later, on another CU —
+// i.e. over-fetched by the pack and written as partial lines by P.cat.  Measured with all-equal lengths (scripts/exp/aligned_pcat.py, 32-byte rows):
+// everything aligned 6.0 / 5.6 TB/s (pack / P.cat); only the PackedSequence's runs misaligned 5.6 / 5.35; only the
+// batch-major runs misaligned 5.1 / 4.35; ragged lengths 4.5 / 3.8.  So every rank gets its OWN time origin: with
+// R = 128 / row_bytes rows per line and s = (first row of the sequence) mod R, the rank's windows are
+// [c TT - s, (c + 1) TT - s) — whole lines on the batch-major side, except where a sequence begins and ends.  The
+// PackedSequence side pays: a tile touches TT + R - 1 time steps, and at the R - 1 steps on either edge only some of
+// the sixteen ranks (the cheap kind of misalignment, above).  The host builds the tile table for the shifted windows
+// (chunk c needs the ranks alive at step c TT - (R - 1)) and says so in rua_layout::tile_t_log2 bits 16..23.
+constexpr int TILE_SHIFT_MAX = 8;                // R <= 8: rows of 16 bytes
 struct TileTables {
-  int64_t obase[TR_MAX];  // batch-major storage row of the rank's sequence at the tile's first time step
-  int64_t olen[TR_MAX];   // its length (0: no such sequence)
-  int64_t pboff[64];      // first PackedSequence row of the time step
-  int64_t pbsz[64];       // sequences alive at the time step (0 past T)
+  int64_t obase[TR_MAX];  // batch-major storage row of the rank's window start: first row of the sequence - shift + t0
+  int64_t olen[TR_MAX];   // the sequence's length (0: no such sequence)
+  int shift[TR_MAX];      // the rank's time shift s in [0, R)
+  int64_t pboff[64 + TILE_SHIFT_MAX];      // first PackedSequence row of time step t0 - (R - 1) + k
+  int64_t pbsz[64 + TILE_SHIFT_MAX];       // sequences alive at that step (0 before 0 and past T)
 };
 
 template <int TTL, int TRL>
 __device__ __forceinline__ void tile_tables(const rua_layout& Pk, const rua_layout& Ot, int64_t tile, TileTables& tb,
-                                            int64_t& r0_out, int64_t& t0_out) {
+                                            int64_t& r0_out, int64_t& t0_out, int R = 1, int64_t phase = 0) {
   constexpr int TT = 1 << TTL, TR = 1 << TRL;
   // which time chunk does this tile belong to?  largest c with tile_start[c] <= tile.  Up to 64 chunks
   // every lane loads one entry and a ballot counts them: ONE load instead of a six-step chain of dependent ones
@@ -369,14 +382,16 @@ __device__ __forceinline__ void tile_tables(const rua_layout& Pk, const rua_layo
         base = token_to_row(Ot, b, 0, len);
       }
     }
-    tb.obase[i] = base + t0;                      // batch-major row of the sequence's token at the tile's first time step
-    tb.olen[i] = len - t0;                        // tokens of the sequence from that step on
-  } else if (i >= RUA_WAVE && i < RUA_WAVE + TT) {   // wave 1 (and 2): the time steps
-    const int j = i - RUA_WAVE;
-    const int64_t t = t0 + j;
-    const bool ok = t < Pk.T;
-    tb.pboff[j] = ok ? Pk.boff[t] : 0;
-    tb.pbsz[j] = ok ? Pk.bsz[t] : 0;
+    const int s = R > 1 ? (int)((base + phase) & (int64_t)(R - 1)) : 0;
+    tb.shift[i] = s;
+    tb.obase[i] = base - s + t0;                  // batch-major row of the rank's window start (a whole-line boundary)
+    tb.olen[i] = len;
+  } else if (i >= RUA_WAVE && i < RUA_WAVE + TT + R - 1) {   // waves 1..: the time steps t0 - (R - 1) .. t0 + TT - 1
+    const int k = i - RUA_WAVE;
+    const int64_t t = t0 - (R - 1) + k;
+    const bool ok = t >= 0 && t < Pk.T;
+    tb.pboff[k] = ok ? Pk.boff[t] : 0;
+    tb.pbsz[k] = ok ? Pk.bsz[t] : 0;
   }
 }
 
@@ -388,10 +403,11 @@ __device__ __forceinline__ void tile_tables(const rua_layout& Pk, const rua_layo
 template <int VEC, bool TO_PACK, int TTL, int TRL>
 __global__ __launch_bounds__(RUA_BLOCK) void pack_tile_lds_kernel(rua_layout Pk, rua_layout Ot, char* __restrict__ dst,
                                                               const char* __restrict__ src, int64_t row_bytes,
-                                                              int64_t lpr, int64_t tiles_per_xcd) {
+                                                              int64_t lpr, int64_t tiles_per_xcd, int R, int64_t phase) {
   using V = typename vec_of<VEC>::type;
   constexpr int TT = 1 << TTL, TR = 1 << TRL, TILE = TR * TT;
-  static_assert(TT <= 64 && TR <= TR_MAX && RUA_BLOCK >= RUA_WAVE + TT, "one lane per rank in wave 0, per time step in waves 1..");
+  static_assert(TT <= 64 && TR <= TR_MAX && RUA_BLOCK >= RUA_WAVE + TT + TILE_SHIFT_MAX,
+                "one lane per rank in wave 0, per time step in waves 1..");
   __shared__ TileTables tb;
 
   int64_t tile = blockIdx.x;                  // (block-uniform) one contiguous span of tiles per XCD, as in the row mover
@@ -400,40 +416,66 @@ __global__ __launch_bounds__(RUA_BLOCK) void pack_tile_lds_kernel(rua_layout Pk,
     if ((int64_t)(blockIdx.x >> 3) >= tiles_per_xcd || tile >= Pk.n_tiles) return;
   }
   int64_t r0, t0;
-  tile_tables<TTL, TRL>(Pk, Ot, tile, tb, r0, t0);
-  (void)t0;
+  tile_tables<TTL, TRL>(Pk, Ot, tile, tb, r0, t0, R, phase);
   __syncthreads();
 
   // ---- phase 2: the tile goes through LDS.  It is read in the SOURCE's contiguous order (consecutive lanes =
   // consecutive 16-byte pieces of consecutive rows of one run) and written in the DESTINATION's contiguous order,
   // so both sides see whole runs per wave instruction (16 ranks on the PackedSequence's side, TT time steps on the
-  // batch-major side).  Cell (rank, time): batch-major row obase[rank] + time, PackedSequence row pboff[time] + r0 + rank;
-  // live iff the sequence still has a token there (time < olen[rank]) and the rank is alive (r0 + rank < pbsz[time]).
+  // batch-major side).  Cell (rank, j), j = the slot in the rank's OWN window (see TileTables): time t = t0 + j - shift[rank],
+  // batch-major row obase[rank] + j, PackedSequence row pboff[k] + r0 + rank with k = j - shift[rank] + R - 1 (the step's
+  // slot in the tile's table); live iff the sequence has a token there (0 <= t < len) and the rank is alive at the step.
   extern __shared__ __attribute__((aligned(16))) unsigned char s_stage_raw[];
   V* stage = reinterpret_cast<V*>(s_stage_raw);
-  const int n_pieces = TILE * (int)lpr;
   // one padding ROW (lpr slots) per rank: the transposed order strides over TT * lpr slots, which would otherwise land
   // the sixteen ranks of a time step on the same LDS banks; with (TT + 1) * lpr the sixteen lanes of a 128-bit LDS
   // pass — ranks x pieces — fall on sixteen different bank groups (a single slot of padding left piece 1 of rank r
   // on the banks of piece 0 of rank r + 1)
-#define RUA_SLOT(rank, time, piece) (((((rank) << TTL) | (time)) + (rank)) * (int)lpr + (piece))
-#define RUA_CELL(rank, time, orow, prow, live)                                                           \
-  const int64_t orow = tb.obase[rank] + (time), prow = tb.pboff[time] + r0 + (rank);                      \
-  const bool live = (time) < tb.olen[rank] && r0 + (rank) < tb.pbsz[time] && orow < Ot.n_rows && prow < Pk.n_rows
+#define RUA_SLOT(rank, j, piece) (((((rank) << TTL) | (j)) + (rank)) * (int)lpr + (piece))
+#define RUA_CELL(rank, j, k, orow, prow, live)                                                                     \
+  const int64_t t_ = t0 + (j) - tb.shift[rank];                                                                    \
+  const int64_t orow = tb.obase[rank] + (j), prow = tb.pboff[k] + r0 + (rank);                                     \
+  const bool live = t_ >= 0 && t_ < tb.olen[rank] && r0 + (rank) < tb.pbsz[k] && orow < Ot.n_rows && prow < Pk.n_rows
+  const int n_major = TILE * (int)lpr;                        // batch-major order: (rank, j), j fastest
+  const int n_packed = (TT + R - 1) * TR * (int)lpr;          // PackedSequence order: (k, rank), rank fastest
+  if (TO_PACK) {
 #pragma unroll 4
-  for (int idx = threadIdx.x; idx < n_pieces; idx += RUA_BLOCK) {
-    const int pos = idx / (int)lpr, piece = idx - pos * (int)lpr;
-    const int rank = TO_PACK ? pos >> TTL : pos & (TR - 1), time = TO_PACK ? pos & (TT - 1) : pos >> TRL;
-    RUA_CELL(rank, time, orow, prow, live);
-    if (live) stage[RUA_SLOT(rank, time, piece)] = ld_row<V, false>(src + (TO_PACK ? orow : prow) * row_bytes + (int64_t)piece * VEC);
-  }
-  __syncthreads();
+    for (int idx = threadIdx.x; idx < n_major; idx += RUA_BLOCK) {
+      const int pos = idx / (int)lpr, piece = idx - pos * (int)lpr;
+      const int rank = pos >> TTL, j = pos & (TT - 1), k = j - tb.shift[rank] + R - 1;
+      RUA_CELL(rank, j, k, orow, prow, live);
+      (void)prow;
+      if (live) stage[RUA_SLOT(rank, j, piece)] = ld_row<V, false>(src + orow * row_bytes + (int64_t)piece * VEC);
+    }
+    __syncthreads();
 #pragma unroll 4
-  for (int idx = threadIdx.x; idx < n_pieces; idx += RUA_BLOCK) {
-    const int pos = idx / (int)lpr, piece = idx - pos * (int)lpr;
-    const int rank = TO_PACK ? pos & (TR - 1) : pos >> TTL, time = TO_PACK ? pos >> TRL : pos & (TT - 1);
-    RUA_CELL(rank, time, orow, prow, live);
-    if (live) st_row<V, false>(dst + (TO_PACK ? prow : orow) * row_bytes + (int64_t)piece * VEC, stage[RUA_SLOT(rank, time, piece)]);
+    for (int idx = threadIdx.x; idx < n_packed; idx += RUA_BLOCK) {
+      const int pos = idx / (int)lpr, piece = idx - pos * (int)lpr;
+      const int rank = pos & (TR - 1), k = pos >> TRL, j = k - (R - 1) + tb.shift[rank];
+      if (j < 0 || j >= TT) continue;
+      RUA_CELL(rank, j, k, orow, prow, live);
+      (void)orow;
+      if (live) st_row<V, false>(dst + prow * row_bytes + (int64_t)piece * VEC, stage[RUA_SLOT(rank, j, piece)]);
+    }
+  } else {
+#pragma unroll 4
+    for (int idx = threadIdx.x; idx < n_packed; idx += RUA_BLOCK) {
+      const int pos = idx / (int)lpr, piece = idx - pos * (int)lpr;
+      const int rank = pos & (TR - 1), k = pos >> TRL, j = k - (R - 1) + tb.shift[rank];
+      if (j < 0 || j >= TT) continue;
+      RUA_CELL(rank, j, k, orow, prow, live);
+      (void)orow;
+      if (live) stage[RUA_SLOT(rank, j, piece)] = ld_row<V, false>(src + prow * row_bytes + (int64_t)piece * VEC);
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int idx = threadIdx.x; idx < n_major; idx += RUA_BLOCK) {
+      const int pos = idx / (int)lpr, piece = idx - pos * (int)lpr;
+      const int rank = pos >> TTL, j = pos & (TT - 1), k = j - tb.shift[rank] + R - 1;
+      RUA_CELL(rank, j, k, orow, prow, live);
+      (void)prow;
+      if (live) st_row<V, false>(dst + orow * row_bytes + (int64_t)piece * VEC, stage[RUA_SLOT(rank, j, piece)]);
+    }
   }
 #undef RUA_CELL
 #undef RUA_SLOT
@@ -457,8 +499,8 @@ __global__ __launch_bounds__(RUA_BLOCK) void pack_roll_tile_kernel(rua_layout Pk
     tile = (int64_t)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
     if ((int64_t)(blockIdx.x >> 3) >= tiles_per_xcd || tile >= Pk.n_tiles) return;
   }
-  int64_t r0, t0;                                  // olen[rank] = tokens of the rank's sequence from the tile's first step
-  tile_tables<TTL, 4>(Pk, Pk, tile, tb, r0, t0);   // (t0) on; the token map needs the absolute step t0 + time
+  int64_t r0, t0;                                  // (no shift here: both sides are the PackedSequence's own runs, so
+  tile_tables<TTL, 4>(Pk, Pk, tile, tb, r0, t0);   //  pboff / pbsz [time] are those of step t0 + time, olen[rank] the length)
   __syncthreads();
   const V fillv = fill_of<VEC>(fillpat);
   const int n_pieces = TILE * (int)lpr;
@@ -466,9 +508,9 @@ __global__ __launch_bounds__(RUA_BLOCK) void pack_roll_tile_kernel(rua_layout Pk
   for (int idx = threadIdx.x; idx < n_pieces; idx += RUA_BLOCK) {
     const int pos = idx / (int)lpr, piece = idx - pos * (int)lpr;
     const int rank = pos & (TR - 1), time = pos >> 4;
-    const int64_t left = tb.olen[rank];                   // len - t0
-    if (time < left && r0 + rank < tb.pbsz[time]) {
-      const int64_t len = left + t0, t = t0 + time;
+    const int64_t len = tb.olen[rank];
+    if (t0 + time < len && r0 + rank < tb.pbsz[time]) {
+      const int64_t t = t0 + time;
       const int64_t ts = apply_tmap(tmap, targ, t, len, len);
       const int64_t drow = tb.pboff[time] + r0 + rank;
       V val = fillv;
@@ -509,10 +551,24 @@ static int launch_pack_tiles(int vec, hipStream_t s, const rua_layout& Pk, const
   const int ttl = (Pk.tile_t_log2 & 0xff) == 0 ? 4 : (Pk.tile_t_log2 & 0xff);      // (0: a caller of ABI <= 3, 16 x 16 tiles)
   const int trl = ((Pk.tile_t_log2 >> 8) & 0xff) == 0 ? 4 : ((Pk.tile_t_log2 >> 8) & 0xff);
   if (ttl < 4 || ttl > 6 || trl != 4) return RUA_EINVAL;
+  // the batch-major side's runs start on 128-byte lines (TileTables): R rows per line, if the host built the table for
+  // it, the rows divide a line and the payload's own address does not spoil it (its offset inside a line, in rows)
+  int R = (int)((Pk.tile_t_log2 >> 16) & 0xff);
+  const uintptr_t major = TO_PACK ? (uintptr_t)src : (uintptr_t)dst;
+  int64_t phase = 0;
+  // ... and only where the batch-major side is the one WRITTEN (P.cat): what costs is a partial-line STORE — the shifted
+  // windows trade whole lines on the batch-major side for fragments on the PackedSequence's, so they gain 2-20 % for
+  // P.cat and LOSE 6-15 % for the pack, whose packed-side fragments would then be the stores (same-box A/B of both
+  // directions at 16 / 32 / 64-byte rows: profiles/r04_tile_shift_ab.txt)
+  if (TO_PACK || R < 2 || R > TILE_SHIFT_MAX || (R & (R - 1)) != 0 || R * row_bytes != 128 || (major & 127) % (uintptr_t)row_bytes != 0) R = 1;
+  else phase = (int64_t)((major & 127) / (uintptr_t)row_bytes);
+#ifdef RUA_TILE_NO_SHIFT          // developer A/B build
+  R = 1; phase = 0;
+#endif
   const size_t lds = (size_t)((((int64_t)1 << (ttl + trl)) + ((int64_t)1 << trl)) * lpr) * vec;   // the staged tile + one padding row per rank
   if (lds > (48u << 10)) return RUA_EINVAL;                            // (the host picks the tile by row width: 32 KiB staged at most)
 #define RUA_LAUNCH_T(VEC, TTLV, TRLV) \
-  hipLaunchKernelGGL((pack_tile_lds_kernel<VEC, TO_PACK, TTLV, TRLV>), g, b, lds, s, Pk, Ot, dst, src, row_bytes, lpr, per_xcd)
+  hipLaunchKernelGGL((pack_tile_lds_kernel<VEC, TO_PACK, TTLV, TRLV>), g, b, lds, s, Pk, Ot, dst, src, row_bytes, lpr, per_xcd, R, phase)
 #define RUA_LAUNCH(VEC)                                                             \
   switch (ttl) {             /* (32 ranks per tile were measured too: slower at every width, not instantiated) */ \
     case 4: RUA_LAUNCH_T(VEC, 4, 4); break;                                         \
