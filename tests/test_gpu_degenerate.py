@@ -139,3 +139,28 @@ def test_short_sequences_side_by_side(H, dtype):
     lens2[77] = 10_000
     data2 = torch.zeros(int(lens2.sum()), H, dtype=dtype, device=DEV)
     assert O.short_seqs_hint(describe(ta.with_host_sizes(data2, lens2)), H * data.element_size()) == 0
+
+
+@pytest.mark.parametrize('H,dtype,skip', [(8, torch.bfloat16, 1), (16, torch.bfloat16, 3), (8, torch.float32, 2), (16, torch.float32, 1)])
+def test_narrow_p_cat_into_a_view_that_starts_inside_a_line(H, dtype, skip):
+    """P.cat at 16 / 32 / 64-byte rows gives every rank its own time origin so that its stores are whole 128-byte lines
+    (rua_move.hip: TileTables); the origin depends on where the OUTPUT starts inside a line.  Write into a view that
+    begins `skip` rows into a fresh allocation: same rows as the plain call, nothing outside the view touched."""
+    from torchrua_amd import _ops as O
+    from torchrua_amd.layout import describe
+    g = torch.Generator().manual_seed(H + skip)
+    lens = torch.randint(1, 200, (3000,), generator=g)
+    N = int(lens.sum())
+    data = torch.randn(N, H, generator=g).to(dtype).to(DEV)
+    c = ta.with_host_sizes(data, lens)
+    p = c.pack()
+    buf = torch.full((N + 8, H), 7.0, dtype=dtype, device=DEV)
+    out = buf[skip:skip + N]
+    O.launch_move(O.MovePlan(describe(c), describe(p), data.shape), p.data, out=out)
+    assert torch.equal(out, data)
+    assert bool((buf[:skip] == 7).all()) and bool((buf[skip + N:] == 7).all())
+    # and the other direction out of such a view (plain windows there: the reads tolerate the misalignment)
+    src = buf[skip:skip + N]
+    packed = torch.empty_like(data)
+    O.launch_move(O.MovePlan(describe(p), describe(c), data.shape), src, out=packed)
+    assert torch.equal(packed, p.data)
