@@ -177,7 +177,7 @@ def int_split_workspace(n_rows: int, H: int, dtype: torch.dtype, dev) -> Tuple[i
     is long the machinery costs two launches of at most ~1 024 waves that find nothing to do."""
     if n_rows < 4096:
         return 0, None
-    # about a thousand parts, but no part beyond ~2 MB of payload: a part is ONE wave's walk (profiles/r04_int_skew.txt)
+    # about a thousand parts, but no part beyond ~2 MB of payload: a part is ONE wave's walk (profiles/r04_skew.txt)
     split = max(1024, min(n_rows // 1024, (2 << 20) // max(1, H * dtype.itemsize)))
     nbytes = L.load().rua_reduce_ws_bytes(n_rows, H, L.INT_DTYPES[dtype], split)
     return split, torch.empty(nbytes, dtype=torch.uint8, device=dev)
