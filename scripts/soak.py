@@ -34,7 +34,7 @@ while time.time() < t_end:
         H = int(rng.choice([3, 8, 64, 130, 512]))
     else:                        # so many short sequences that narrow rows take the adjacent-rank kernels
         B = int(rng.choice([40000, 140000]))
-        hi = int(rng.choice([1, 2, 4, 9, 30]))
+        hi = int(rng.choice([1, 2, 4, 9, 30, 150]))      # (150: four sequences per wave at rows of <= 32 bytes)
         H = int(rng.choice([1, 2, 4, 8, 16, 24, 64, 128]))
     lo = int(rng.randint(1, hi + 1))
     dtype = [torch.float32, torch.bfloat16, torch.float16, torch.float64, torch.int64][int(rng.randint(0, 5))]

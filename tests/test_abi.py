@@ -135,9 +135,8 @@ def test_reducer_split_policy():
     assert O.short_seqs_hint(CatLay(8_000_000, 500_000, None), 32) == 0                     # lengths on the device only
     assert O.short_seqs_hint(CatLay(8_000_000, 500_000, 10_000), 32) == 0                   # one long sequence among them
     assert O.short_seqs_hint(CatLay(8_000_000, 500_000, 31), 1024) == 0                     # rows of a whole wave instruction
-    assert O.short_seqs_hint(CatLay(17_046_960, 65536, 512), 32) == 0                       # 260 rows on average
-    assert O.short_seqs_hint(CatLay(8_000_000, 250_000, 63), 512) == 0                      # 32 on average at 512-byte rows: no
-    assert O.short_seqs_hint(CatLay(8_000_000, 250_000, 63), 64) == _lib.OP_SHORT_SEQS      # ... at 64-byte rows: yes
+    assert O.short_seqs_hint(CatLay(17_046_960, 65536, 512), 32) == _lib.OP_SHORT_SEQS      # 260 on average, at most 512
+    assert O.short_seqs_hint(CatLay(17_046_960, 65536, 5000), 32) == 0                      # ... with an outlier
     pk = CatLay(8_000_000, 500_000, 31)
     pk.kind = _lib.PACK
     assert O.short_seqs_hint(pk, 32) == 0

@@ -96,6 +96,39 @@ def test_every_index_names_one_bucket():
     assert dt < 0.05, f'{dt * 1e3:.1f} ms for three scatters of 4 M entries into one bucket'
 
 
+@pytest.mark.parametrize('H,dtype', [(4, torch.float32), (8, torch.bfloat16), (8, torch.float32), (16, torch.bfloat16), (2, torch.float64)])
+def test_four_sequences_per_wave_at_narrow_rows(H, dtype):
+    """Rows of <= 32 bytes, a few hundred rows per sequence, lengths the host knows and none far above the average: four
+    sequences share a wave, 16 / 8 rows of each per instruction (RUA_OP_SHORT_SEQS, glog > 0 in make_unit).  Same values
+    as the one-wave-per-sequence walk (device-only lengths), gradients included; an empty sequence and a one-row one
+    among them."""
+    g = torch.Generator().manual_seed(100 + H)
+    B = 40_000
+    lens = torch.randint(50, 301, (B,), generator=g)
+    lens[5], lens[6], lens[B - 1] = 0, 1, 700
+    N = int(lens.sum())
+    data = (torch.randn(N, H, generator=g) * 0.5).to(dtype).to(DEV)
+    host, dev = ta.with_host_sizes(data, lens), ta.C(data, lens.to(DEV))
+    for name in ('sum', 'mean', 'max', 'min', 'prod', 'logsumexp'):
+        fn = getattr(ta, f'reduce_{name}')
+        a, b = fn(host), fn(dev)
+        if name in ('max', 'min'):
+            assert torch.equal(a, b), name
+        else:
+            tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
+            assert torch.allclose(a.double(), b.double(), rtol=tol, atol=tol, equal_nan=True), name
+    if dtype in (torch.float32, torch.float64):
+        tied = torch.randint(0, 3, (N, H), generator=g).to(dtype).to(DEV)
+        cot = torch.randn(B, H, generator=g).to(dtype).to(DEV)
+        for name in ('max', 'sum'):
+            grads = []
+            for z_of in (lambda x: ta.with_host_sizes(x, lens), lambda x: ta.C(x, lens.to(DEV))):
+                x = tied.clone().requires_grad_(True)
+                getattr(ta, f'reduce_{name}')(z_of(x)).backward(cot)
+                grads.append(x.grad)
+            assert torch.allclose(grads[0], grads[1], rtol=1e-5, atol=1e-6), f'grad {name}'
+
+
 @pytest.mark.parametrize('H,dtype', [(4, torch.float32), (8, torch.float32), (16, torch.bfloat16), (32, torch.float32),
                                      (50, torch.float32), (100, torch.bfloat16), (128, torch.float32)])
 def test_short_sequences_side_by_side(H, dtype):

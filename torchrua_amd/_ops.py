@@ -184,19 +184,18 @@ def int_split_workspace(n_rows: int, H: int, dtype: torch.dtype, dev) -> Tuple[i
 
 
 def short_seqs_hint(lay: M.Lay, row_bytes: int) -> int:
-    """RUA_OP_SHORT_SEQS for a reduce over a CattedSequence whose lengths the host knows: many short sequences, none far
-    above the average.  One wave (= one workgroup) per sequence is bound by the workgroup dispatch rate there (4 M
-    singletons: 3 ms at any row width; 500 000 sequences of 16 rows: 0.4 ms where the payload takes 0.06); adjacent
-    sequences side by side in a wave win up to 16 .. 64 rows on average by row width (profiles/r04_cat_ranks_ab.txt).
-    The wave walks to the longest of its sequences, hence the bound on the longest one — and no hint at all when the
-    lengths live on the device only."""
+    """RUA_OP_SHORT_SEQS for a reduce over a CattedSequence whose lengths the host knows and none of which is far above
+    the average (at most 8 x, or 64 rows).  One wave (= one workgroup) per sequence is bound by the workgroup dispatch
+    rate when the sequences are short (4 M singletons: 3 ms at any row width; 500 000 sequences of 16 rows: 0.4 ms where
+    the payload takes 0.06) and by a chain of dependent loads per sequence when the rows are narrow; with the hint the
+    launcher puts adjacent sequences side by side in a wave — all of a wave's row slots up to 16 .. 64 rows on average
+    by row width, four sequences per wave beyond that at rows of <= 32 bytes (profiles/r04_cat_ranks_ab.txt).  The wave
+    walks to the longest of its sequences, hence the bound — and no hint at all when the lengths live on the device
+    only."""
     if lay.kind != L.CAT or lay.max_len is None or lay.B <= 0 or not 0 < row_bytes <= 512:
         return 0
-    groups = 64 >> max(0, (-(-row_bytes // 16) - 1).bit_length())      # sequences side by side in a wave
     avg = lay.n_rows / lay.B
-    if avg <= min(64, max(16, 4 * groups)) and lay.max_len <= max(64, 8 * avg):
-        return L.OP_SHORT_SEQS
-    return 0
+    return L.OP_SHORT_SEQS if lay.max_len <= max(64, 8 * avg) else 0
 
 
 def launch_reduce(lay: M.Lay, data: Tensor, op: int, out: Optional[Tensor] = None, include_self: int = 0,

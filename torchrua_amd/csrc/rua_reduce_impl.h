@@ -122,11 +122,14 @@ struct Unit {
 // whole 128-byte line).  Each group then owns its own sequence: no cross-group combine.
 template <typename T, int EPL, bool COPY, int CPW = 1, bool RANKS = false>
 __device__ __forceinline__ Unit<T, EPL> make_unit(const rua_layout& L, const rua_layout& CD, const int64_t* perm,
-                                                   int64_t q, int64_t chunk, int64_t H, int lp_log2, int lane) {
+                                                   int64_t q, int64_t chunk, int64_t H, int lp_log2, int lane,
+                                                   int glog = 0) {
   Unit<T, EPL> u;
   bool live = true;
+  // RANKS with glog > 0 (a CattedSequence of narrow rows): a sequence's lane group is 1 << glog ROW SLOTS wide — it
+  // reads that many consecutive rows of its sequence per instruction — so a wave serves 64 >> (lp_log2 + glog) sequences
   if (RANKS) {
-    q = q * (RUA_WAVE >> lp_log2) + (lane >> lp_log2);
+    q = q * (RUA_WAVE >> (lp_log2 + glog)) + (lane >> (lp_log2 + glog));
     live = q < L.B;
     if (!live) q = L.B - 1;
   }
@@ -137,8 +140,8 @@ __device__ __forceinline__ Unit<T, EPL> make_unit(const rua_layout& L, const rua
   u.b = COPY ? (CD.sorted ? CD.sorted[q] : q) : ((L.kind == RUA_PACK && L.sorted) ? L.sorted[q] : q);
   if (u.b < 0 || u.b >= L.B) u.b = q;   // a corrupt sorted_indices must not index out of range
   u.lp_log2 = lp_log2;
-  u.rpw = RUA_WAVE >> lp_log2;
-  u.rsub = lane >> lp_log2;
+  u.rpw = RANKS ? (1 << glog) : (RUA_WAVE >> lp_log2);                       // rows of ONE sequence per wave instruction
+  u.rsub = RANKS ? ((lane >> lp_log2) & ((1 << glog) - 1)) : (lane >> lp_log2);
   u.col = (chunk * CPW * RUA_WAVE + (lane & ((1 << lp_log2) - 1))) * EPL;   // sub-chunk c adds c * 64 * EPL
   u.colok = u.col < H && live;
   // rows that end in half a vector (dispatch_reduce_main: tail_ok): the last lane covers the row's last EPL elements
@@ -224,15 +227,15 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
     const int64_t tv_next = (tbl && nxt < t_hi) ? tbl[tb + nxt] : 0;
     const int64_t cv_next = (COPY && nxt < t_hi) ? CD.boff[nxt] : 0;
     const int nblk = (t_hi - tblk) < RUA_WAVE ? (int)(t_hi - tblk) : RUA_WAVE;
-    for (int k = 0; k < nblk; k += (RANKS ? 1 : rpw) * UT) {
+    for (int k = 0; k < nblk; k += rpw * UT) {       // (RANKS: rpw = the group's row slots, 1 for adjacent ranks)
       // a team of waves shares one sequence (seg_reduce_team_kernel): wave w takes every team_n-th row group
-      if (team_n > 1 && (int)(((tblk - t_lo) / ((RANKS ? 1 : rpw) * UT) + k / ((RANKS ? 1 : rpw) * UT)) % team_n) != team_w) continue;
+      if (team_n > 1 && (int)(((tblk - t_lo) / (rpw * UT) + k / (rpw * UT)) % team_n) != team_w) continue;
       int64_t row[UT];
       int64_t crow[UT];
       Pack p[UT][CPW];
 #pragma unroll
       for (int u = 0; u < UT; ++u) {
-        const int tl = RANKS ? k + u : k + u * rpw + rsub;   // RANKS: every group walks the same time steps
+        const int tl = k + u * rpw + rsub;   // RANKS: every group walks the same time steps of its own sequence
         const int64_t tabv = __shfl(tv, tl & (RUA_WAVE - 1), RUA_WAVE);
         row[u] = -1;
         if (colok && tl < nblk && (!RANKS || tblk + tl < U.len)) row[u] = base + (tbl ? tabv : tblk + tl);
@@ -385,8 +388,9 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
 // fold the NaN flags in and combine the rpw row-groups of the wave (lanes that differ in the bits above
 // lp_log2); afterwards every lane of a column holds the wave's value
 template <typename A, int EPL, int OP, bool RANKS = false>
-__device__ __forceinline__ void fold_wave(Fold<A, EPL>& f, int lp_log2) {
-  for (int d = RANKS ? RUA_WAVE : (1 << lp_log2); d < RUA_WAVE; d <<= 1) {   // RANKS: groups are separate sequences
+__device__ __forceinline__ void fold_wave(Fold<A, EPL>& f, int lp_log2, int glog = 0) {
+  // RANKS: groups are separate sequences — only the row slots INSIDE a group (1 << glog of them) meet
+  for (int d = 1 << lp_log2; d < (RANKS ? (1 << (lp_log2 + glog)) : RUA_WAVE); d <<= 1) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
       const A o = __shfl_xor(f.acc[e], d, RUA_WAVE);
@@ -436,7 +440,7 @@ __device__ __forceinline__ void fold_store(const Unit<T, EPL>& U, Fold<typename 
   constexpr int CW = RUA_WAVE * EPL;
   const bool keep = include_self == 2 && U.len <= 0;
   const bool inc = include_self == 1;
-  if (U.colok && (RANKS || U.rsub == 0) && !keep) {
+  if (U.colok && U.rsub == 0 && !keep) {       // (RANKS: rsub = the row slot inside the sequence's group)
     const int64_t cnt = U.len + (inc ? 1 : 0);
 #pragma unroll
     for (int ce = 0; ce < EPL * CPW; ++ce) {
@@ -612,10 +616,10 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_ranks_kernel(rua_layout L
                                                                     T* __restrict__ out, int64_t H, int lp_log2,
                                                                     int include_self, T empty_val,
                                                                     unsigned long long* __restrict__ extreme,
-                                                                    typename elem<T>::acc* __restrict__ ties) {
+                                                                    typename elem<T>::acc* __restrict__ ties, int glog) {
   using A = typename elem<T>::acc;
   const int lane = threadIdx.x;
-  const Unit<T, EPL> U = make_unit<T, EPL, false, 1, true>(L, L, nullptr, blockIdx.x, 0, H, lp_log2, lane);
+  const Unit<T, EPL> U = make_unit<T, EPL, false, 1, true>(L, L, nullptr, blockIdx.x, 0, H, lp_log2, lane, glog);
   int64_t t_hi = U.len;                       // the wave walks to its longest sequence
 #pragma unroll
   for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {
@@ -625,7 +629,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_ranks_kernel(rua_layout L
   Fold<A, EPL> f;
   fold_init<A, EPL, OP>(f);
   fold_rows<T, EPL, OP, NT, false, 1, true>(U, 0, t_hi, data, H, f, L, nullptr, lane);
-  fold_wave<A, EPL, OP, true>(f, lp_log2);
+  fold_wave<A, EPL, OP, true>(f, lp_log2, glog);
   fold_store<T, EPL, OP, 1, true>(U, f, out, H, include_self, empty_val, ties);
   fold_flags<A, EPL, OP>(f, extreme, lane, U.live && U.len <= 0);
 }
@@ -1504,16 +1508,29 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
   // (only when that still leaves >= 4 waves per SIMD: with fewer sequences one wave per sequence fills the chip better)
   // (RUA_OP_SHORT_SEQS: the caller knows the longest sequence and vouches that none is far above the average — the
   // wave walks to the longest of its sequences, so ONE long sequence among short ones would be walked by one lane group)
-  const bool cat_ranks = short_seqs && L.kind == RUA_CAT && L.lens && L.len_add == 0;
+  bool cat_ranks = short_seqs && L.kind == RUA_CAT && L.lens && L.len_add == 0 && lp_log2 < 6;
+  int glog = 0;                                   // log2 of the row slots of one sequence's lane group (make_unit)
+  if (cat_ranks) {
+    const int64_t side = RUA_WAVE >> lp_log2;     // sequences side by side with one row slot each
+    const int64_t short_avg = 4 * side < 16 ? 16 : (4 * side > 64 ? 64 : 4 * side);
+    if (L.n_rows > short_avg * L.B) {             // longer than that on average: FOUR sequences per wave at rows of
+      if (lp_log2 <= 1) glog = 4 - lp_log2;       // <= 32 bytes (16 / 8 rows of each per instruction), else one wave each
+      else cat_ranks = false;
+    }
+  }
   if (((L.kind == RUA_PACK && L.sorted) || cat_ranks) && !copy && !perm && lp_log2 < 6 && !(split > 0 && ws) &&
-      (L.B >> (6 - lp_log2)) >= RANKS_MIN_WAVES) {
+      (L.B >> (6 - lp_log2 - glog)) >= RANKS_MIN_WAVES) {
     // narrow rows of a PackedSequence: adjacent ranks share a wave instruction
     // (tried for a CattedSequence with 32-byte rows too — groups = adjacent sequences: 4.0 -> 2.8 TB/s at U(8,512),
     // unsorted neighbours differ too much in length — so C keeps one wave per sequence, EXCEPT for batches of short
     // sequences, when the caller says so: there a wave per sequence is bound by the rate at which workgroups can be
     // dispatched at all — 4 M singletons: 2.98 ms, 1.3 workgroups per ns; 500 000 sequences of 16 rows on average:
-    // 0.40 -> 0.06-0.07 ms at 16 / 32-byte rows, 0.43 -> 0.21 at 128: profiles/r04_cat_ranks_ab.txt)
-    const int64_t rpw = RUA_WAVE >> lp_log2;
+    // 0.40 -> 0.06-0.07 ms at 16 / 32-byte rows, 0.43 -> 0.21 at 128: profiles/r04_cat_ranks_ab.txt.  And at rows of
+    // <= 32 bytes a whole sequence of a few hundred rows is a handful of wave instructions behind a chain of dependent
+    // loads — 2.2 / 4.1 TB/s at 16 / 32 bytes with U(8,512) lengths — so there FOUR sequences share a wave, sixteen /
+    // eight rows of each per instruction; all of it only under the caller's word that no sequence is far above the
+    // average, because the wave walks to the longest of its sequences)
+    const int64_t rpw = RUA_WAVE >> (lp_log2 + glog);
     const int64_t nblk = (L.B + rpw - 1) / rpw;
     if (nblk > 0x7fffffffLL) return RUA_ERANGE;
     T ev;
@@ -1522,7 +1539,7 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
     unsigned long long* ext = (unsigned long long*)extreme;
 #define RUA_RANKS(EPLV, NTV, OPV)                                                                                  \
   hipLaunchKernelGGL((seg_reduce_ranks_kernel<T, EPLV, OPV, NTV>), gg, bb, 0, s, L, (const T*)data, (T*)out, H,    \
-                     lp_log2, include_self, ev, ext, (typename elem<T>::acc*)ties)
+                     lp_log2, include_self, ev, ext, (typename elem<T>::acc*)ties, glog)
 #define RUA_RANKS_OP(EPLV, NTV)                                  \
   switch (op) {                                                  \
     case RUA_SUM: RUA_RANKS(EPLV, NTV, RUA_SUM); break;          \
