@@ -209,11 +209,11 @@ enum rua_op {
 #define RUA_OP_SCRATCH_CLEAN 0x100
 #define RUA_OP_NO_EMPTY      0x200
 /* rua_segment_reduce over a CattedSequence with rows narrower than 1 KiB: the caller KNOWS the lengths and vouches
- * that no sequence is far above the average (torchrua_amd: at most 8 x the average, or 64 rows).  Adjacent sequences
- * may then share a wave, side by side — every row slot of the wave its own sequence when they are short (16 .. 64 rows
- * on average by row width: one wave = one workgroup per sequence is bound by the workgroup dispatch rate there), four
- * sequences per wave at rows of <= 32 bytes whatever their length — because the wave walks to the longest of them.
- * A hint: results do not depend on it (sums to rounding: the association of the fold changes). */
+ * that no sequence is far above the average (torchrua_amd: at most 8 x the average, or 64 rows).  When the sequences
+ * are short (16 .. 64 rows on average by row width) every row slot of a wave then takes a sequence of its own — one
+ * wave = one workgroup per sequence is bound by the workgroup dispatch rate there — and the wave walks to the longest of
+ * them, hence the word.  (At rows of <= 32 bytes four sequences share a wave with or without it: that form checks its
+ * own lengths, wave by wave.)  A hint: results do not depend on it (sums to rounding: the fold's association changes). */
 #define RUA_OP_SHORT_SEQS    0x400
 int64_t rua_reduce_ws_bytes(int64_t n_rows, int64_t H, int32_t dtype, int64_t split_rows);
 /* Waves (1, 2 or 4) that share one sequence in rua_segment_reduce for an aligned payload of `row_bytes`-wide

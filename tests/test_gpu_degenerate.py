@@ -96,37 +96,43 @@ def test_every_index_names_one_bucket():
     assert dt < 0.05, f'{dt * 1e3:.1f} ms for three scatters of 4 M entries into one bucket'
 
 
+@pytest.mark.parametrize('giant', [False, True])
 @pytest.mark.parametrize('H,dtype', [(4, torch.float32), (8, torch.bfloat16), (8, torch.float32), (16, torch.bfloat16), (2, torch.float64)])
-def test_four_sequences_per_wave_at_narrow_rows(H, dtype):
-    """Rows of <= 32 bytes, a few hundred rows per sequence, lengths the host knows and none far above the average: four
-    sequences share a wave, 16 / 8 rows of each per instruction (RUA_OP_SHORT_SEQS, glog > 0 in make_unit).  Same values
-    as the one-wave-per-sequence walk (device-only lengths), gradients included; an empty sequence and a one-row one
-    among them."""
+def test_four_sequences_per_wave_at_narrow_rows(H, dtype, giant):
+    """Rows of <= 32 bytes, a few hundred rows per sequence: four sequences share a wave, 16 / 8 rows of each per
+    instruction (glog > 0 in make_unit), whether the host knows the lengths or not — every wave checks its own four
+    lengths and walks them one after the other when they are far apart (giant=True: one sequence of 50 000 rows among
+    them; with host-known lengths that one arms the long-sequence split instead).  Against the oracle's sequential
+    folds; gradients against the one-row-at-a-time backward of the same library in float64."""
+    import numpy as np
+    from helpers import orc
     g = torch.Generator().manual_seed(100 + H)
     B = 40_000
     lens = torch.randint(50, 301, (B,), generator=g)
     lens[5], lens[6], lens[B - 1] = 0, 1, 700
+    if giant:
+        lens[7777] = 50_000
     N = int(lens.sum())
-    data = (torch.randn(N, H, generator=g) * 0.5).to(dtype).to(DEV)
-    host, dev = ta.with_host_sizes(data, lens), ta.C(data, lens.to(DEV))
-    for name in ('sum', 'mean', 'max', 'min', 'prod', 'logsumexp'):
-        fn = getattr(ta, f'reduce_{name}')
-        a, b = fn(host), fn(dev)
-        if name in ('max', 'min'):
-            assert torch.equal(a, b), name
-        else:
-            tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
-            assert torch.allclose(a.double(), b.double(), rtol=tol, atol=tol, equal_nan=True), name
+    data = (torch.randn(N, H, generator=g) * 0.5).to(dtype)
+    f = data.double().numpy() if dtype == torch.float64 else data.float().numpy()
+    dd = data.to(DEV)
+    ulp = {torch.float32: 0.0, torch.float64: 0.0, torch.bfloat16: 2.0 ** -8}[dtype]
+    for z in (ta.with_host_sizes(dd, lens), ta.C(dd, lens.to(DEV))):
+        for name in ('sum', 'mean', 'max', 'min', 'logsumexp'):
+            ref = getattr(orc, f'segment_{name}')(f, lens.numpy()).astype(np.float64)
+            got = getattr(ta, f'reduce_{name}')(z).double().cpu().numpy()
+            scale = float(np.abs(f).max()) * (int(lens.max()) if name == 'sum' else 1)
+            np.testing.assert_allclose(got, ref, rtol=2e-5 + ulp, atol=2e-5 * scale + ulp + 1e-6, err_msg=name)
     if dtype in (torch.float32, torch.float64):
-        tied = torch.randint(0, 3, (N, H), generator=g).to(dtype).to(DEV)
-        cot = torch.randn(B, H, generator=g).to(dtype).to(DEV)
+        tied = torch.randint(0, 3, (N, H), generator=g).to(dtype)
+        cot = torch.randn(B, H, generator=g).to(dtype)
         for name in ('max', 'sum'):
-            grads = []
+            r = tied.clone().requires_grad_(True)
+            torch.segment_reduce(r, name, lengths=lens, unsafe=True).backward(cot)
             for z_of in (lambda x: ta.with_host_sizes(x, lens), lambda x: ta.C(x, lens.to(DEV))):
-                x = tied.clone().requires_grad_(True)
-                getattr(ta, f'reduce_{name}')(z_of(x)).backward(cot)
-                grads.append(x.grad)
-            assert torch.allclose(grads[0], grads[1], rtol=1e-5, atol=1e-6), f'grad {name}'
+                x = tied.clone().to(DEV).requires_grad_(True)
+                getattr(ta, f'reduce_{name}')(z_of(x)).backward(cot.to(DEV))
+                assert torch.allclose(x.grad.cpu(), r.grad, rtol=1e-5, atol=1e-6), f'grad {name}'
 
 
 @pytest.mark.parametrize('H,dtype', [(4, torch.float32), (8, torch.float32), (16, torch.bfloat16), (32, torch.float32),

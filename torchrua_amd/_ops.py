@@ -188,10 +188,10 @@ def short_seqs_hint(lay: M.Lay, row_bytes: int) -> int:
     the average (at most 8 x, or 64 rows).  One wave (= one workgroup) per sequence is bound by the workgroup dispatch
     rate when the sequences are short (4 M singletons: 3 ms at any row width; 500 000 sequences of 16 rows: 0.4 ms where
     the payload takes 0.06) and by a chain of dependent loads per sequence when the rows are narrow; with the hint the
-    launcher puts adjacent sequences side by side in a wave — all of a wave's row slots up to 16 .. 64 rows on average
-    by row width, four sequences per wave beyond that at rows of <= 32 bytes (profiles/r04_cat_ranks_ab.txt).  The wave
-    walks to the longest of its sequences, hence the bound — and no hint at all when the lengths live on the device
-    only."""
+    launcher gives every row slot of a wave a sequence of its own up to 16 .. 64 rows on average by row width
+    (profiles/r04_cat_ranks_ab.txt).  The wave walks to the longest of its sequences, hence the bound — and no hint at
+    all when the lengths live on the device only.  (Four sequences per wave at rows of <= 32 bytes need no hint: that
+    form checks its own lengths, wave by wave.)"""
     if lay.kind != L.CAT or lay.max_len is None or lay.B <= 0 or not 0 < row_bytes <= 512:
         return 0
     avg = lay.n_rows / lay.B

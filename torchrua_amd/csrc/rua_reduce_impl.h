@@ -626,6 +626,30 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_ranks_kernel(rua_layout L
     const int64_t o = __shfl_xor(t_hi, d, RUA_WAVE);
     t_hi = o > t_hi ? o : t_hi;
   }
+  if (glog > 0) {
+    // Several row slots per sequence (a CattedSequence at rows of <= 32 bytes, a few sequences per wave): the wave checks
+    // its OWN lengths — the lengths may live on the device only, nobody vouched for them — and when they are far apart
+    // (the longest beyond twice the wave's average + 64 rows: one giant sequence next to short ones would be walked by
+    // a quarter of the lanes) it takes its sequences one after the other with every row slot, as seg_reduce_kernel does.
+    const int per_wave = RUA_WAVE >> (lp_log2 + glog);
+    int64_t total = (U.rsub == 0 && (lane & ((1 << lp_log2) - 1)) == 0 && U.live) ? U.len : 0;   // one lane per sequence
+#pragma unroll
+    for (int d = RUA_WAVE / 2; d > 0; d >>= 1) total += __shfl_xor(total, d, RUA_WAVE);
+    if (t_hi * per_wave > 2 * total + (int64_t)64 * per_wave) {        // (wave-uniform)
+      for (int g = 0; g < per_wave; ++g) {
+        const int64_t q = (int64_t)blockIdx.x * per_wave + g;
+        if (q >= L.B) break;
+        const Unit<T, EPL> V = make_unit<T, EPL, false, 1, false>(L, L, nullptr, q, 0, H, lp_log2, lane);
+        Fold<A, EPL> fv;
+        fold_init<A, EPL, OP>(fv);
+        fold_rows<T, EPL, OP, NT, false, 1, false>(V, 0, V.len, data, H, fv, L, nullptr, lane);
+        fold_wave<A, EPL, OP, false>(fv, lp_log2);
+        fold_store<T, EPL, OP, 1, false>(V, fv, out, H, include_self, empty_val, ties);
+        fold_flags<A, EPL, OP>(fv, extreme, lane, V.len <= 0);
+      }
+      return;
+    }
+  }
   Fold<A, EPL> f;
   fold_init<A, EPL, OP>(f);
   fold_rows<T, EPL, OP, NT, false, 1, true>(U, 0, t_hi, data, H, f, L, nullptr, lane);
@@ -1508,14 +1532,14 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
   // (only when that still leaves >= 4 waves per SIMD: with fewer sequences one wave per sequence fills the chip better)
   // (RUA_OP_SHORT_SEQS: the caller knows the longest sequence and vouches that none is far above the average — the
   // wave walks to the longest of its sequences, so ONE long sequence among short ones would be walked by one lane group)
-  bool cat_ranks = short_seqs && L.kind == RUA_CAT && L.lens && L.len_add == 0 && lp_log2 < 6;
+  bool cat_ranks = L.kind == RUA_CAT && L.lens && L.len_add == 0 && lp_log2 < 6;
   int glog = 0;                                   // log2 of the row slots of one sequence's lane group (make_unit)
   if (cat_ranks) {
     const int64_t side = RUA_WAVE >> lp_log2;     // sequences side by side with one row slot each
     const int64_t short_avg = 4 * side < 16 ? 16 : (4 * side > 64 ? 64 : 4 * side);
-    if (L.n_rows > short_avg * L.B) {             // longer than that on average: FOUR sequences per wave at rows of
-      if (lp_log2 <= 1) glog = 4 - lp_log2;       // <= 32 bytes (16 / 8 rows of each per instruction), else one wave each
-      else cat_ranks = false;
+    if (!short_seqs || L.n_rows > short_avg * L.B) {   // no word about the lengths, or longer than that on average:
+      if (lp_log2 <= 1) glog = 4 - lp_log2;       // FOUR sequences per wave at rows of <= 32 bytes (16 / 8 rows of each
+      else cat_ranks = false;                     // per instruction; the wave checks its own lengths), else one wave each
     }
   }
   if (((L.kind == RUA_PACK && L.sorted) || cat_ranks) && !copy && !perm && lp_log2 < 6 && !(split > 0 && ws) &&
@@ -1528,8 +1552,9 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
     // 0.40 -> 0.06-0.07 ms at 16 / 32-byte rows, 0.43 -> 0.21 at 128: profiles/r04_cat_ranks_ab.txt.  And at rows of
     // <= 32 bytes a whole sequence of a few hundred rows is a handful of wave instructions behind a chain of dependent
     // loads — 2.2 / 4.1 TB/s at 16 / 32 bytes with U(8,512) lengths — so there FOUR sequences share a wave, sixteen /
-    // eight rows of each per instruction; all of it only under the caller's word that no sequence is far above the
-    // average, because the wave walks to the longest of its sequences)
+    // eight rows of each per instruction.  Every row slot its own sequence only under the caller's word that no sequence
+    // is far above the average, because the wave walks to the longest of its sequences; the four-per-wave form checks
+    // that by itself, wave by wave (seg_reduce_ranks_kernel), so it also serves lengths that live on the device only)
     const int64_t rpw = RUA_WAVE >> (lp_log2 + glog);
     const int64_t nblk = (L.B + rpw - 1) / rpw;
     if (nblk > 0x7fffffffLL) return RUA_ERANGE;
