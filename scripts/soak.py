@@ -44,6 +44,9 @@ while time.time() < t_end:
     if family == 'long':
         lens[rng.randint(0, B)] = hi          # at least one really long sequence next to random ones
         lens[rng.randint(0, B)] = 1
+    if family == 'many' and rng.randint(0, 2):
+        for _ in range(5):                    # a few outliers: the waves that hold them walk their sequences one by one
+            lens[rng.randint(0, B)] = 40 * hi + 100
     g = torch.Generator().manual_seed(int(rng.randint(0, 2 ** 31)))
     N = int(lens.sum())
     data = torch.randint(-99, 99, (N, H), generator=g) if dtype == torch.int64 else (torch.randn(N, H, generator=g) * 0.5).to(dtype)
