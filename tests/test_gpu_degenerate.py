@@ -203,3 +203,31 @@ def test_narrow_p_cat_into_a_view_that_starts_inside_a_line(H, dtype, skip):
     packed = torch.empty_like(data)
     O.launch_move(O.MovePlan(describe(p), describe(c), data.shape), src, out=packed)
     assert torch.equal(packed, p.data)
+
+
+@pytest.mark.parametrize('H,dtype', [(64, torch.float32), (16, torch.bfloat16), (3, torch.float64)])
+def test_mostly_empty_batch_under_max_min_logsumexp(H, dtype):
+    """Nine sequences in ten are empty: their rows take the reference's `initial` — the global minimum / maximum of the
+    payload (reduce.py:35,40,57).  When the host knows how many rows that is (megabytes: _ops.PARALLEL_PATCH_BYTES) they
+    are patched by a launch of their own, otherwise by the last workgroup of the merged trailing launch; same values
+    either way, for a CattedSequence and a PackedSequence, against the oracle."""
+    import numpy as np
+    from helpers import orc
+    g = torch.Generator().manual_seed(7 + H)
+    B = 150_000
+    lens = torch.where(torch.rand(B, generator=g) < 0.9, torch.tensor(0), torch.randint(1, 40, (B,), generator=g))
+    N = int(lens.sum())
+    data = (torch.randn(N, H, generator=g) * 0.5).to(dtype)
+    f = data.double().numpy() if dtype == torch.float64 else data.float().numpy()
+    dd = data.to(DEV)
+    host = ta.with_host_sizes(dd, lens)
+    ulp = {torch.float32: 0.0, torch.float64: 0.0, torch.bfloat16: 2.0 ** -8}[dtype]
+    for z in (host, ta.C(dd, lens.to(DEV)), host.pack()):
+        for name in ('max', 'min', 'logsumexp'):
+            ref = getattr(orc, f'segment_{name}')(f, lens.numpy()).astype(np.float64)
+            got = getattr(ta, f'reduce_{name}')(z).double().cpu().numpy()
+            np.testing.assert_allclose(got, ref, rtol=2e-5 + ulp, atol=2e-5 + ulp, err_msg=name)
+    # and again (the persistent scratch must have come back zeroed from either form)
+    for z in (host, host.pack()):
+        ref = orc.segment_max(f, lens.numpy()).astype(np.float64)
+        np.testing.assert_allclose(ta.reduce_max(z).double().cpu().numpy(), ref, rtol=2e-5 + ulp, atol=2e-5 + ulp)

@@ -156,6 +156,19 @@ def known_no_empty(token_sizes: Optional[Tensor]) -> bool:
     return hit > 0
 
 
+def known_n_empty(token_sizes: Optional[Tensor]) -> Optional[int]:
+    """How many sequences are empty, when the host can tell WITHOUT a device sync (None otherwise)."""
+    if token_sizes is None:
+        return None
+    hit = _memo_get(token_sizes, 'n_empty')
+    if hit is None:
+        if token_sizes.is_cuda and _memo_get(token_sizes, 'host') is None:
+            return None
+        h = host_lens(token_sizes)
+        hit = _memo_put(token_sizes, 'n_empty', int((h.detach().numpy() <= 0).sum()) if h.numel() else 0)
+    return hit
+
+
 def total_len(token_sizes: Tensor) -> int:
     hit = _memo_get(token_sizes, 'sum')
     if hit is not None:
@@ -377,7 +390,7 @@ def known_max_len(token_sizes: Optional[Tensor]) -> Optional[int]:
 
 class Lay:
     """A rua_layout plus the tensors its pointers borrow (kept alive with it)."""
-    __slots__ = ('c', 'keep', 'kind', 'n_rows', 'B', 'max_len', '_no_empty', 'heavy_tail')
+    __slots__ = ('c', 'keep', 'kind', 'n_rows', 'B', 'max_len', '_no_empty', 'heavy_tail', '_n_empty')
 
     def __init__(self, keep: List[Optional[Tensor]], max_len: Optional[int] = None, **fields):
         self.c = L.RuaLayout(**fields)
@@ -388,9 +401,17 @@ class Lay:
         self.max_len = max_len      # longest sequence, when the host knows it for free
         self._no_empty = False      # bool, or a callable that decides on first use (set by the lay_* builders)
         self.heavy_tail = False     # the buckets of a scatter_*: sizes counted on the device, ONE hot bucket is ordinary
+        self._n_empty = None        # int, None (unknown), or a callable that counts on first use (lay_cat / lay_pack)
 
     def ref(self):
         return ctypes.byref(self.c)
+
+    @property
+    def n_empty(self) -> Optional[int]:
+        """Empty sequences, when the host knows their number without a device sync (only max / min / logsumexp ask)."""
+        if callable(self._n_empty):
+            self._n_empty = self._n_empty()
+        return self._n_empty
 
     @property
     def no_empty(self) -> bool:
@@ -410,6 +431,7 @@ def lay_cat(lens: Optional[Tensor], B: int, n_rows: int, len_add: int = 0) -> La
     mx = known_max_len(lens)
     lay = Lay([lens, off], max_len=None if mx is None else mx + len_add, kind=L.CAT, n_rows=n_rows, B=B, lens=L.ptr(lens), len_add=len_add, off=L.ptr(off))
     lay._no_empty = (lambda: known_no_empty(lens)) if len_add >= 0 else False
+    lay._n_empty = (lambda: known_n_empty(lens)) if len_add == 0 else None
     return lay
 
 
@@ -507,6 +529,8 @@ def lay_pack(p, lens: Optional[Tensor] = None, len_add: int = 0, boff: Optional[
               unsorted=L.ptr(p.unsorted_indices), **extra)
     # batch_sizes[0] counts the sequences that hold a row (a host tensor): all of them, unless some are empty
     lay._no_empty = len_add == 0 and T == p.batch_sizes.numel() and T > 0 and pack_B(p) == pack_nseq(p)
+    if len_add == 0 and T == p.batch_sizes.numel():
+        lay._n_empty = pack_nseq(p) - (pack_B(p) if T > 0 else 0)
     return lay
 
 
