@@ -57,7 +57,10 @@ typedef struct rua_layout {
   int64_t n_rows;          /* storage rows: CAT/PACK: sum(len); LEFT/RIGHT: B*T_phys; LIST: M */
   int64_t B;               /* number of sequences */
   int64_t T_phys;          /* LEFT/RIGHT: rows per sequence in storage (data.size(1)) */
-  int64_t T_log;           /* RIGHT: the T used for right alignment (reference: token_sizes.max()) */
+  int64_t T_log;           /* RIGHT: the T used for right alignment (reference: token_sizes.max()).
+                              CAT: optional hint — the longest sequence when the caller knows it, 0 = unknown
+                              (rua_enum_rows writes sequence by sequence only when no sequence can be a large
+                              share of the launch; results never depend on it) */
   const int64_t* lens;     /* [B] or NULL                                   */
   int64_t len_add;         /* len[b] = (lens ? lens[b] : 0) + len_add       */
   const int64_t* off;      /* CAT: exclusive scan of lens, [B] (NULL when lens is NULL);

@@ -24,6 +24,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 REPS = 3
+DEFAULT = ('ns', 'w32', 'w64')      # the families of round 4's committed file; --only=bwd,odd,w8 ... picks others
+ONLY = [a.split('=', 1)[1].split(',') for a in sys.argv if a.startswith('--only=')]
+ONLY = ONLY[0] if ONLY else []
 MARK = 'mask_kernel<unsigned long'
 
 
@@ -80,12 +83,68 @@ def groups():
         yield f'{tag}.P.roll(1)', 2 * nb, lambda: O.launch_move(O.MovePlan(pl, pl, data.shape, tmap=1, arg=1), p.data, out=out)
         yield f'{tag}.C.roll(0)  [calib: streaming copy, {H * 2} B rows]', 2 * nb, lambda: O.launch_move(O.MovePlan(cl, cl, data.shape, tmap=1, arg=0), data, out=out)
 
-    yield from north_star()
+    def backward():
+        """[r5] the fused reduce backward (rua_segment_reduce_backward) at the north-star shape over C and over P.
+        Algorithmic bytes: sum writes the gradient and reads the [B, H] cotangent; max / logsumexp also read the payload
+        and out (max: and the [B, H] fp32 tie counts the forward left)."""
+        lens, data = ragged(5, 65536, 8, 512, 512)
+        c = ta.with_host_sizes(data, lens)
+        p = c.pack()
+        N, H, B, e = data.size(0), 512, 65536, 2
+        for name, alg in (('sum', N * H * e + B * H * e), ('max', 2 * N * H * e + B * H * (2 * e + 4)),
+                          ('logsumexp', 2 * N * H * e + 2 * B * H * e)):
+            for tag, z in (('C', c), ('P', p)):
+                x = z.data.detach().requires_grad_(True)
+                out = getattr(ta, f'reduce_{name}')(z._replace(data=x))
+                cot = torch.randn_like(out)
+                yield f'bwd.{name}({tag})', alg, (lambda out=out, x=x, cot=cot: torch.autograd.grad(out, x, cot, retain_graph=True))
+                del x, out, cot
+
+    def odd(H):
+        """[r5] rows of 8 (mod 16) bytes (H = 500 / 1 000 in bf16), 8 GB payloads."""
+        rows = int(8e9 / (H * 2))
+        B = max(1024, rows // 260)
+        lens, data = ragged(H, B, 8, 512, H)
+        c = ta.with_host_sizes(data, lens)
+        p = c.pack()
+        nb = data.numel() * 2
+        T = int(lens.max())
+        tag = f'odd{H * 2}'
+        yield f'{tag}.pack', 2 * nb, lambda: c.pack()
+        yield f'{tag}.P.cat', 2 * nb, lambda: p.cat()
+        yield f'{tag}.C.left', nb + B * T * H * 2, lambda: c.left()
+        yield f'{tag}.C.roll(0)  [calib: streaming copy, {H * 2} B rows]', 2 * nb, lambda: c.roll(0)
+
+    def tiny(rb):
+        """[r5] 1-D payloads: rows of 1 / 2 / 4 / 8 bytes (bool masks, fp16 / fp32 scalars, int64 token ids), 500 M rows."""
+        dtype = {1: torch.uint8, 2: torch.float16, 4: torch.float32, 8: torch.int64}[rb]
+        B = 1923076
+        g = torch.Generator().manual_seed(rb)
+        lens = torch.randint(8, 513, (B,), generator=g)
+        n = int(lens.sum())
+        data = torch.randint(0, 100, (n,), device=dev, dtype=torch.int32).to(dtype)
+        c = ta.with_host_sizes(data, lens)
+        p = c.pack()
+        nb = n * rb
+        T = int(lens.max())
+        tag = f'w{rb}'
+        yield f'{tag}.pack', 2 * nb, lambda: c.pack()
+        yield f'{tag}.P.cat', 2 * nb, lambda: p.cat()
+        yield f'{tag}.C.left', nb + B * T * rb, lambda: c.left()
+        yield f'{tag}.P.left', nb + B * T * rb, lambda: p.left()
+        yield f'{tag}.P.roll(1)', 2 * nb, lambda: p.roll(1)
+        yield f'{tag}.C.roll(0)  [calib: streaming copy, {rb} B rows]', 2 * nb, lambda: c.roll(0)
+
     import gc
-    gc.collect()
-    torch.cuda.empty_cache()
-    for H in (16, 32):
-        yield from narrow(H)
+    fams = [('ns', north_star)] + [(f'w{2 * H}', (lambda H=H: narrow(H))) for H in (16, 32)]
+    fams += [('bwd', backward)] + [(f'odd{2 * H}', (lambda H=H: odd(H))) for H in (500, 1000)]
+    fams += [(f'w{rb}', (lambda rb=rb: tiny(rb))) for rb in (8, 4, 2, 1)]
+    for fam, gen in fams:
+        if ONLY and not any(fam.startswith(o) for o in ONLY):
+            continue
+        if not ONLY and fam not in DEFAULT:
+            continue
+        yield from gen()
         gc.collect()
         torch.cuda.empty_cache()
 
@@ -149,12 +208,12 @@ def cut(rows, order):
     return out
 
 
-def summarize(tag):
+def summarize(tag, pre='pmcops'):
     G = os.path.join(ROOT, 'gpurun_out')
-    meta = json.load(open(os.path.join(G, 'pmcops_time.json')))
+    meta = json.load(open(os.path.join(G, f'{pre}_time.json')))
     order = meta['order']
-    fetch = cut(counter_rows(os.path.join(G, 'pmcops_fetch'), 'FETCH_SIZE'), order)
-    write = cut(counter_rows(os.path.join(G, 'pmcops_write'), 'WRITE_SIZE'), order)
+    fetch = cut(counter_rows(os.path.join(G, f'{pre}_fetch'), 'FETCH_SIZE'), order)
+    write = cut(counter_rows(os.path.join(G, f'{pre}_write'), 'WRITE_SIZE'), order)
     out = {'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of scripts/pmc_ops.py; per CALL of the operator '
                    '(all its kernels); read = 2 * FETCH_SIZE KiB (gfx950: half of a wide read stream is reported), write = '
                    'WRITE_SIZE KiB; widths other than 16 B per lane are uncalibrated in absolute terms: compare with the '
@@ -169,7 +228,7 @@ def summarize(tag):
             'hbm_read_bytes': rd, 'hbm_write_bytes': wr, 'traffic_over_algorithmic': round((rd + wr) / alg, 3) if alg else None,
             'kernels_read_KiB_x2': {k: round(2 * v, 1) for k, v in fetch.get(name, {}).items()},
             'kernels_write_KiB': {k: round(v, 1) for k, v in write.get(name, {}).items()}}
-    path = os.path.join(ROOT, 'profiles', f'{tag}_pmc_ops.json')
+    path = os.path.join(ROOT, 'profiles', f'{tag}.json' if pre != 'pmcops' else f'{tag}_pmc_ops.json')
     with open(path, 'w') as f:
         json.dump(out, f, indent=1)
     for name, o in out['ops'].items():
@@ -179,6 +238,6 @@ def summarize(tag):
 
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'summarize':
-        summarize(sys.argv[2] if len(sys.argv) > 2 else 'r04')
+        summarize(sys.argv[2] if len(sys.argv) > 2 else 'r04', *(sys.argv[3:4]))
     else:
         run('--time' in sys.argv)

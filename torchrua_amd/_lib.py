@@ -6,6 +6,7 @@ streams; every kernel is launched through the plain-pointer C ABI on torch's cur
 """
 import ctypes
 import os
+import threading
 from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_int64, c_uint64, c_void_p
 
 import torch  # noqa: F401  (must be imported first: maps the HIP runtime our library binds to)
@@ -112,7 +113,14 @@ def load():
     return lib
 
 
+_tls = threading.local()       # .prev: the device stream_ptr() switched away from for the launch in flight
+
+
 def check(code: int, what: str) -> None:
+    prev = getattr(_tls, 'prev', None)
+    if prev is not None:           # stream_ptr() made another device current for this one launch: hand it back
+        _tls.prev = None
+        torch.cuda.set_device(prev)
     if code == 0:
         return
     if code < 0:
@@ -122,13 +130,19 @@ def check(code: int, what: str) -> None:
 
 
 def stream_ptr(device) -> int:
-    """torch's current stream on `device`.  HIP launches go to the calling thread's current device, so the
-    tensors' device must be it (one process per GPU sets it once with torch.cuda.set_device)."""
-    if device.index is not None and torch.cuda.current_device() != device.index:
-        raise RuaError(f'tensors live on cuda:{device.index} but the current device is '
-                       f'cuda:{torch.cuda.current_device()}: call torch.cuda.set_device / use torch.cuda.device(...)')
+    """torch's current stream on `device` — the device the TENSORS live on, whatever the thread's current device is,
+    as with any torch op (and therefore with the reference: core/get.py:25-29 indexes on `self.data.device`).  A HIP
+    launch goes to the calling thread's current device, so when that is another one it is switched for this ONE launch:
+    every call site is `check(lib.rua_xxx(..., stream_ptr(dev)), name)`, the stream argument is evaluated last before
+    the call and check() runs right after it and switches back.  (One process per GPU never takes this branch.)"""
+    cur = torch.cuda.current_device()
+    idx = cur if device.index is None else device.index
+    if idx != cur:
+        if getattr(_tls, 'prev', None) is None:
+            _tls.prev = cur
+        torch.cuda.set_device(idx)
     # the raw hipStream_t of torch's current stream; torch.cuda.current_stream() builds a Stream object (~6 us a call)
-    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if device.index is None else device.index)
+    return torch._C._cuda_getCurrentRawStream(idx)
 
 
 def require_device(*tensors) -> torch.device:

@@ -429,7 +429,9 @@ def lay_cat(lens: Optional[Tensor], B: int, n_rows: int, len_add: int = 0) -> La
     lens = _as_lens(lens)
     off = dev_off(lens)
     mx = known_max_len(lens)
-    lay = Lay([lens, off], max_len=None if mx is None else mx + len_add, kind=L.CAT, n_rows=n_rows, B=B, lens=L.ptr(lens), len_add=len_add, off=L.ptr(off))
+    longest = None if mx is None else mx + len_add
+    lay = Lay([lens, off], max_len=longest, kind=L.CAT, n_rows=n_rows, B=B, lens=L.ptr(lens), len_add=len_add,
+              off=L.ptr(off), T_log=longest or 0)            # (T_log of a CAT layout: the longest sequence, 0 = unknown)
     lay._no_empty = (lambda: known_no_empty(lens)) if len_add >= 0 else False
     lay._n_empty = (lambda: known_n_empty(lens)) if len_add == 0 else None
     return lay

@@ -123,11 +123,49 @@ def build(pkg) -> None:
             setattr(pkg, k, v)
 
 
+class _AliasFinder:
+    """Meta-path finder that answers `import <alias>.x.y` with the module `torchrua_amd.x.y` ITSELF.  Without it a
+    submodule that was not yet imported when alias_as() ran (`import torchrua.parallel`) would be found through the
+    package's shared __path__ and executed a second time under the alias: two module objects, two sets of classes and
+    autograd Functions, two copies of every piece of module state."""
+
+    def __init__(self, alias: str):
+        self.alias = alias
+
+    def find_spec(self, fullname, path=None, target=None):
+        if fullname != self.alias and not fullname.startswith(self.alias + '.'):
+            return None
+        import importlib
+        import importlib.util
+        real = _PKG + fullname[len(self.alias):]
+        try:
+            mod = importlib.import_module(real)
+        except ModuleNotFoundError as e:
+            if e.name == real:          # no such module under torchrua_amd either: let the import fail as usual
+                return None
+            raise
+        own_spec = mod.__spec__
+
+        class _Loader:
+            def create_module(self, spec):
+                return mod
+
+            def exec_module(self, module):      # already executed under its own name; keep its own spec
+                module.__spec__ = own_spec
+
+        spec = importlib.util.spec_from_loader(fullname, _Loader(), origin=getattr(mod, '__file__', None),
+                                               is_package=hasattr(mod, '__path__'))
+        return spec
+
+
 def alias_as(name: str) -> None:
-    """Every `torchrua_amd[.x.y]` module also answers to `<name>[.x.y]` in sys.modules (install_as_torchrua)."""
+    """Every `torchrua_amd[.x.y]` module also answers to `<name>[.x.y]` in sys.modules (install_as_torchrua): the ones
+    already imported are aliased at once, the rest (`torchrua.parallel`, private modules) when somebody imports them."""
     for key, mod in list(sys.modules.items()):
         if key == _PKG or key.startswith(_PKG + '.'):
             tail = key[len(_PKG):]
-            if tail.startswith('._'):          # private modules keep their own name only
+            if tail.startswith('._'):          # private modules: aliased lazily, by the finder
                 continue
             sys.modules.setdefault(name + tail, mod)
+    if not any(isinstance(f, _AliasFinder) and f.alias == name for f in sys.meta_path):
+        sys.meta_path.insert(0, _AliasFinder(name))

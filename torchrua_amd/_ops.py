@@ -346,12 +346,13 @@ class _ScatterSumRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rows: Tensor, index: Tensor, n_out: int):
-        ctx.index = index
+        ctx.save_for_backward(index)        # (saved, not a plain attribute: autograd then checks its version)
         return scatter_sum_rows(rows.detach(), index, n_out)
 
     @staticmethod
     def backward(ctx, g: Tensor):
-        return gather_rows(g.contiguous(), ctx.index), None, None
+        index, = ctx.saved_tensors
+        return gather_rows(g.contiguous(), index), None, None
 
 
 class _GatherRows(torch.autograd.Function):
@@ -359,14 +360,16 @@ class _GatherRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rows: Tensor, index: Tensor):
-        ctx.index, ctx.n = index, int(rows.size(0))
+        ctx.save_for_backward(index)
+        ctx.n = int(rows.size(0))
         plan = MovePlan(M.lay_list(None, index), M.lay_flat(ctx.n), (index.numel(),) + tuple(rows.shape[1:]), fill=0,
                         name='gather_rows')
         return launch_move(plan, rows.detach())
 
     @staticmethod
     def backward(ctx, g: Tensor):
-        return scatter_sum(g.contiguous(), ctx.index, ctx.n), None
+        index, = ctx.saved_tensors
+        return scatter_sum(g.contiguous(), index, ctx.n), None
 
 
 def gather_rows(rows: Tensor, index: Tensor) -> Tensor:
@@ -385,6 +388,9 @@ def scatter_sum(rows: Tensor, index: Tensor, n_out: int) -> Tensor:
 
 class _NoCtx:
     """Stands in for an autograd context when a Function's forward is run for its value only."""
+
+    def save_for_backward(self, *tensors) -> None:
+        pass
 
 
 def scatter_sum_rows(rows: Tensor, index: Tensor, n_out: int) -> Tensor:

@@ -280,8 +280,18 @@ def _flat_rows(z: Z, key: Tuple[Tensor, Tensor]) -> Tensor:
     """Flat storage rows of (batch_ptr, token_ptr) — core/get.py:25-26, 41-42, 57-58, 73-74 —
     produced by the mover itself (moving an iota of the storage)."""
     n_rows = describe(z).n_rows
-    iota = M.exclusive_scan(torch.ones(n_rows, dtype=torch.long, device=z.data.device))
+    iota = _iota(n_rows, z.data.device)
     return O.launch_move(O.MovePlan(M.lay_list(*key), describe(z), (key[0].numel(),), name='flat_rows'), iota)
+
+
+def _iota(n: int, dev: torch.device) -> Tensor:
+    """0 .. n - 1 as ONE launch of K2: the flat rows of a single sequence of n tokens (round 4 scanned n ones: two
+    n-sized tensors and a three-pass scan per autograd `X[batch_ptr, token_ptr]`)."""
+    out = torch.empty(n, dtype=torch.long, device=dev)
+    if n:
+        K.check(K.load().rua_enum_rows(M.lay_cat(None, 1, n, len_add=n).ref(), n, None, None, K.ptr(out),
+                                       K.stream_ptr(dev)), 'rua_enum_rows')
+    return out
 
 
 def _row_index(index: Tensor, n_rows: int):

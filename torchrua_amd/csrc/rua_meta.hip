@@ -361,6 +361,7 @@ constexpr int ENUM_SEQ_PER_WAVE = 8;
 // 50 -> 41 us at an average of 48, but 41 -> 72 us at an average of 20; with batch_ptr / token_ptr as well (two or
 // three stores per token) the per-sequence form only draws level from ~130 tokens up (46.6 -> 44.4 us at 260)
 constexpr int64_t ENUM_SEQ_MIN_AVG_FLAT = 48, ENUM_SEQ_MIN_AVG_PTR = 128;
+constexpr int64_t ENUM_SEQ_MAX_SHARE_INV = 256;   // the longest sequence may hold at most this fraction^-1 of the tokens
 typedef long long i64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 __device__ __forceinline__ void store_run2(int64_t* __restrict__ dst, int64_t t, int64_t len, int64_t a, int64_t b) {
   if (t + 1 < len) {
@@ -582,7 +583,12 @@ int rua_enum_rows(const rua_layout* lay, int64_t n_tokens, int64_t* batch_ptr, i
   // the batch-major layouts with ragged lengths (C.idx() alone stays an iota)
   if (lay->kind != RUA_PACK && lay->off && lay->lens && (batch_ptr || token_ptr || lay->kind != RUA_CAT)) {
     const int64_t min_avg = (batch_ptr || token_ptr) ? ENUM_SEQ_MIN_AVG_PTR : ENUM_SEQ_MIN_AVG_FLAT;
-    const bool by_seq = n_tokens >= lay->B * min_avg;
+    // ... sequence by sequence only when no sequence can be a large share of the launch: a wave walks its sequences
+    // whole, so one multi-million-token sequence among short ones would be written by a single wave (milliseconds where
+    // the token-balanced enum_flat_kernel takes tens of microseconds: ADVICE r4).  An upper bound on the lengths is the
+    // storage's own T for the padded layouts and the caller's hint (rua_layout::T_log, 0 = unknown) for a CattedSequence.
+    const int64_t longest = lay->kind == RUA_CAT ? lay->T_log : lay->T_phys;
+    const bool by_seq = n_tokens >= lay->B * min_avg && longest > 0 && longest <= n_tokens / ENUM_SEQ_MAX_SHARE_INV;
     if (by_seq && lay->len_add == 0) {
       const int64_t waves = (lay->B + ENUM_SEQ_PER_WAVE - 1) / ENUM_SEQ_PER_WAVE;
       hipLaunchKernelGGL(enum_seq_kernel, dim3((unsigned)((waves + RUA_WAVES_PER_BLOCK - 1) / RUA_WAVES_PER_BLOCK)),

@@ -992,6 +992,116 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_tail_kernel(rua_layout 
   }
 }
 
+// [r5] The walk, lean: SUM / MEAN / LOGSUMEXP and MAX / MIN with the forward's tie counts over whole sequences of any
+// layout — no row indirection, no old destination row, no PROD, no parts.  backward_unit serves all of those at once and
+// pays for it in registers (87 VGPRs for max / logsumexp: FIVE waves per SIMD, and plain stores); here the sequence's
+// three rows become two register sets once (what a hit / every element receives, and out or its exp shift), rows are
+// 64-bit element offsets, and payload accesses are non-temporal on big payloads like the mover's.  Over a
+// PackedSequence at the north-star shape: see DESIGN.md §4.4.
+template <typename T, int EPL, int OP, bool NT>
+__global__ __launch_bounds__(RUA_WAVE) void seg_backward_walk_kernel(rua_layout L, const T* __restrict__ data,
+                                                                     const T* __restrict__ out,
+                                                                     const T* __restrict__ gout, T* __restrict__ gin,
+                                                                     int64_t H, int lp_log2, int64_t n_chunks,
+                                                                     int tie_rule,
+                                                                     const typename elem<T>::acc* __restrict__ ties) {
+  using A = typename elem<T>::acc;
+  struct alignas(sizeof(T) * EPL) Pack { T v[EPL]; };
+  typedef unsigned int RawV __attribute__((ext_vector_type(sizeof(T) * EPL >= 4 ? sizeof(T) * EPL / 4 : 1)));
+  struct alignas(sizeof(A) * EPL >= 16 ? 16 : sizeof(A) * EPL) Cnt { A v[EPL]; };
+  constexpr bool need_x = (OP != RUA_SUM && OP != RUA_MEAN);
+  constexpr bool is_ext = (OP == RUA_MAX || OP == RUA_MIN);
+  constexpr int UB = UNROLL_B;
+  const int lane = threadIdx.x;
+  const int64_t wid = blockIdx.x;
+  const int64_t q = wid / n_chunks;
+  if (q >= L.B) return;
+  const Unit<T, EPL> U = make_unit<T, EPL, false>(L, L, nullptr, q, wid - q * n_chunks, H, lp_log2, lane);
+  const int64_t len = U.len;
+  if (len <= 0) return;
+  A f[EPL], o[EPL];
+  Pack rs;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) { f[e] = (A)0; o[e] = (A)0; rs.v[e] = elem<T>::down((A)0); }
+  if (U.colok) {
+    const int64_t at = U.b * H + U.col;
+    const Pack pg = *reinterpret_cast<const Pack*>(gout + at);
+    if (need_x) {
+      const Pack po = *reinterpret_cast<const Pack*>(out + at);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) o[e] = elem<T>::up(po.v[e]);
+    }
+    if (is_ext) {
+      const Cnt pc = *reinterpret_cast<const Cnt*>(ties + at);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) f[e] = tie_share(elem<T>::up(pg.v[e]), (A)pc.v[e], tie_rule != 0);
+    } else {
+      const A scale = OP == RUA_MEAN ? (A)1 / (A)len : (A)1;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) f[e] = elem<T>::up(pg.v[e]) * scale;
+    }
+    if (OP == RUA_LOGSUMEXP) {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) o[e] = exp_shift(o[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) rs.v[e] = OP == RUA_SUM ? pg.v[e] : elem<T>::down(f[e]);
+  }
+  const int64_t* __restrict__ tbl = U.tbl;
+  const int64_t tb = U.tb, base = U.base, n_rows = U.n_rows;
+  const int rpw = U.rpw, rsub = U.rsub;
+  const int64_t col = U.col;
+  const bool colok = U.colok;
+  int64_t tv = (tbl && lane < len) ? tbl[tb + lane] : 0;
+  for (int64_t tblk = 0; tblk < len; tblk += RUA_WAVE) {
+    const int64_t nxt = tblk + RUA_WAVE + lane;
+    const int64_t tv_next = (tbl && nxt < len) ? tbl[tb + nxt] : 0;
+    const int nblk = (len - tblk) < RUA_WAVE ? (int)(len - tblk) : RUA_WAVE;
+    for (int k = 0; k < nblk; k += rpw * UB) {
+      int64_t at[UB];
+      Pack px[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int tl = k + u * rpw + rsub;
+        const int64_t tabv = __shfl(tv, tl & (RUA_WAVE - 1), RUA_WAVE);
+        int64_t row = -1;
+        if (colok && tl < nblk) row = base + (tbl ? tabv : tblk + tl);
+        at[u] = (row >= 0 && row < n_rows) ? row * H + col : -1;
+        if (need_x && at[u] >= 0) {
+          if (NT && sizeof(Pack) >= 4) {
+            RawV raw = __builtin_nontemporal_load(reinterpret_cast<const RawV*>(data + at[u]));
+            __builtin_memcpy(&px[u], &raw, sizeof(Pack));
+          } else {
+            px[u] = *reinterpret_cast<const Pack*>(data + at[u]);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        if (at[u] < 0) continue;
+        if (need_x) {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            const A x = elem<T>::up(px[u].v[e]);
+            A gi;
+            if (OP == RUA_LOGSUMEXP) gi = f[e] * exp_shifted(x, o[e]);
+            else gi = ((x == o[e]) || (x != x && o[e] != o[e])) ? f[e] : (A)0;
+            rs.v[e] = elem<T>::down(gi);
+          }
+        }
+        if (NT && sizeof(Pack) >= 4) {
+          RawV raw;
+          __builtin_memcpy(&raw, &rs, sizeof(Pack));
+          __builtin_nontemporal_store(raw, reinterpret_cast<RawV*>(gin + at[u]));
+        } else {
+          *reinterpret_cast<Pack*>(gin + at[u]) = rs;
+        }
+      }
+    }
+    tv = tv_next;
+  }
+}
+
 // backward over a PackedSequence with narrow rows: adjacent ranks side by side (see seg_reduce_ranks_kernel)
 template <typename T, int EPL, int OP, int TIES>
 __global__ __launch_bounds__(RUA_WAVE) void seg_backward_ranks_kernel(rua_layout L, const T* __restrict__ data,
@@ -1084,60 +1194,136 @@ __global__ __launch_bounds__(RUA_BLOCK) void seg_backward_rows_kernel(rua_layout
   }
   __syncthreads();
 
-  // ---- phase 2: one wave instruction per row piece, 4 row groups in flight
+  // ---- phase 2 [r5].  A wave takes UB CONSECUTIVE row groups of the tile (4 KiB of contiguous stores at 1-KiB rows).
+  // Round 4's body kept four rows' addresses as 64-bit pairs, fetched the sequence's rows inside the per-row loop and
+  // divided by the tie count per ELEMENT and row: 103-123 VGPRs, i.e. FOUR waves per SIMD — half the loads in flight of
+  // the mover, whose rate at that occupancy is this kernel's (8 -> 4 workgroups per CU takes C->P from
+  // 6.2 to 5.6 TB/s) — 4.6 TB/s for max, 5.1 for logsumexp at the north-star shape with traffic = 1.000 x algorithmic.
+  // Now: the rows of a wave almost always belong to ONE sequence (a wave-uniform test of its first and last row), so
+  // the sequence's g / out / ties rows are fetched once through a scalar base, the tie share is divided once, and the
+  // payload is addressed as tile base (scalar) + a 32-bit offset.  A wave that straddles a boundary, or holds padding
+  // rows of L / R, walks its rows one at a time.
   constexpr int UB = 4;
   const int lane = threadIdx.x & (RUA_WAVE - 1), wave = threadIdx.x >> 6;
   const int rpw = RUA_WAVE >> lp_log2;
   const int rsub = lane >> lp_log2;
-  const int64_t col0 = (int64_t)(lane & ((1 << lp_log2) - 1)) * EPL;
+  const int col0 = (lane & ((1 << lp_log2) - 1)) * EPL;
   constexpr bool need_x = (OP != RUA_SUM && OP != RUA_MEAN);
-  for (int g0 = wave; g0 * rpw < nrows; g0 += RUA_WAVES_PER_BLOCK * UB) {
-    for (int c = 0; c < cpr; ++c) {
-      const int64_t col = col0 + (int64_t)c * RUA_WAVE * EPL;
-      const bool colok = col < H;
-      int64_t row[UB], bb[UB];
-      Pack px[UB];
+  constexpr bool is_ext = (OP == RUA_MAX || OP == RUA_MIN);
+  struct alignas(sizeof(A) * EPL >= 16 ? 16 : sizeof(A) * EPL) Cnt { A v[EPL]; };
+  const T* __restrict__ xt = data + tile0 * H;          // (wave-uniform: scalar base + 32-bit offsets below)
+  T* __restrict__ gt = gin + tile0 * H;
+  const int Hi = (int)H;
+  auto load_x = [&](unsigned off) -> Pack {
+    Pack v;
+    if (NT && sizeof(Pack) >= 4) {
+      RawV raw = __builtin_nontemporal_load(reinterpret_cast<const RawV*>(xt + off));
+      __builtin_memcpy(&v, &raw, sizeof(Pack));
+    } else {
+      v = *reinterpret_cast<const Pack*>(xt + off);
+    }
+    return v;
+  };
+  auto store_g = [&](unsigned off, const Pack& v) {
+    if (NT && sizeof(Pack) >= 4) {
+      RawV raw;
+      __builtin_memcpy(&raw, &v, sizeof(Pack));
+      __builtin_nontemporal_store(raw, reinterpret_cast<RawV*>(gt + off));
+    } else {
+      *reinterpret_cast<Pack*>(gt + off) = v;
+    }
+  };
+  for (int g0 = wave * UB; g0 * rpw < nrows; g0 += RUA_WAVES_PER_BLOCK * UB) {
+    const int rA = g0 * rpw;
+    const int rB = (rA + UB * rpw < nrows ? rA + UB * rpw : nrows) - 1;
+    const int64_t bA = s_b[rA], bB = s_b[rB];
+    if (bA == bB && bA >= 0) {                           // wave-uniform: every row of the wave is a token of sequence bA
+      const int64_t bs = ((int64_t)__builtin_amdgcn_readfirstlane((int)(bA >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)bA);
+      const T* __restrict__ gs = gout + bs * H;
+      const T* __restrict__ os = out + bs * H;
+      A scale = (A)1;
+      if (OP == RUA_MEAN) scale = s_scale[rA];
+      for (int c = 0; c < cpr; ++c) {
+        const int col = col0 + c * RUA_WAVE * EPL;
+        const bool colok = col < Hi;
+        Pack px[UB];
+        unsigned off[UB];
+        bool ok[UB];
 #pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        const int r = (g0 + u * RUA_WAVES_PER_BLOCK) * rpw + rsub;
-        row[u] = -1;
-        bb[u] = -1;
-        if (colok && r < nrows) {
-          row[u] = tile0 + r;
-          bb[u] = s_b[r];
-          if (need_x && bb[u] >= 0) {
-            const T* src = data + row[u] * H + col;
-            if (NT && sizeof(Pack) >= 4) {
-              RawV raw = __builtin_nontemporal_load(reinterpret_cast<const RawV*>(src));
-              __builtin_memcpy(&px[u], &raw, sizeof(Pack));
-            } else {
-              px[u] = *reinterpret_cast<const Pack*>(src);
+        for (int u = 0; u < UB; ++u) {
+          const int r = (g0 + u) * rpw + rsub;
+          ok[u] = colok && r < nrows;
+          off[u] = (unsigned)(r * Hi + col);
+          if (need_x && ok[u]) px[u] = load_x(off[u]);
+        }
+        if (!colok) continue;
+        const Pack pg = *reinterpret_cast<const Pack*>(gs + col);
+        A f[EPL], o[EPL];                                // f: what a hit (max / min), or every element, receives
+        if (need_x) {
+          const Pack po = *reinterpret_cast<const Pack*>(os + col);
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) o[e] = elem<T>::up(po.v[e]);
+        }
+        if (is_ext) {
+          const Cnt pc = *reinterpret_cast<const Cnt*>(ties + bs * H + col);
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) f[e] = tie_share(elem<T>::up(pg.v[e]), (A)pc.v[e], tie_rule != 0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) f[e] = elem<T>::up(pg.v[e]) * scale;
+        }
+        if (OP == RUA_LOGSUMEXP) {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) o[e] = exp_shift(o[e]);
+        }
+        Pack rs;
+        if (!need_x) {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) rs.v[e] = OP == RUA_SUM ? pg.v[e] : elem<T>::down(f[e]);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          if (!ok[u]) continue;
+          if (need_x) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+              const A x = elem<T>::up(px[u].v[e]);
+              A gi;
+              if (OP == RUA_LOGSUMEXP) gi = f[e] * exp_shifted(x, o[e]);
+              else gi = ((x == o[e]) || (x != x && o[e] != o[e])) ? f[e] : (A)0;
+              rs.v[e] = elem<T>::down(gi);
             }
           }
+          store_g(off[u], rs);
         }
       }
-      // the tie counts of the lane's EPL columns in one (or two) 16-byte loads: EPL scalar loads would touch a
-      // different cache line in every lane group
-      struct alignas(sizeof(A) * EPL >= 16 ? 16 : sizeof(A) * EPL) Cnt { A v[EPL]; };
-      Pack pg, po;
-      Cnt pc;
-      int64_t have = -1;        // the sequence whose rows pg / po / pc hold: neighbouring rows mostly share it
+      continue;
+    }
+    // a sequence boundary (or padding rows) inside the wave's rows: one row group at a time
+#pragma unroll 1
+    for (int u = 0; u < UB; ++u) {
+      const int r = (g0 + u) * rpw + rsub;
+      if (r >= nrows) continue;
+      const int64_t b = s_b[r];
+      for (int c = 0; c < cpr; ++c) {
+        const int col = col0 + c * RUA_WAVE * EPL;
+        if (col >= Hi) continue;
+        const unsigned off = (unsigned)(r * Hi + col);
+        Pack rs;
+        if (b < 0) {
 #pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        if (row[u] < 0) continue;
-        Pack res;
-        if (bb[u] < 0) {
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) res.v[e] = elem<T>::down((A)0);
+          for (int e = 0; e < EPL; ++e) rs.v[e] = elem<T>::down((A)0);
         } else {
-          if (bb[u] != have) {
-            have = bb[u];
-            pg = *reinterpret_cast<const Pack*>(gout + have * H + col);
-            if (need_x) po = *reinterpret_cast<const Pack*>(out + have * H + col);
-            if (OP == RUA_MAX || OP == RUA_MIN) pc = *reinterpret_cast<const Cnt*>(ties + have * H + col);
-          }
+          Pack px;
+          if (need_x) px = load_x(off);
+          const Pack pg = *reinterpret_cast<const Pack*>(gout + b * H + col);
+          Pack po;
+          Cnt pc;
+          if (need_x) po = *reinterpret_cast<const Pack*>(out + b * H + col);
+          if (is_ext) pc = *reinterpret_cast<const Cnt*>(ties + b * H + col);
           A scale = (A)1;
-          if (OP == RUA_MEAN) scale = s_scale[(g0 + u * RUA_WAVES_PER_BLOCK) * rpw + rsub];
+          if (OP == RUA_MEAN) scale = s_scale[r];
 #pragma unroll
           for (int e = 0; e < EPL; ++e) {
             const A g = elem<T>::up(pg.v[e]);
@@ -1145,24 +1331,14 @@ __global__ __launch_bounds__(RUA_BLOCK) void seg_backward_rows_kernel(rua_layout
             if (OP == RUA_SUM) gi = g;
             else if (OP == RUA_MEAN) gi = g * scale;
             else {
-              const A x = elem<T>::up(px[u].v[e]), o = elem<T>::up(po.v[e]);
-              if (OP == RUA_LOGSUMEXP) gi = g * fexp(x - o);
-              else {
-                const bool hit = (x == o) || (x != x && o != o);
-                gi = hit ? tie_share(g, (A)pc.v[e], tie_rule != 0) : (A)0;
-              }
+              const A x = elem<T>::up(px.v[e]), o = elem<T>::up(po.v[e]);
+              if (OP == RUA_LOGSUMEXP) gi = g * exp_shifted(x, exp_shift(o));
+              else gi = ((x == o) || (x != x && o != o)) ? tie_share(g, (A)pc.v[e], tie_rule != 0) : (A)0;
             }
-            res.v[e] = elem<T>::down(gi);
+            rs.v[e] = elem<T>::down(gi);
           }
         }
-        T* dstp = gin + row[u] * H + col;
-        if (NT && sizeof(Pack) >= 4) {
-          RawV raw;
-          __builtin_memcpy(&raw, &res, sizeof(Pack));
-          __builtin_nontemporal_store(raw, reinterpret_cast<RawV*>(dstp));
-        } else {
-          *reinterpret_cast<Pack*>(dstp) = res;
-        }
+        store_g(off, rs);
       }
     }
   }
@@ -1798,6 +1974,30 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
     if (vec_ok) { RUA_BRANKS_OP(FULL) } else if (half_ok) { RUA_BRANKS_OP(HALF) } else { RUA_BRANKS_OP(1) }
 #undef RUA_BRANKS_OP
 #undef RUA_BRANKS
+    return (int)hipGetLastError();
+  }
+  // whole sequences, no indirection, an op whose row gradient needs no counting walk: the lean walk (one wave per
+  // (sequence, column chunk) — a PackedSequence of wide rows, and x-reading ops over rows wider than 1 KiB)
+  if (!perm && !self_in && !(extra_count & BWD_SELF_COUNTS) && rows_op && !(split > 0 && ws)) {
+    const bool nt = (double)L.n_rows * (double)H * (double)sizeof(T) >= (double)(512ll << 20);
+    const dim3 gg((unsigned)blocks), bb(RUA_WAVE);
+    using A = typename elem<T>::acc;
+#define RUA_BWALK(EPLV, OPV, NTV)                                                                                   \
+  hipLaunchKernelGGL((seg_backward_walk_kernel<T, EPLV, OPV, NTV>), gg, bb, 0, s, L, (const T*)data, (const T*)out,  \
+                     (const T*)gout, (T*)gin, H, lp_log2, n_chunks, tie_rule, (const A*)ties)
+#define RUA_BWALK_OP(EPLV, NTV)                                 \
+  switch (op) {                                                 \
+    case RUA_SUM: RUA_BWALK(EPLV, RUA_SUM, NTV); break;         \
+    case RUA_MEAN: RUA_BWALK(EPLV, RUA_MEAN, NTV); break;       \
+    case RUA_MAX: RUA_BWALK(EPLV, RUA_MAX, NTV); break;         \
+    case RUA_MIN: RUA_BWALK(EPLV, RUA_MIN, NTV); break;         \
+    default: RUA_BWALK(EPLV, RUA_LOGSUMEXP, NTV); break;        \
+  }
+#define RUA_BWALK_NT(EPLV) if (nt) { RUA_BWALK_OP(EPLV, true) } else { RUA_BWALK_OP(EPLV, false) }
+    if (vec_ok) { RUA_BWALK_NT(FULL) } else if (half_ok) { RUA_BWALK_NT(HALF) } else { RUA_BWALK_NT(1) }
+#undef RUA_BWALK_NT
+#undef RUA_BWALK_OP
+#undef RUA_BWALK
     return (int)hipGetLastError();
   }
   if (vec_ok)

@@ -10,6 +10,8 @@ reduce_*   : the same reductions over the sequences of ANY container (C/L/P/R) -
              order, without first converting to C (BASELINE.json's `reduce_sum`; SURVEY.md §8d spells
              it in the reference as p.cat() + segment_sum, or scatter_sum over p.ptr()[0]).
 """
+import os
+
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -168,7 +170,12 @@ class _Scatter(torch.autograd.Function):
             H *= d
         g_src = g_ten = None
         if ctx.needs_input_grad[2]:
-            g_src = torch.empty(source.shape, dtype=source.dtype, device=dev)   # every source row sits in one bucket
+            # every source row sits in one bucket — unless its index is out of range: the bucket builder drops such
+            # entries (torch's index_add / index_reduce device-assert on them), and their gradient rows would stay
+            # unwritten.  Small gradients are simply zeroed first; large ones are not (a second pass over N x H), and
+            # RUA_CHECK_INDEX=1 turns the silent drop into torch's IndexError in the forward (_scatter)
+            g_src = (torch.zeros if source.numel() * source.element_size() <= _ZERO_GRAD_BYTES else torch.empty)(
+                source.shape, dtype=source.dtype, device=dev)
             ties, mode, self_in = None, (1 if inc else 0), None
             if op in (K.MAX, K.MIN):
                 # the forward counted the source rows equal to the result; the kernel adds the old row's tie
@@ -206,6 +213,10 @@ class _Scatter(torch.autograd.Function):
 _Scatter._backward_once = staticmethod(once_differentiable(_Scatter._backward_impl))      # every op but the one above
 
 
+_ZERO_GRAD_BYTES = 16 << 20
+_CHECK_INDEX = os.environ.get('RUA_CHECK_INDEX', '') not in ('', '0')
+
+
 def _scatter(tensor: T, index: T, source: T, op: int, include_self: bool, dim: int) -> T:
     K.require_device(tensor, index, source)
     if dim != 0:
@@ -232,6 +243,12 @@ def _scatter(tensor: T, index: T, source: T, op: int, include_self: bool, dim: i
                          f'(got {tuple(index.shape)} for {source.size(0)} rows)')
     if index.dtype not in (torch.long, torch.int32):
         raise K.RuaError(f'scatter_*: index must be int64 or int32 (got {index.dtype})')
+    if _CHECK_INDEX and index.numel():
+        # debug aid (one sync): entries outside [0, S) are DROPPED by the bucket builder (rua.h: rua_index_buckets),
+        # where torch.index_add / index_reduce device-assert; with the switch on they raise like torch's CPU path
+        lo, hi = int(index.min()), int(index.max())
+        if lo < 0 or hi >= tensor.size(0):
+            raise IndexError(f'scatter_*: index out of range [0, {tensor.size(0)}): min {lo}, max {hi}')
     if tensor.dtype in K.INT_DTYPES:
         return _scatter_int(tensor, index, source, op, bool(include_self))
     return _Scatter.apply(tensor, index, source, op, bool(include_self))
