@@ -368,6 +368,7 @@ def main():
         sync()
         dl_ms = (time.perf_counter() - t1) / k * 1e3
         extra['value_device_lens'] = round(N * H / (dl_ms * 1e-3) / 1e6, 1)
+        extra['value_reference_signature'] = extra['value_device_lens']     # (the call a user of the reference makes)
         extra['device_lens'] = {
             'call': 'C(data, token_sizes_host.to(device)).pack() -> reduce_sum: the reference\'s own constructor signature; '
                     'every step uploads the lengths from pageable memory, every pack() reads them back (blocking D2H) '
@@ -410,6 +411,53 @@ def main():
             'kernel_ms': round(timer.mean_ms('pack_reduce') or 0.0, 4),
             'hbm_bytes_moved': 2.0 * N * H * e + 1.0 * B * H * e,
             'note': 'one kernel returns the PackedSequence AND the [B,H] sums; 2/3 of the pipeline traffic'}
+        del pf, of, p_ref
+        # [r5] what a plain copy gets on THIS box, in THIS process, through the same mover: c.roll(0) streams the payload
+        # from one CattedSequence into another (no gather).  Boxes of the pool differ by +-4 % and buffer placement by
+        # as much again; the pack kernel's rate over this one is the figure that does not move with them
+        c_stream = ta.with_host_sizes(data, lens_host)
+        cr = c_stream.roll(0)
+        sync()
+        evs = []
+        for _ in range(k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            cr = c_stream.roll(0)
+            e1.record()
+            evs.append((e0, e1))
+        sync()
+        copy_ms = sorted(a.elapsed_time(b) for a, b in evs)[len(evs) // 2]
+        del cr
+        extra['copy_ceiling'] = {'op': 'c.roll(0): a streaming copy of the same payload through the row mover, same process',
+                                 'ms': round(copy_ms, 4), 'GBps': round(2.0 * N * H * e / (copy_ms * 1e-3) / 1e9, 1),
+                                 'frac_of_hbm_peak': round(2.0 * N * H * e / (copy_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        # [r5] forward + backward: pack -> reduce_sum -> backward to `data` (a training step's share of this path).
+        # Algorithmic bytes: the forward's 3 N H e + B H e, the reduce's backward writes N H e (and reads the [B, H]
+        # cotangent), the pack's backward (P -> C, the adjoint move) reads and writes N H e: 6 N H e + 2 B H e
+        xg = data.detach().requires_grad_(True)
+        cot = torch.ones((B, H), dtype=data.dtype, device=dev)
+
+        def fwd_bwd():
+            out_ = ta.reduce_sum(ta.with_host_sizes(xg, lens_host).pack())
+            return torch.autograd.grad(out_, xg, cot)[0]
+
+        for _ in range(2):
+            gx = fwd_bwd()
+        sync()
+        t3 = time.perf_counter()
+        for _ in range(k):
+            gx = fwd_bwd()
+        sync()
+        fb_ms = (time.perf_counter() - t3) / k * 1e3
+        fb_bytes = 6.0 * N * H * e + 2.0 * B * H * e
+        assert gx.shape == data.shape
+        del gx
+        extra['fwd_bwd'] = {
+            'call': 'g = autograd.grad(reduce_sum(C(x, lens).pack()), x, ones): the timed pipeline plus its backward '
+                    '(rua_segment_reduce_backward over the PackedSequence, then the adjoint move P -> C)',
+            'ms_per_step': round(fb_ms, 4), 'steps': k, 'value': round(N * H / (fb_ms * 1e-3) / 1e6, 1), 'unit': 'M elements/s',
+            'algorithmic_bytes': fb_bytes,
+            'frac_of_hbm_peak_wall': round(fb_bytes / (fb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
     # the host side of a rank, with every other rank of the node live: the enqueue loop (Python + ctypes per step) and
@@ -476,6 +524,7 @@ def main():
                        'numa_node_of_rank0_gpu': _gpu_numa_node(dev),
                        'host_sort': os.environ.get('RUA_HOST_SORT', 'self-tuned'),
                        'host_sort_threads_rank0': _meta.host_sort_threads(),
+                       'host_sort_native': _meta.host_sort_is_native(),      # False: the self-test kept torch.sort
                        'backend': (os.environ.get('RUA_BENCH_BACKEND', 'nccl') + (' (RCCL)' if os.environ.get('RUA_BENCH_BACKEND', 'nccl') == 'nccl' else '')) if use_dist else None},
             'per_rank': [{'rank': r, 'rows': int(row[0]), 'ms_per_step': round(row[1] / args.steps * 1e3, 4),
                           'pack_kernel_GBps': round((2.0 * row[0] * H * e + 8.0 * (3 * B + T)) / (row[2] * 1e-3) / 1e9, 1) if row[2] else None,
@@ -497,6 +546,9 @@ def main():
                          'frac_of_hbm_peak_wall': round((pack_bytes + reduce_bytes) * world / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world, 4)},
         }
         line.update(extra)
+        if 'copy_ceiling' in extra:
+            line['roofline']['frac_of_copy_ceiling'] = round(achieved / extra['copy_ceiling']['GBps'], 4)
+            line['roofline']['copy_ceiling_GBps'] = extra['copy_ceiling']['GBps']
         if world == 1 and not args.no_cpu_baseline:
             line['parity'] = parity_leg(ta, data, lens_host, out_graded)
             line['cpu_baseline'] = cpu_baseline(args)

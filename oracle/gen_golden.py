@@ -8,6 +8,7 @@ Outputs:
     tests/golden/small.npz     every hot-path function on tiny + seeded random cases
     tests/golden/sha.json      SHA-256 of the reference's outputs on reduced BASELINE.json configs
     tests/golden/r4.npz        (--round4) scatter_* on integer tensors; names.json: dir() of the reference's modules
+    tests/golden/r5.npz        (--round5) 1-D / sub-16-byte rows and rows of 8 (mod 16) bytes through every layout function; integer scatter_logsumexp
     tests/golden/r3.npz        (--round3) compose, Z- / tensor-keyed indexing, split, and gradients of every op under
                                one fixed cotangent, from the reference's CPU autograd
 """
@@ -59,21 +60,26 @@ def put_seq(case, name, z):
         put(case, f'{name}.token_sizes', z.token_sizes)
 
 
-def layout_case(case, lens, H, dtype, seed):
-    """All layout / select functions for one batch."""
+def layout_case(case, lens, H, dtype, seed, small_ints=False):
+    """All layout / select functions for one batch.  small_ints (round 5): payload values are small integers whatever
+    the dtype (compressible fixtures for wide rows), and the narrow integer dtypes / bool get a fill of their own."""
     g = torch.Generator().manual_seed(seed)
     lens = torch.as_tensor(lens, dtype=torch.long)
     N = int(lens.sum())
     shape = (N,) if H == 0 else (N, H)
-    if dtype == torch.long:
+    fill = FILL if dtype != torch.long else -7
+    if dtype == torch.long and not small_ints:
         data = torch.randint(-1000, 1000, shape, generator=g)
+    elif small_ints or not dtype.is_floating_point:
+        data = torch.randint(0, 2 if dtype == torch.bool else 120, shape, generator=g).to(dtype)
+        if not dtype.is_floating_point:
+            fill = {torch.long: -7, torch.int32: -7, torch.int16: -7, torch.int8: -7, torch.uint8: 7, torch.bool: 1}[dtype]
     else:
         data = torch.randn(shape, generator=g).to(dtype)
     put(case, 'lens', lens)
     put(case, 'data', data)
-    put(case, 'fill', np.float64(FILL))
+    put(case, 'fill', np.float64(fill if (small_ints or not dtype.is_floating_point) and dtype != torch.long else FILL))
     c = C(data=data, token_sizes=lens)
-    fill = FILL if dtype != torch.long else -7
     seqs = {'C': c, 'L': c.left(fill), 'P': c.pack(), 'R': c.right(fill)}
     put(case, 'sorted_indices', seqs['P'].sorted_indices)
     for k, z in seqs.items():
@@ -113,8 +119,11 @@ def layout_case(case, lens, H, dtype, seed):
     bp, tp = b_all[pick], t_all[pick]
     put(case, 'key.batch', bp)
     put(case, 'key.token', tp)
-    value = (torch.randn((M,) + tuple(data.shape[1:]), generator=g).to(dtype) if dtype != torch.long
-             else torch.randint(-50, 50, (M,) + tuple(data.shape[1:]), generator=g))
+    if dtype.is_floating_point:
+        value = torch.randn((M,) + tuple(data.shape[1:]), generator=g).to(dtype)
+    else:
+        value = torch.randint(0 if dtype in (torch.uint8, torch.bool) else -50, 2 if dtype == torch.bool else 50,
+                              (M,) + tuple(data.shape[1:]), generator=g).to(dtype)
     put(case, 'key.value', value)
     for k, z in seqs.items():
         put(case, f'getitem.{k}', z[bp, tp])
@@ -844,8 +853,63 @@ def round4():
     print('wrote', len(store), 'round-4 arrays;', os.path.getsize(os.path.join(OUT, 'r4.npz')), 'bytes')
 
 
+def scatter_lse_int_case(case, S, M, H, dtype, seed, lo, hi):
+    """scatter_logsumexp on INTEGER tensors (reduce.py:26-31): the reference answers in float32 — the differences are
+    taken in the integer type (they wrap there, e.g. for int8 values far apart), `.exp()` promotes."""
+    g = torch.Generator().manual_seed(seed)
+    index = torch.randint(0, S, (M,), generator=g)
+    if S > 3:
+        index[index == 1] = 0
+    tensor = torch.randint(lo, hi + 1, (S, H) if H else (S,), generator=g).to(dtype)
+    source = torch.randint(lo, hi + 1, (M, H) if H else (M,), generator=g).to(dtype)
+    put(case, 'index', index)
+    put(case, 'tensor', tensor)
+    put(case, 'source', source)
+    for inc in (False, True):
+        put(case, f'scatter_logsumexp.{int(inc)}', ref.scatter_logsumexp(tensor, index, source, include_self=inc))
+
+
+def round5():
+    """tests/golden/r5.npz (earlier files stay byte-for-byte): VERDICT r4 — 1-D payloads whose ROWS are 1 / 2 / 4 / 8
+    bytes wide (bool masks, int16, fp32 scalars, int64 token ids) and rows of 8 / 4 / 2 (mod 16) bytes at sizes that fill
+    several tiles of the movers, through every layout / select function (`layout.r5.*`: picked up by every test that
+    walks the `layout.` cases); integer scatter_logsumexp."""
+    global store
+    store = {}
+    rng = np.random.RandomState(5)
+    I = torch
+    narrow = [('u8', I.uint8), ('bool', I.bool), ('i16', I.int16), ('f16', I.float16), ('i32', I.int32), ('f32', I.float32),
+              ('i64', I.int64)]
+    for i, (name, dtype) in enumerate(narrow):
+        layout_case(f'layout.r5.vec.{name}', rng.randint(1, 48, 70), 0, dtype, seed=700 + i, small_ints=True)
+    layout_case('layout.r5.vec.i64.long', np.concatenate([rng.randint(1, 12, 60), [700, 333]]), 0, I.int64, seed=710, small_ints=True)
+    layout_case('layout.r5.vec.u8.singletons', np.ones(300, dtype=np.int64), 0, I.uint8, seed=711, small_ints=True)
+    layout_case('layout.r5.row8', rng.randint(1, 40, 40), 4, I.bfloat16, seed=712, small_ints=True)      # 8-byte rows, 2-d
+    layout_case('layout.r5.row4', rng.randint(1, 40, 40), 2, I.float16, seed=713, small_ints=True)
+    layout_case('layout.r5.row2', rng.randint(1, 40, 40), 2, I.uint8, seed=714, small_ints=True)
+    # rows of 8, 4 and 2 (mod 16) bytes: H = 500 bf16 (1 000 bytes), H = 125 fp32 (500), H = 9 bf16 (18), H = 1 000 bf16
+    layout_case('layout.r5.odd1000', rng.randint(1, 7, 6), 500, I.bfloat16, seed=720, small_ints=True)
+    layout_case('layout.r5.odd500', rng.randint(1, 9, 8), 125, I.float32, seed=721, small_ints=True)
+    layout_case('layout.r5.odd18', rng.randint(1, 30, 30), 9, I.bfloat16, seed=722, small_ints=True)
+    layout_case('layout.r5.odd2000', rng.randint(1, 5, 4), 1000, I.bfloat16, seed=723, small_ints=True)
+    scatter_lse_int_case('scatter_lse_int.i64', 9, 60, 3, I.int64, seed=730, lo=-9, hi=9)
+    scatter_lse_int_case('scatter_lse_int.i64.big', 5, 40, 2, I.int64, seed=731, lo=-(2 ** 40), hi=2 ** 40)
+    scatter_lse_int_case('scatter_lse_int.i32', 8, 50, 5, I.int32, seed=732, lo=-30, hi=30)
+    scatter_lse_int_case('scatter_lse_int.i16', 10, 80, 0, I.int16, seed=733, lo=-40, hi=40)
+    scatter_lse_int_case('scatter_lse_int.i8', 6, 70, 3, I.int8, seed=734, lo=-128, hi=127)       # differences wrap
+    np.savez_compressed(os.path.join(OUT, 'r5.npz'), **store)
+    meta_path = os.path.join(OUT, 'META.json')
+    meta = json.load(open(meta_path))
+    meta['r5_n_arrays'] = len(store)
+    with open(meta_path, 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print('wrote', len(store), 'round-5 arrays;', os.path.getsize(os.path.join(OUT, 'r5.npz')), 'bytes')
+
+
 if __name__ == '__main__':
-    if '--round4' in sys.argv:
+    if '--round5' in sys.argv:
+        round5()
+    elif '--round4' in sys.argv:
         round4()
     elif '--round3' in sys.argv:
         round3()
@@ -859,3 +923,4 @@ if __name__ == '__main__':
         foreign()
         round3()
         round4()
+        round5()

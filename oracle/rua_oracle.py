@@ -516,7 +516,15 @@ def scatter_prod(tensor, index, source, include_self=False):
 
 
 def scatter_logsumexp(tensor, index, source, include_self=False):
-    """reduce.py:26-31."""
+    """reduce.py:26-31.  Integer tensors: the maximum and both differences are taken IN THE INTEGER TYPE (they wrap
+    there, as torch's do), `.exp()` promotes to float32, and so does `+ m` at the end."""
+    if np.asarray(tensor).dtype in _INT_KINDS:
+        tensor, source = np.asarray(tensor), np.asarray(source, dtype=np.asarray(tensor).dtype)
+        m = scatter_max(tensor, index, source, include_self)
+        with np.errstate(all='ignore'):
+            t = np.exp((tensor - m).astype(np.float32))              # (numpy integer subtraction wraps like torch's)
+            s = np.exp((source - m[_i64(index)]).astype(np.float32))
+            return np.log(scatter_sum(t, index, s, include_self)) + m.astype(np.float32)
     tensor = np.asarray(tensor, dtype=np.float32)
     source = np.asarray(source, dtype=np.float32)
     m = scatter_max(tensor, index, source, include_self)

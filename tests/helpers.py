@@ -22,13 +22,26 @@ def golden():
     global _small
     if _small is None:
         out = {}
-        for fname in ('small.npz', 'extra.npz', 'foreign.npz', 'r3.npz', 'r4.npz'):   # oracle/gen_golden.py: main / extra / foreign / round3 / round4
+        for fname in ('small.npz', 'extra.npz', 'foreign.npz', 'r3.npz', 'r4.npz', 'r5.npz'):   # oracle/gen_golden.py: main / extra / foreign / round3 / round4 / round5
             z = np.load(os.path.join(GOLDEN, fname))
             for key in z.files:
                 case, name = key.split('/', 1)
                 out.setdefault(case, {})[name] = z[key]
         _small = out
     return _small
+
+
+def fill_of(fields):
+    """The fill value a `layout.*` fixture was padded with (oracle/gen_golden.py: layout_case): -1.5 for floating
+    payloads, -7 for signed integers, and — round 5 — what the case stored for uint8 (7) and bool (True)."""
+    dt = fields['data'].dtype
+    if dt.kind == 'i':
+        return -7
+    if dt.kind == 'u' and dt.itemsize == 1:
+        return int(fields['fill'])
+    if dt.kind == 'b':
+        return bool(fields['fill'])
+    return float(fields['fill'])
 
 
 def cotangent(shape, salt=0) -> np.ndarray:

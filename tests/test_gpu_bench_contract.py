@@ -33,6 +33,13 @@ def test_bench_json_line():
     dl = d['device_lens']                             # the reference-signature call, first class with its own fraction
     assert dl['value'] > 0 and 0 < dl['frac_of_hbm_peak_wall'] < 1 and d['value_device_lens'] == dl['value']
     assert 'traffic_source' in r and d['config']['ranks_reported_by_process_group'] == 1
+    # [r5] self-normalising and self-describing: the same-process copy ceiling, the sort in use, the reference-signature
+    # number at top level, and a forward + backward leg with its own bytes
+    assert d['value_reference_signature'] == dl['value'] and isinstance(d['config']['host_sort_native'], bool)
+    cc = d['copy_ceiling']
+    assert cc['ms'] > 0 and abs(r['frac_of_copy_ceiling'] - r['achieved'] / cc['GBps']) < 1e-3
+    fb = d['fwd_bwd']
+    assert fb['ms_per_step'] > 0 and fb['value'] > 0 and fb['algorithmic_bytes'] > d['pipeline']['algorithmic_bytes']
     assert d['value'] > 0 and d['ms_per_step'] > 0
 
 
@@ -112,6 +119,10 @@ def test_bench_legs_are_sane_at_the_north_star_shape():
     on_dev = d['device_lens']['produced_on_device']            # lengths a previous kernel left on the device
     assert on_dev['ms_per_step'] <= 1.4 * kernels and 0.6 <= on_dev['frac_of_hbm_peak_wall'] < 1
     assert d['roofline']['frac'] >= 0.6 and d['pipeline']['frac_of_hbm_peak_wall'] >= 0.6
+    assert 0.85 <= d['roofline']['frac_of_copy_ceiling'] <= 1.1, d['roofline']      # the gather costs a few % of a plain copy
+    assert d['config']['host_sort_native'] is True
+    fb = d['fwd_bwd']                                          # forward + backward: twice the passes, the same rate class
+    assert fb['frac_of_hbm_peak_wall'] >= 0.55 and fb['ms_per_step'] <= 2.6 * d['ms_per_step'], fb
     par = d['parity']
     assert par['max_exact'] is True and par['sum_f32_vs_fp64_over_sum_abs'] <= 1e-5
     assert par['logsumexp_f32_vs_reference_max_rel'] <= 1e-5 and par['pipeline_bf16_sum_vs_exact_rounded_to_bf16_max_ulps'] <= 1

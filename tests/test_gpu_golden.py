@@ -6,7 +6,7 @@ import torch
 
 import torchrua_amd as ta
 from gpu_util import DEV, assert_same_seq, dev_seq
-from helpers import cases, golden, orc, seq_from, to_np, to_torch
+from helpers import cases, fill_of, golden, orc, seq_from, to_np, to_torch
 
 pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-5, 1e-5   # north_star: float reductions within 1e-5 relative of the reference
@@ -37,9 +37,7 @@ def _bf16(f):
 
 
 def _fill(f):
-    if f['data'].dtype.kind == 'i':
-        return -7
-    return float(f['fill'])
+    return fill_of(f)
 
 
 def _inputs(f):

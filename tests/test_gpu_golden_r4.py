@@ -160,8 +160,9 @@ def test_integer_scatter_rejects_what_it_cannot_do():
     ten = torch.zeros(4, 2, dtype=torch.long, device=DEV)
     idx = torch.tensor([0, 1], device=DEV)
     src = torch.ones(2, 2, dtype=torch.long, device=DEV)
+    assert ta.scatter_logsumexp(ten, idx, src).dtype == torch.float32      # [r5] answers like the reference (test_gpu_golden_r5.py)
     with pytest.raises(ta.RuaError):
-        ta.scatter_logsumexp(ten, idx, src)
+        ta.scatter_logsumexp(ten.to(torch.uint8), idx, src.to(torch.uint8))   # the reference's own differences wrap: inf
     with pytest.raises(ta.RuaError):
         ta.scatter_sum(ten, idx, src.int())                       # dtype mismatch, as torch
     with pytest.raises(ta.RuaError):

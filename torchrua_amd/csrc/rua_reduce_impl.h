@@ -1102,6 +1102,12 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_walk_kernel(rua_layout 
   }
 }
 
+// [r5] Measured and NOT kept: the same backward on (rank x time) tiles — sixteen neighbouring ranks x 8 / 32 / 64 time
+// steps per workgroup, the sixteen sequences' rows fetched once into LDS, then runs of sixteen consecutive storage rows
+// swept step by step — i.e. the PackedSequence in its own storage order.  In-process A/B at the north-star shape
+// (profiles/r05_backward_ab_tiles.txt): sum 3.25-3.33 ms against the walk's 3.25, max 7.8-8.5 against 6.8, logsumexp
+// 7.3-7.6 against 6.8, with or without a span of tiles per XCD.  Sweeping the storage row by row with the sequence's rows
+// gathered per row (the mover's ZERO map) writes at 3.0 TB/s.  The walk stays.
 // backward over a PackedSequence with narrow rows: adjacent ranks side by side (see seg_reduce_ranks_kernel)
 template <typename T, int EPL, int OP, int TIES>
 __global__ __launch_bounds__(RUA_WAVE) void seg_backward_ranks_kernel(rua_layout L, const T* __restrict__ data,
@@ -1233,113 +1239,114 @@ __global__ __launch_bounds__(RUA_BLOCK) void seg_backward_rows_kernel(rua_layout
       *reinterpret_cast<Pack*>(gt + off) = v;
     }
   };
-  for (int g0 = wave * UB; g0 * rpw < nrows; g0 += RUA_WAVES_PER_BLOCK * UB) {
+  // a unit = (block of UB consecutive row groups, 64-lane column chunk): one per wave at rows up to 1 KiB; at wider rows
+  // the waves of a workgroup take the CHUNKS of the same few rows (a 4-row tile of 4-KiB rows: wave w streams chunk w of
+  // all four rows), so every wave still has UB loads in flight and holds ONE chunk of the sequence's rows
+  const int nblocks = (nrows + UB * rpw - 1) / (UB * rpw);
+  for (int unit = wave; unit < nblocks * cpr; unit += RUA_WAVES_PER_BLOCK) {
+    const int blk = cpr == 1 ? unit : unit / cpr, c = unit - blk * cpr;
+    const int g0 = blk * UB;
     const int rA = g0 * rpw;
     const int rB = (rA + UB * rpw < nrows ? rA + UB * rpw : nrows) - 1;
     const int64_t bA = s_b[rA], bB = s_b[rB];
-    if (bA == bB && bA >= 0) {                           // wave-uniform: every row of the wave is a token of sequence bA
+    const int col = col0 + c * RUA_WAVE * EPL;
+    const bool colok = col < Hi;
+    if (bA == bB && bA >= 0) {                           // wave-uniform: every row of the block is a token of sequence bA
       const int64_t bs = ((int64_t)__builtin_amdgcn_readfirstlane((int)(bA >> 32)) << 32) |
                          (uint32_t)__builtin_amdgcn_readfirstlane((int)bA);
       const T* __restrict__ gs = gout + bs * H;
       const T* __restrict__ os = out + bs * H;
       A scale = (A)1;
       if (OP == RUA_MEAN) scale = s_scale[rA];
-      for (int c = 0; c < cpr; ++c) {
-        const int col = col0 + c * RUA_WAVE * EPL;
-        const bool colok = col < Hi;
-        Pack px[UB];
-        unsigned off[UB];
-        bool ok[UB];
+      Pack px[UB];
+      unsigned off[UB];
+      bool ok[UB];
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          const int r = (g0 + u) * rpw + rsub;
-          ok[u] = colok && r < nrows;
-          off[u] = (unsigned)(r * Hi + col);
-          if (need_x && ok[u]) px[u] = load_x(off[u]);
-        }
-        if (!colok) continue;
-        const Pack pg = *reinterpret_cast<const Pack*>(gs + col);
-        A f[EPL], o[EPL];                                // f: what a hit (max / min), or every element, receives
+      for (int u = 0; u < UB; ++u) {
+        const int r = (g0 + u) * rpw + rsub;
+        ok[u] = colok && r < nrows;
+        off[u] = (unsigned)(r * Hi + col);
+        if (need_x && ok[u]) px[u] = load_x(off[u]);
+      }
+      if (!colok) continue;
+      const Pack pg = *reinterpret_cast<const Pack*>(gs + col);
+      A f[EPL], o[EPL];                                // f: what a hit (max / min), or every element, receives
+      if (need_x) {
+        const Pack po = *reinterpret_cast<const Pack*>(os + col);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[e] = elem<T>::up(po.v[e]);
+      }
+      if (is_ext) {
+        const Cnt pc = *reinterpret_cast<const Cnt*>(ties + bs * H + col);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) f[e] = tie_share(elem<T>::up(pg.v[e]), (A)pc.v[e], tie_rule != 0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) f[e] = elem<T>::up(pg.v[e]) * scale;
+      }
+      if (OP == RUA_LOGSUMEXP) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[e] = exp_shift(o[e]);
+      }
+      Pack rs;
+      if (!need_x) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) rs.v[e] = OP == RUA_SUM ? pg.v[e] : elem<T>::down(f[e]);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        if (!ok[u]) continue;
         if (need_x) {
-          const Pack po = *reinterpret_cast<const Pack*>(os + col);
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) o[e] = elem<T>::up(po.v[e]);
-        }
-        if (is_ext) {
-          const Cnt pc = *reinterpret_cast<const Cnt*>(ties + bs * H + col);
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) f[e] = tie_share(elem<T>::up(pg.v[e]), (A)pc.v[e], tie_rule != 0);
-        } else {
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) f[e] = elem<T>::up(pg.v[e]) * scale;
-        }
-        if (OP == RUA_LOGSUMEXP) {
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) o[e] = exp_shift(o[e]);
-        }
-        Pack rs;
-        if (!need_x) {
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) rs.v[e] = OP == RUA_SUM ? pg.v[e] : elem<T>::down(f[e]);
-        }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          if (!ok[u]) continue;
-          if (need_x) {
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-              const A x = elem<T>::up(px[u].v[e]);
-              A gi;
-              if (OP == RUA_LOGSUMEXP) gi = f[e] * exp_shifted(x, o[e]);
-              else gi = ((x == o[e]) || (x != x && o[e] != o[e])) ? f[e] : (A)0;
-              rs.v[e] = elem<T>::down(gi);
-            }
+          for (int e = 0; e < EPL; ++e) {
+            const A x = elem<T>::up(px[u].v[e]);
+            A gi;
+            if (OP == RUA_LOGSUMEXP) gi = f[e] * exp_shifted(x, o[e]);
+            else gi = ((x == o[e]) || (x != x && o[e] != o[e])) ? f[e] : (A)0;
+            rs.v[e] = elem<T>::down(gi);
           }
-          store_g(off[u], rs);
         }
+        store_g(off[u], rs);
       }
       continue;
     }
-    // a sequence boundary (or padding rows) inside the wave's rows: one row group at a time
+    // a sequence boundary (or padding rows) inside the block's rows: one row group at a time
+    if (!colok) continue;
 #pragma unroll 1
     for (int u = 0; u < UB; ++u) {
       const int r = (g0 + u) * rpw + rsub;
       if (r >= nrows) continue;
       const int64_t b = s_b[r];
-      for (int c = 0; c < cpr; ++c) {
-        const int col = col0 + c * RUA_WAVE * EPL;
-        if (col >= Hi) continue;
-        const unsigned off = (unsigned)(r * Hi + col);
-        Pack rs;
-        if (b < 0) {
+      const unsigned off = (unsigned)(r * Hi + col);
+      Pack rs;
+      if (b < 0) {
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) rs.v[e] = elem<T>::down((A)0);
-        } else {
-          Pack px;
-          if (need_x) px = load_x(off);
-          const Pack pg = *reinterpret_cast<const Pack*>(gout + b * H + col);
-          Pack po;
-          Cnt pc;
-          if (need_x) po = *reinterpret_cast<const Pack*>(out + b * H + col);
-          if (is_ext) pc = *reinterpret_cast<const Cnt*>(ties + b * H + col);
-          A scale = (A)1;
-          if (OP == RUA_MEAN) scale = s_scale[r];
+        for (int e = 0; e < EPL; ++e) rs.v[e] = elem<T>::down((A)0);
+      } else {
+        Pack px;
+        if (need_x) px = load_x(off);
+        const Pack pg = *reinterpret_cast<const Pack*>(gout + b * H + col);
+        Pack po;
+        Cnt pc;
+        if (need_x) po = *reinterpret_cast<const Pack*>(out + b * H + col);
+        if (is_ext) pc = *reinterpret_cast<const Cnt*>(ties + b * H + col);
+        A scale = (A)1;
+        if (OP == RUA_MEAN) scale = s_scale[r];
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) {
-            const A g = elem<T>::up(pg.v[e]);
-            A gi;
-            if (OP == RUA_SUM) gi = g;
-            else if (OP == RUA_MEAN) gi = g * scale;
-            else {
-              const A x = elem<T>::up(px.v[e]), o = elem<T>::up(po.v[e]);
-              if (OP == RUA_LOGSUMEXP) gi = g * exp_shifted(x, exp_shift(o));
-              else gi = ((x == o) || (x != x && o != o)) ? tie_share(g, (A)pc.v[e], tie_rule != 0) : (A)0;
-            }
-            rs.v[e] = elem<T>::down(gi);
+        for (int e = 0; e < EPL; ++e) {
+          const A g = elem<T>::up(pg.v[e]);
+          A gi;
+          if (OP == RUA_SUM) gi = g;
+          else if (OP == RUA_MEAN) gi = g * scale;
+          else {
+            const A x = elem<T>::up(px.v[e]), o = elem<T>::up(po.v[e]);
+            if (OP == RUA_LOGSUMEXP) gi = g * exp_shifted(x, exp_shift(o));
+            else gi = ((x == o) || (x != x && o != o)) ? tie_share(g, (A)pc.v[e], tie_rule != 0) : (A)0;
           }
+          rs.v[e] = elem<T>::down(gi);
         }
-        store_g(off, rs);
       }
+      store_g(off, rs);
     }
   }
 }
@@ -1915,7 +1922,8 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
   // three rows to fetch — measured 3.4 TB/s for sum over P against 6.0 for the walk, which loads them once per sequence
   // (ops that read x: rows up to 1 KiB — one wave instruction per row; wider rows leave a wave one row of a 4-row
   // tile and the walk's 4.4 TB/s beats 3.5)
-  const bool rows_width_ok = (op == RUA_SUM || op == RUA_MEAN) ? true : n_chunks == 1;
+  // ([r5] every width: at rows wider than 1 KiB the waves of a workgroup take the column chunks of the same few rows)
+  const bool rows_width_ok = true;
   const int tie_rule = extra_count & BWD_TIES_POSITIVE;
   if (vec_ok && !perm && !self_in && !(extra_count & BWD_SELF_COUNTS) && rows_op && rows_width_ok && L.kind != RUA_PACK &&
       H * (int64_t)sizeof(T) >= 64) {

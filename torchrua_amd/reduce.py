@@ -259,9 +259,18 @@ def _scatter_int(tensor: T, index: T, source: T, op: int, include_self: bool) ->
     (reduce.py:6-23).  Same buckets, an integer reducer (rua_reduce_int.hip): the element type's own wrapping sums and
     products, and ATen's floor division by a count of that type for `mean`.  Bit-exact; integers carry no gradient."""
     if op == K.LOGSUMEXP:
-        # reduce.py:26-31 on integers is a float computation (exp of a difference that wraps for unsigned types);
-        # torch.logsumexp itself takes floating tensors only
-        raise K.RuaError('scatter_logsumexp takes floating-point tensors (got ' + str(tensor.dtype) + ')')
+        # reduce.py:26-31 on integers: the maximum and the two differences are taken in the integer type, `.exp()`
+        # promotes to float32 and the result is float32.  [r5] The same composition over this library's own scatter_max
+        # (integer kernel, bit-exact) and scatter_sum (float kernel); the four elementwise steps on [S, H] / [M, H] are
+        # torch's, as in the reference.  For uint8 the differences wrap to 256 - d and the reference's own answer is
+        # inf wherever a bucket holds two different values (tests/golden/META.json): that stays an error here.
+        if tensor.dtype == torch.uint8:
+            raise K.RuaError('scatter_logsumexp of uint8 tensors: the reference\'s differences wrap (its result is inf); '
+                             'convert to a signed or floating type')
+        m = _scatter_int(tensor, index, source, K.MAX, include_self)
+        t = (tensor - m).exp()
+        s = (source - m.index_select(0, index.long())).exp()
+        return _Scatter.apply(t, index, s, K.SUM, include_self).log() + m
     S = tensor.size(0)
     counts, perm = _buckets(index, S)
     lay = M.lay_cat(counts, S, int(source.size(0)))
