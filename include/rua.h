@@ -102,6 +102,7 @@ enum rua_tmap {
 #define RUA_MOVE_XCD_SPAN_ON  256  /* every XCD takes ONE contiguous span of tiles (blockIdx % 8 picks the span) */
 #define RUA_MOVE_XCD_SPAN_OFF 512  /* tiles in plain blockIdx order                                             */
 #define RUA_MOVE_NO_TAIL8 1024     /* rows of 8 (mod 16) bytes: keep 8-byte lanes instead of 16-byte lanes + an 8-byte tail */
+#define RUA_MOVE_NO_NARROW 2048    /* rows of one vector (1 .. 16 bytes): the generic kernel instead of the lane-per-row one */
 
 /* K1. Exclusive prefix sum of n int64 (wavefront scan).  out[i] = sum(in[0..i)).
  * `ws` must hold rua_scan_ws_elems(n) int64.  If total != NULL, *total (device) = sum(in).

@@ -24,6 +24,7 @@ BWD_FILL_PADDING = 0x100   # ... OR-ed in: the call itself zeroes the padding ro
 BWD_TIES_POSITIVE = 0x200  # ... OR-ed in (max/min): torch.segment_reduce's tie rule — ties share g only where g > 0
 MOVE_SCATTER = 1
 MOVE_NT_ON, MOVE_NT_OFF = 2, 4       # rua.h: force / forbid non-temporal payload accesses
+MOVE_NO_NARROW = 2048               # rua.h: developer A/B — rows of one vector through the generic kernel
 OP_SCRATCH_CLEAN, OP_NO_EMPTY = 0x100, 0x200     # rua.h: bits OR-ed into `op` (persistent zeroed extreme scratch)
 OP_SHORT_SEQS = 0x400      # rua.h: a CattedSequence of short sequences, none far above the average (a hint)
 # enum rua_dtype / rua_op

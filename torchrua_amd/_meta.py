@@ -460,8 +460,17 @@ TILE_MIN_LIVE_INV = 4       # ... when at least one cell in this many is a live 
 
 
 def tile_shape_log2(row_bytes: int) -> Tuple[int, int]:
-    """(log2 time steps, log2 ranks) of a (rank x time) tile by row width (rua_move.hip: pack_tile_lds_kernel)."""
+    """(log2 time steps, log2 ranks) of a (rank x time) tile by row width (rua_move.hip: pack_tile_lds_kernel).  [r5] Rows
+    of ONE vector below 16 bytes — 1-D payloads of 8 / 4 / 2 / 1-byte elements — get more ranks (and steps) per tile, so
+    that a tile still carries 16 KiB and both sides still move runs of 128 .. 512 bytes: 32 x 64, 64 x 64, 64 x 128,
+    128 x 128.  (The kernel falls back to the row mover when the payload's address is less aligned than its rows.)"""
+    narrow = {8: (6, 5), 4: (6, 6), 2: (7, 6), 1: (7, 7)}.get(row_bytes)
+    if narrow is not None:
+        return narrow
     return (6 if row_bytes <= 16 else 5 if row_bytes <= 32 else 4), 4
+
+
+TILE_FULL_GRID = 1 << 24      # rua_layout::tile_t_log2: the tiles cover the whole (sequence x step) grid of a padded destination
 
 
 def tile_line_rows(row_bytes: int) -> int:
@@ -505,7 +514,8 @@ def pack_tiling(p, ttl: int, trl: int, line_rows: int = 1) -> 'PackTiling':
 
 
 def lay_pack(p, lens: Optional[Tensor] = None, len_add: int = 0, boff: Optional[Tensor] = None,
-             T: Optional[int] = None, n_rows: Optional[int] = None, row_bytes: Optional[int] = None) -> Lay:
+             T: Optional[int] = None, n_rows: Optional[int] = None, row_bytes: Optional[int] = None,
+             full_grid_T: Optional[int] = None) -> Lay:
     lens = pack_lens(p) if lens is None else _as_lens(lens)
     boff = pack_boff(p) if boff is None else boff
     T = p.batch_sizes.numel() if T is None else T
@@ -516,7 +526,16 @@ def lay_pack(p, lens: Optional[Tensor] = None, len_add: int = 0, boff: Optional[
         bsz = pack_bsz_dev(p)
         keep.append(bsz)
         extra['bsz'] = L.ptr(bsz)
-    if row_bytes is not None and 0 < row_bytes <= NARROW_ROW_BYTES and T == p.batch_sizes.numel() and len_add == 0:
+    if (full_grid_T is not None and row_bytes is not None and 0 < row_bytes <= NARROW_ROW_BYTES
+            and T == p.batch_sizes.numel() and len_add == 0 and T > 0):
+        # [r5] the SOURCE of a pad at narrow rows (P.left() / P.right()): tiles over the destination's whole
+        # (sequence x step) grid — tokens and fill in one pass; no table: every chunk holds ceil(B / ranks per tile) tiles
+        ttl, trl = tile_shape_log2(row_bytes)
+        nseq = pack_nseq(p)
+        n_tchunks = (max(full_grid_T, T) + (1 << ttl) - 1) >> ttl
+        extra.update(n_tchunks=n_tchunks, n_tiles=n_tchunks * ((nseq + (1 << trl) - 1) >> trl),
+                     tile_t_log2=ttl | (trl << 8) | TILE_FULL_GRID)
+    elif row_bytes is not None and 0 < row_bytes <= NARROW_ROW_BYTES and T == p.batch_sizes.numel() and len_add == 0:
         ttl, trl = tile_shape_log2(row_bytes)
         t = pack_tiling(p, ttl, trl, tile_line_rows(row_bytes))       # narrow rows: hand the (rank x time) tile table to the mover ...
         # ... unless the tiles would be mostly dead cells: one giant sequence among short ones (its tail is one live rank

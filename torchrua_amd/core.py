@@ -227,7 +227,11 @@ def _to_padded(cls, kind):
         lens = lens_of(self)
         b, t = lens.numel(), self.size()[1]
         dst = M.lay_padded(kind, lens, b, t, t)
-        plan = O.MovePlan(dst, describe(self), (b, t) + _hidden(self), fill=fill_value,
+        src = describe(self)
+        if isinstance(self, P) and 0 < M.row_bytes(self.data, 1) <= M.NARROW_ROW_BYTES:
+            # narrow rows out of a PackedSequence: (rank x time) tiles over the destination's whole grid (tokens + fill)
+            src = M.lay_pack(self, row_bytes=M.row_bytes(self.data, 1), full_grid_T=t)
+        plan = O.MovePlan(dst, src, (b, t) + _hidden(self), fill=fill_value,
                           name='to_left' if kind == K.LEFT else 'to_right')
         return cls(data=O.move(self.data, plan), token_sizes=lens)
     return cast

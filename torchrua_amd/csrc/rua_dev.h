@@ -33,12 +33,20 @@ __device__ __forceinline__ int64_t cat_off(const rua_layout& L, int64_t b) {
   return (L.off ? L.off[b] : 0) + b * L.len_add;
 }
 
+// j / n for 0 <= j, 0 < n: a 64-bit division is ~150 VALU instructions on gfx950 (no hardware divider); row numbers and
+// row counts below 2^32 — every realistic storage — divide in 32 bits (~25).  One lane per ROW computes these, so at
+// narrow rows (a 1-D payload moves 8 bytes per row) the division was most of the kernel.
+__device__ __forceinline__ int64_t div_rows(int64_t j, int64_t n) {
+  if (((uint64_t)j | (uint64_t)n) >> 32) return j / n;
+  return (int64_t)((uint32_t)j / (uint32_t)n);
+}
+
 // largest b in [0, B) with cat_off(b) <= j   (requires cat_off(0) <= j)
 __device__ __forceinline__ int64_t search_cat(const rua_layout& L, int64_t j) {
   int64_t lo = 0, hi = L.B;
   if (!L.off) {  // constant length: closed form
     int64_t n = L.len_add;
-    return n > 0 ? j / n : 0;
+    return n > 0 ? div_rows(j, n) : 0;
   }
   while (hi - lo > 1) {
     int64_t mid = (lo + hi) >> 1;
@@ -72,11 +80,11 @@ __device__ __forceinline__ bool row_to_token(const rua_layout& D, int64_t j, int
       return b >= 0 && b < D.B;                     // a corrupt sorted_indices must not index out of range
     }
     case RUA_LEFT:
-      b = j / D.T_phys;
+      b = div_rows(j, D.T_phys);
       t = j - b * D.T_phys;
       return t < seq_len(D, b);
     case RUA_RIGHT: {
-      b = j / D.T_phys;
+      b = div_rows(j, D.T_phys);
       int64_t len = seq_len(D, b);
       t = (j - b * D.T_phys) - (D.T_log - len);
       return t >= 0 && t < len;
@@ -105,8 +113,13 @@ __device__ __forceinline__ int64_t apply_tmap(int32_t tmap, int64_t arg, int64_t
     case RUA_T_SHIFT: return t + arg;
     case RUA_T_ROLL: {
       if (slen <= 0) return -1;
-      int64_t m = (t - arg) % slen;   // C remainder: sign of dividend
-      return m < 0 ? m + slen : m;
+      int64_t m = t - arg;            // 0 <= t < slen: a shift shorter than the sequence wraps at most once
+      if (m < 0) m += slen; else if (m >= slen) m -= slen;
+      if (m < 0 || m >= slen) {       // |shift| >= length: the full remainder (C remainder: sign of dividend)
+        m = (t - arg) % slen;
+        if (m < 0) m += slen;
+      }
+      return m;
     }
     case RUA_T_REV_S: return slen - 1 - t;
     case RUA_T_REV_D: return dlen - 1 - t;

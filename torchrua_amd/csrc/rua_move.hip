@@ -41,6 +41,7 @@ constexpr int64_t TILE_SPAN_MIN_TILES_FROM_PACK = 1 << 18;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef u32x4 u32x4_a8 __attribute__((aligned(8)));     // a 16-byte piece that only sits on an 8-byte boundary
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));     // ... or on a 4-byte one (gfx950 takes a dwordx4 at any dword-aligned address)
 
 template <int VEC> struct vec_of;
 template <> struct vec_of<16> { using type = u32x4; };
@@ -80,6 +81,111 @@ template <bool NT> __device__ __forceinline__ u32x4 ld_row_a8(const char* p) {
 template <bool NT> __device__ __forceinline__ void st_row_a8(char* p, u32x4 v) {
   if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4_a8*>(p));
   else *reinterpret_cast<u32x4_a8*>(p) = v;
+}
+
+// The other side of the wave's enumerated rows: lane i holds enumerated row jw0 + i of `D` (i < nw; ALL 64 lanes must
+// call) and gets the row of `S` it maps to — the source row of a gather, the destination row of a scatter — or -1 (fill /
+// skip), or `pad_row` for a padding row of a padded destination.  The wave resolves its rows TOGETHER (coop_resolve).
+// `win` (may be NULL): a window of D's offsets computed ONCE for rows at or before jw0 (wave_window) — the narrow-row
+// kernel resolves 64 * CH consecutive rows per wave from one 64-ary search instead of CH.
+struct WaveWindow { int64_t lo, W; };
+__device__ __forceinline__ bool wave_window(const rua_layout& D, int64_t jw0, int lane1, WaveWindow& w) {
+  if (D.kind == RUA_PACK && D.T > 0 && D.boff) { coop_window([&](int64_t k) { return D.boff[k]; }, D.T, jw0, lane1, w.lo, w.W); return true; }
+  if (D.kind == RUA_CAT && D.off && D.B > 0) { coop_window([&](int64_t k) { return cat_off(D, k); }, D.B, jw0, lane1, w.lo, w.W); return true; }
+  return false;
+}
+template <bool SCATTER>
+__device__ __forceinline__ int64_t resolve_wave_rows(const rua_layout& D, const rua_layout& S, int32_t tmap, int64_t targ,
+                                                     int64_t pad_row, int64_t jw0, int nw, int lane1, bool same_pack,
+                                                     const WaveWindow* win = nullptr) {
+  const int64_t j = jw0 + lane1;
+  const bool mine = lane1 < nw;
+  int64_t b = 0, t = 0, other = -1;
+  bool token = false;
+  bool resolved = false;
+  bool done = false;
+  if (D.kind == RUA_PACK && D.T > 0 && D.boff) {
+    int64_t bt;
+    const bool ok = win ? coop_lookup(win->W, win->lo, D.T, j, t, bt)
+                        : coop_resolve([&](int64_t k) { return D.boff[k]; }, D.T, jw0, nw, lane1, t, bt);
+    if (same_pack) {
+      // roll / rev inside ONE PackedSequence: the rank r of a row is its own source rank, and its length is
+      // #{t : bsz[t] > r} — read off batch_sizes instead of two random gathers per row.  The wave looks its rows'
+      // lengths up TOGETHER (a 10-step binary search per row was the longest dependent chain of the tile: cfg4's
+      // P.roll, 2-KiB rows): -bsz is non-decreasing, len = 1 + the largest k with -bsz[k] <= -(r + 1); the rows
+      // of a wave are neighbouring ranks, whose lengths sit within one 64-entry window of the smallest of them.
+      constexpr int64_t BIG = 0x7fffffffffffffffLL;
+      const bool have = mine && ok && j - bt >= 0 && j - bt < D.bsz[0];
+      const int64_t r = have ? j - bt : 0;
+      const int64_t x = have ? -(r + 1) : BIG;
+      int64_t base = x;
+#pragma unroll
+      for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {
+        const int64_t o = __shfl_xor(base, d, RUA_WAVE);
+        base = o < base ? o : base;
+      }
+      int64_t wlo = 0, W = BIG, k = 0, fk = 0;
+      bool hit = false;
+      if (base != BIG) {                                          // wave-uniform
+        coop_window([&](int64_t q) { return -D.bsz[q]; }, D.T, base, lane1, wlo, W);
+        hit = coop_lookup(W, wlo, D.T, x, k, fk);
+      }
+      if (mine && ok) {
+        resolved = true;
+        int64_t len = 0;
+        if (have) {
+          if (hit && fk <= x) {
+            len = k + 1;
+          } else {                                                // the window did not reach: search alone
+            int64_t lo = 0, hi = D.T;
+            while (lo < hi) {
+              const int64_t mid = (lo + hi) >> 1;
+              if (D.bsz[mid] > r) lo = mid + 1; else hi = mid;
+            }
+            len = lo;
+          }
+        }
+        const int64_t ts = apply_tmap(tmap, targ, t, len, len);
+        if (have && ts >= 0 && ts < len) other = S.boff[ts] + r;
+        if (other >= S.n_rows) other = -1;
+        done = true;
+      }
+    } else if (mine && ok) {
+      resolved = true;
+      const int64_t r = j - bt;
+      if (r >= 0 && r < D.B) {
+        b = D.sorted ? D.sorted[r] : r;
+        token = b >= 0 && b < D.B;
+      }
+    }
+  } else if (D.kind == RUA_CAT && D.off && D.B > 0) {
+    int64_t ob;
+    const bool ok = win ? coop_lookup(win->W, win->lo, D.B, j, b, ob)
+                        : coop_resolve([&](int64_t k) { return cat_off(D, k); }, D.B, jw0, nw, lane1, b, ob);
+    if (mine && ok) { resolved = true; token = true; t = j - ob; }
+  }
+  if (mine && !done) {
+    if (!resolved) token = row_to_token(D, j, b, t);
+    if (token) {
+      // caller-supplied (batch_ptr, token_ptr) pairs are range-checked: a bad pair yields the fill /
+      // is skipped instead of faulting the GPU (the reference raises an IndexError there)
+      if (D.kind == RUA_LIST) {
+        if (!D.bptr) { if (t < 0) t += S.n_rows; }        // a flat row list wraps negatives like torch's indexing
+        else if (b < 0 || b >= S.B) { b = 0; t = -1; }
+      }
+      const int64_t slen = seq_len(S, b);
+      const int64_t dlen = D.kind == RUA_LIST ? slen : seq_len(D, b);
+      const int64_t ts = apply_tmap(tmap, targ, t, slen, dlen);
+      if (ts >= 0 && ts < slen) other = token_to_row(S, b, ts, slen);
+      // metadata that does not match the storage (lengths summing past the payload, a corrupt
+      // PackedSequence) must not become an out-of-bounds access: such rows read as padding
+      if (other >= S.n_rows) other = -1;
+    } else {
+      other = pad_row;  // padding row: fill (-1) or a copy of one fixed source row
+    }
+  }
+  (void)SCATTER;
+  return mine ? other : -1;
 }
 
 // lpr      : lanes (VEC-byte columns) per row = ceil(row_bytes / VEC)
@@ -164,91 +270,9 @@ __global__ __launch_bounds__(BLOCK) void move_rows_kernel(rua_layout D, rua_layo
     const int w0 = i - lane1;                                     // first tile row of this wave
     const int nw = nrows - w0 < RUA_WAVE ? nrows - w0 : RUA_WAVE; // rows in this wave (<= 0: none)
     if (nw > 0) {                                                 // wave-uniform
-      const int64_t j = tile0 + i;
-      const bool mine = i < nrows;
-      int64_t b = 0, t = 0, other = -1;
-      bool token = false;
-      bool resolved = false;
-      bool done = false;
-      if (D.kind == RUA_PACK && D.T > 0 && D.boff) {
-        int64_t bt;
-        const bool ok = coop_resolve([&](int64_t k) { return D.boff[k]; }, D.T, tile0 + w0, nw, lane1, t, bt);
-        if (same_pack) {
-          // roll / rev inside ONE PackedSequence: the rank r of a row is its own source rank, and its length is
-          // #{t : bsz[t] > r} — read off batch_sizes instead of two random gathers per row.  The wave looks its rows'
-          // lengths up TOGETHER (a 10-step binary search per row was the longest dependent chain of the tile: cfg4's
-          // P.roll, 2-KiB rows): -bsz is non-decreasing, len = 1 + the largest k with -bsz[k] <= -(r + 1); the rows
-          // of a wave are neighbouring ranks, whose lengths sit within one 64-entry window of the smallest of them.
-          constexpr int64_t BIG = 0x7fffffffffffffffLL;
-          const bool have = mine && ok && j - bt >= 0 && j - bt < D.bsz[0];
-          const int64_t r = have ? j - bt : 0;
-          const int64_t x = have ? -(r + 1) : BIG;
-          int64_t base = x;
-#pragma unroll
-          for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {
-            const int64_t o = __shfl_xor(base, d, RUA_WAVE);
-            base = o < base ? o : base;
-          }
-          int64_t wlo = 0, W = BIG, k = 0, fk = 0;
-          bool hit = false;
-          if (base != BIG) {                                          // wave-uniform
-            coop_window([&](int64_t q) { return -D.bsz[q]; }, D.T, base, lane1, wlo, W);
-            hit = coop_lookup(W, wlo, D.T, x, k, fk);
-          }
-          if (mine && ok) {
-            resolved = true;
-            int64_t len = 0;
-            if (have) {
-              if (hit && fk <= x) {
-                len = k + 1;
-              } else {                                                // the window did not reach: search alone
-                int64_t lo = 0, hi = D.T;
-                while (lo < hi) {
-                  const int64_t mid = (lo + hi) >> 1;
-                  if (D.bsz[mid] > r) lo = mid + 1; else hi = mid;
-                }
-                len = lo;
-              }
-            }
-            const int64_t ts = apply_tmap(tmap, targ, t, len, len);
-            if (have && ts >= 0 && ts < len) other = S.boff[ts] + r;
-            if (other >= S.n_rows) other = -1;
-            s_ld[i] = other;
-            s_st[i] = j;
-            done = true;
-          }
-        } else if (mine && ok) {
-          resolved = true;
-          const int64_t r = j - bt;
-          if (r >= 0 && r < D.B) {
-            b = D.sorted ? D.sorted[r] : r;
-            token = b >= 0 && b < D.B;
-          }
-        }
-      } else if (D.kind == RUA_CAT && D.off && D.B > 0) {
-        int64_t ob;
-        const bool ok = coop_resolve([&](int64_t k) { return cat_off(D, k); }, D.B, tile0 + w0, nw, lane1, b, ob);
-        if (mine && ok) { resolved = true; token = true; t = j - ob; }
-      }
-      if (mine && !done) {
-        if (!resolved) token = row_to_token(D, j, b, t);
-        if (token) {
-          // caller-supplied (batch_ptr, token_ptr) pairs are range-checked: a bad pair yields the fill /
-          // is skipped instead of faulting the GPU (the reference raises an IndexError there)
-          if (D.kind == RUA_LIST) {
-            if (!D.bptr) { if (t < 0) t += S.n_rows; }        // a flat row list wraps negatives like torch's indexing
-            else if (b < 0 || b >= S.B) { b = 0; t = -1; }
-          }
-          const int64_t slen = seq_len(S, b);
-          const int64_t dlen = D.kind == RUA_LIST ? slen : seq_len(D, b);
-          const int64_t ts = apply_tmap(tmap, targ, t, slen, dlen);
-          if (ts >= 0 && ts < slen) other = token_to_row(S, b, ts, slen);
-          // metadata that does not match the storage (lengths summing past the payload, a corrupt
-          // PackedSequence) must not become an out-of-bounds access: such rows read as padding
-          if (other >= S.n_rows) other = -1;
-        } else {
-          other = pad_row;  // padding row: fill (-1) or a copy of one fixed source row
-        }
+      const int64_t other = resolve_wave_rows<SCATTER>(D, S, tmap, targ, pad_row, tile0 + w0, nw, lane1, same_pack);
+      if (i < nrows) {
+        const int64_t j = tile0 + i;
         if (SCATTER) { s_ld[i] = j; s_st[i] = other; }   // enumerated rows are the source
         else         { s_ld[i] = other; s_st[i] = j; }   // enumerated rows are the destination
       }
@@ -309,13 +333,178 @@ __global__ __launch_bounds__(BLOCK) void move_rows_kernel(rua_layout D, rua_layo
 }
 
 // ---------------------------------------------------------------------------------------------
+// [r5] Rows of ONE vector — 1, 2, 4, 8 or 16 bytes: 1-D payloads (int64 token ids, fp32 scalars, bool masks), the
+// commonest thing `C.new([...]).left()` is called on.  The generic kernel gives such a row a lane in phase 1 and a lane in
+// phase 2 and a workgroup 256 rows: 2 KiB per workgroup at 8-byte rows behind a chain of dependent index loads — 5.8 ms
+// for 500 M rows (0.09 T rows/s, 1.4 TB/s at 8 bytes, 0.17 at 1 byte), whatever the width.  Here a lane keeps its row
+// from resolution to store (no LDS, no barrier) and has CH rows in flight: a wave takes 64 * CH consecutive enumerated
+// rows, chunk by chunk (every chunk one contiguous run of 64 rows on the enumerated side), all CH loads are issued before
+// the first store.  Same row maps as the generic kernel (resolve_wave_rows): every layout pair, gather and scatter,
+// pad_row.  A gather between a PackedSequence and a batch-major layout still reads one row per cache line this way — that
+// pair belongs to the (rank x time) tiles below, which this kernel only replaces when the host withholds the tile table.
+template <int VEC, bool SCATTER, bool NT, int CH>
+__global__ __launch_bounds__(RUA_BLOCK) void move_rows_narrow_kernel(rua_layout D, rua_layout S, int32_t tmap, int64_t targ,
+                                                                     char* __restrict__ dst, const char* __restrict__ src,
+                                                                     uint4 fillpat, int64_t pad_row,
+                                                                     int64_t tiles_per_xcd) {
+  using V = typename vec_of<VEC>::type;
+  constexpr int TILE = RUA_BLOCK * CH;
+  int64_t tile = blockIdx.x;
+  if (tiles_per_xcd > 0) tile = (int64_t)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+  const int64_t tile0 = tile * TILE;
+  if (tile0 >= D.n_rows || (tiles_per_xcd > 0 && (int64_t)(blockIdx.x >> 3) >= tiles_per_xcd)) return;
+  const bool same_pack = !SCATTER && D.kind == RUA_PACK && S.kind == RUA_PACK && D.bsz && D.boff == S.boff &&
+                         D.sorted == S.sorted && D.len_add == 0 && S.len_add == 0 && D.T == S.T;
+  const int lane = threadIdx.x & (RUA_WAVE - 1), wave = threadIdx.x >> 6;
+  const int64_t jw = tile0 + (int64_t)wave * (RUA_WAVE * CH);
+  const V fillv = fill_of<VEC>(fillpat);
+  V val[CH];
+  int64_t st[CH];
+  WaveWindow ww;
+  const bool have_win = jw < D.n_rows && wave_window(D, jw, lane, ww);      // (wave-uniform)
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int64_t jw0 = jw + c * RUA_WAVE;
+    const int64_t left = D.n_rows - jw0;
+    st[c] = -1;
+    val[c] = fillv;
+    if (left <= 0) continue;                                          // wave-uniform
+    const int nw = left < RUA_WAVE ? (int)left : RUA_WAVE;
+    const int64_t other = resolve_wave_rows<SCATTER>(D, S, tmap, targ, pad_row, jw0, nw, lane, same_pack, have_win ? &ww : nullptr);
+    if (lane < nw) {
+      const int64_t j = jw0 + lane;
+      const int64_t ld = SCATTER ? j : other;
+      st[c] = SCATTER ? other : j;
+      if (ld >= 0 && st[c] >= 0) val[c] = ld_row<V, NT>(src + ld * VEC);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+    if (st[c] >= 0) st_row<V, NT>(dst + st[c] * VEC, val[c]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// [r5] Narrow rows between two BATCH-MAJOR layouts (C.left(), L.cat(), C.right(), R.left(), C.roll(s), trunc / head of a
+// padded batch ...): a sequence's tokens are one contiguous run of bytes on both sides, so the cast is a SEGMENTED
+// MEMCPY — per sequence at most two runs to copy (a roll wraps once) and the rest of the destination's slots to fill —
+// and rows stop mattering: a lane moves 16 bytes whatever the row width.  The row kernels give every ROW a lane and its
+// own index arithmetic: 6.3 ms for C.left() of 500 M 8-byte rows (1.9 TB/s), 4.2 ms for C.roll.  Here a wave takes
+// SEQ_PER_WAVE consecutive sequences (their lengths and offsets arrive in one coalesced load, lane i holding sequence
+// i's), and streams every run with 16-byte lanes at whatever dword-aligned address it starts (gfx950 takes a dwordx4
+// there), four vectors in flight per lane.  For rows that are a multiple of 4 bytes; the launcher takes it when no
+// sequence can be a large share of the launch (one wave walks a whole sequence).
+constexpr int SEQ_PER_WAVE = 8;
+template <bool NT>
+__device__ __forceinline__ void wave_copy_bytes(char* __restrict__ d, const char* __restrict__ s, int64_t nbytes, int lane) {
+  constexpr int UN = 4;
+  const int64_t nvec = nbytes >> 4;
+  for (int64_t v0 = 0; v0 < nvec; v0 += RUA_WAVE * UN) {
+    u32x4 x[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int64_t v = v0 + u * RUA_WAVE + lane;
+      if (v < nvec) x[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4*>(s + (v << 4)))
+                              : *reinterpret_cast<const u32x4_a4*>(s + (v << 4));
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int64_t v = v0 + u * RUA_WAVE + lane;
+      if (v < nvec) {
+        if (NT) __builtin_nontemporal_store(x[u], reinterpret_cast<u32x4_a4*>(d + (v << 4)));
+        else *reinterpret_cast<u32x4_a4*>(d + (v << 4)) = x[u];
+      }
+    }
+  }
+  const int tail = (int)(nbytes & 15) >> 2;                          // 0 .. 3 dwords behind the last whole vector
+  if (lane < tail) *reinterpret_cast<uint32_t*>(d + (nvec << 4) + lane * 4) = *reinterpret_cast<const uint32_t*>(s + (nvec << 4) + lane * 4);
+}
+template <bool NT>
+__device__ __forceinline__ void wave_fill_bytes(char* __restrict__ d, int64_t nbytes, u32x4 pat, int lane) {
+  const int64_t nvec = nbytes >> 4;
+  for (int64_t v = lane; v < nvec; v += RUA_WAVE) {
+    if (NT) __builtin_nontemporal_store(pat, reinterpret_cast<u32x4_a4*>(d + (v << 4)));
+    else *reinterpret_cast<u32x4_a4*>(d + (v << 4)) = pat;
+  }
+  const int tail = (int)(nbytes & 15) >> 2;
+  // (the pattern repeats every element and a run starts on an element boundary; elements wider than a dword keep
+  // their phase because a run's length in bytes is a multiple of the element too)
+  if (lane < tail) *reinterpret_cast<uint32_t*>(d + (nvec << 4) + lane * 4) = pat[lane & 3];
+}
+
+template <bool NT>
+__global__ __launch_bounds__(RUA_BLOCK) void seq_copy_kernel(rua_layout D, rua_layout S, int32_t tmap, int64_t targ,
+                                                             char* __restrict__ dst, const char* __restrict__ src,
+                                                             int64_t rb, uint4 fillpat) {
+  const int lane = threadIdx.x & (RUA_WAVE - 1);
+  const int64_t wave_id = ((int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x) >> 6;
+  const int64_t b0 = wave_id * SEQ_PER_WAVE;
+  if (b0 >= D.B) return;                                            // wave-uniform
+  const int64_t bl = b0 + lane;
+  const bool have = lane < SEQ_PER_WAVE && bl < D.B;
+  int64_t my_dlen = 0, my_slen = 0, my_dbase = 0, my_sbase = 0;
+  if (have) {
+    my_dlen = seq_len(D, bl);
+    my_slen = bl < S.B ? seq_len(S, bl) : 0;
+    if (my_dlen < 0) my_dlen = 0;
+    if (my_slen < 0) my_slen = 0;
+    my_dbase = token_to_row(D, bl, 0, my_dlen);
+    my_sbase = bl < S.B ? token_to_row(S, bl, 0, my_slen) : 0;
+  }
+  const u32x4 pat = fill_of<16>(fillpat);
+  const bool padded = D.kind == RUA_LEFT || D.kind == RUA_RIGHT;
+#pragma unroll 1
+  for (int i = 0; i < SEQ_PER_WAVE; ++i) {
+    const int64_t b = b0 + i;
+    if (b >= D.B) break;                                            // wave-uniform
+    int64_t dlen = __shfl(my_dlen, i, RUA_WAVE), slen = __shfl(my_slen, i, RUA_WAVE);
+    const int64_t dbase = __shfl(my_dbase, i, RUA_WAVE), sbase = __shfl(my_sbase, i, RUA_WAVE);
+    // metadata that does not match the storage must not become an out-of-bounds access
+    if (dbase < 0 || dbase > D.n_rows) continue;
+    if (dbase + dlen > D.n_rows) dlen = D.n_rows - dbase;
+    if (sbase < 0 || sbase > S.n_rows) slen = 0;
+    else if (sbase + slen > S.n_rows) slen = S.n_rows - sbase;
+    // destination tokens [lo, hi) come from the source tokens that start at `from`; a roll adds the wrapped run [0, lo)
+    int64_t lo = 0, hi = 0, from = 0, wrap_from = -1;
+    if (tmap == RUA_T_SHIFT) {
+      lo = targ < 0 ? -targ : 0;
+      hi = slen - targ < dlen ? slen - targ : dlen;
+      if (lo > dlen) lo = dlen;
+      if (hi < lo) hi = lo;
+      from = lo + targ;
+    } else {                                                        // RUA_T_ROLL (the launcher checked dlen == slen)
+      const int64_t n = dlen < slen ? dlen : slen;
+      int64_t k = 0;
+      if (n > 0) { k = targ % n; if (k < 0) k += n; }
+      lo = k; hi = n; from = 0; wrap_from = n - k;                  // dst [k, n) <- src [0, n - k);  dst [0, k) <- src [n - k, n)
+      dlen = n;
+    }
+    char* drow = dst + dbase * rb;
+    const char* srow = src + sbase * rb;
+    if (wrap_from >= 0) { if (lo > 0) wave_copy_bytes<NT>(drow, srow + wrap_from * rb, lo * rb, lane); }
+    else if (lo > 0) wave_fill_bytes<NT>(drow, lo * rb, pat, lane);
+    if (hi > lo) wave_copy_bytes<NT>(drow + lo * rb, srow + from * rb, (hi - lo) * rb, lane);
+    if (dlen > hi) wave_fill_bytes<NT>(drow + hi * rb, (dlen - hi) * rb, pat, lane);
+    if (padded) {                                                   // the slots of the sequence that hold no token
+      const int64_t slot0 = b * D.T_phys;
+      const int64_t dl = __shfl(my_dlen, i, RUA_WAVE);              // (the unclipped length: where the tokens sit)
+      int64_t front = dbase - slot0, back0 = dbase + dl;            // LEFT: front = 0; RIGHT: front = T_log - len
+      if (front > 0) wave_fill_bytes<NT>(dst + slot0 * rb, front * rb, pat, lane);
+      int64_t back = slot0 + D.T_phys - back0;
+      if (back0 + back > D.n_rows) back = D.n_rows - back0;
+      if (back > 0) wave_fill_bytes<NT>(dst + back0 * rb, back * rb, pat, lane);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Narrow rows (<= 128 B): C/L/R <-> P is a transpose of the (rank, time) plane — C is contiguous along
 // time, P along rank — and a destination-row-major tile makes the other side a one-row-granular gather:
 // a 32-byte row out of every 128-byte line, i.e. 4x over-fetch (measured 1.3 TB/s at 32-byte rows).
 // Here a tile is TR ranks x TT time steps, so BOTH sides move 16-row runs, and phase 2 walks it in 4x4
 // sub-tiles.  (At >= 1 KiB rows the same tiling changes nothing — a row already fills whole lines — so
 // wide rows keep the generic kernel.)  Phase 1 needs no search: rank r is live at time t iff r < bsz[t].
-constexpr int TR_MAX = 32;        // a tile is (1 << TRL) ranks x (1 << TTL) time steps, TRL = 4 .. 5, TTL = 4 .. 6 (rua_layout::tile_t_log2)
+constexpr int TR_MAX = 128;       // a tile is (1 << TRL) ranks x (1 << TTL) time steps, TRL = 4 .. 7, TTL = 4 .. 7 (rua_layout::tile_t_log2)
+constexpr int TT_MAX = 128;
 constexpr int64_t TILE_MAX_ROW_BYTES = 64;       // rows up to this take the tile kernel (pack_tile_lds_kernel)
 
 // [r4] A tile's life is one chain of dependent loads in front of its payload, and eight resident workgroups per CU
@@ -345,49 +534,63 @@ struct TileTables {
   int64_t obase[TR_MAX];  // batch-major storage row of the rank's window start: first row of the sequence - shift + t0
   int64_t olen[TR_MAX];   // the sequence's length (0: no such sequence)
   int shift[TR_MAX];      // the rank's time shift s in [0, R)
-  int64_t pboff[64 + TILE_SHIFT_MAX];      // first PackedSequence row of time step t0 - (R - 1) + k
-  int64_t pbsz[64 + TILE_SHIFT_MAX];       // sequences alive at that step (0 before 0 and past T)
+  int64_t ofill[TR_MAX];  // padded destination (full-grid tiles): storage row of the sequence's slot 0, -1: no such sequence
+  int64_t pboff[TT_MAX + TILE_SHIFT_MAX];  // first PackedSequence row of time step t0 - (R - 1) + k
+  int64_t pbsz[TT_MAX + TILE_SHIFT_MAX];   // sequences alive at that step (0 before 0 and past T)
 };
+constexpr int TILE_FULL_GRID = 1 << 24;   // rua_layout::tile_t_log2 bit 24: tiles cover the whole (sequence x step) grid
 
 template <int TTL, int TRL>
 __device__ __forceinline__ void tile_tables(const rua_layout& Pk, const rua_layout& Ot, int64_t tile, TileTables& tb,
                                             int64_t& r0_out, int64_t& t0_out, int R = 1, int64_t phase = 0) {
   constexpr int TT = 1 << TTL, TR = 1 << TRL;
-  // which time chunk does this tile belong to?  largest c with tile_start[c] <= tile.  Up to 64 chunks
-  // every lane loads one entry and a ballot counts them: ONE load instead of a six-step chain of dependent ones
-  int64_t lo = 0, hi = Pk.n_tchunks;
-  if (Pk.n_tchunks <= RUA_WAVE) {
-    const int lane = threadIdx.x & (RUA_WAVE - 1);
-    const int64_t v = lane < Pk.n_tchunks ? Pk.tile_start[lane] : 0x7fffffffffffffffLL;
-    lo = (int64_t)__popcll(__ballot(v <= tile)) - 1;
-    if (lo < 0) lo = 0;
+  int64_t lo = 0;
+  int64_t r0;
+  if (Pk.tile_t_log2 & TILE_FULL_GRID) {
+    // [r5] a PADDED destination (P.left() / P.right()): the tiles cover the whole (sequence x step) grid, rank groups
+    // fastest — no table: every chunk holds ceil(B / TR) of them — and a cell that holds no token is written as fill
+    const int64_t groups = (Pk.B + TR - 1) >> TRL;
+    lo = tile / groups;
+    r0 = (tile - lo * groups) << TRL;
   } else {
-    while (hi - lo > 1) {
-      const int64_t mid = (lo + hi) >> 1;
-      if (Pk.tile_start[mid] <= tile) lo = mid; else hi = mid;
+    // which time chunk does this tile belong to?  largest c with tile_start[c] <= tile.  Up to 64 chunks
+    // every lane loads one entry and a ballot counts them: ONE load instead of a six-step chain of dependent ones
+    int64_t hi = Pk.n_tchunks;
+    if (Pk.n_tchunks <= RUA_WAVE) {
+      const int lane = threadIdx.x & (RUA_WAVE - 1);
+      const int64_t v = lane < Pk.n_tchunks ? Pk.tile_start[lane] : 0x7fffffffffffffffLL;
+      lo = (int64_t)__popcll(__ballot(v <= tile)) - 1;
+      if (lo < 0) lo = 0;
+    } else {
+      while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (Pk.tile_start[mid] <= tile) lo = mid; else hi = mid;
+      }
     }
+    r0 = (tile - Pk.tile_start[lo]) * TR;
   }
   const int64_t t0 = lo * TT;
-  const int64_t r0 = (tile - Pk.tile_start[lo]) * TR;
   r0_out = r0;
   t0_out = t0;
-  const int i = threadIdx.x;
-  if (i < TR) {                                   // wave 0, lanes 0..15: the ranks
+  for (int i = threadIdx.x; i < TR; i += RUA_BLOCK) {          // the ranks: sequence -> first row, length
     const int64_t r = r0 + i;
-    int64_t base = 0, len = 0;
+    int64_t base = 0, len = 0, slot0 = -1;
     if (r < Pk.B) {
       const int64_t b = Pk.sorted ? Pk.sorted[r] : r;
       if (b >= 0 && b < Ot.B) {
         len = seq_len(Ot, b);
         base = token_to_row(Ot, b, 0, len);
+        if (Ot.kind == RUA_LEFT || Ot.kind == RUA_RIGHT) slot0 = b * Ot.T_phys;
       }
     }
     const int s = R > 1 ? (int)((base + phase) & (int64_t)(R - 1)) : 0;
     tb.shift[i] = s;
     tb.obase[i] = base - s + t0;                  // batch-major row of the rank's window start (a whole-line boundary)
     tb.olen[i] = len;
-  } else if (i >= RUA_WAVE && i < RUA_WAVE + TT + R - 1) {   // waves 1..: the time steps t0 - (R - 1) .. t0 + TT - 1
-    const int k = i - RUA_WAVE;
+    tb.ofill[i] = slot0;
+  }
+  // the time steps t0 - (R - 1) .. t0 + TT - 1 (threads from the far end: the first ones hold a rank already)
+  for (int k = RUA_BLOCK - 1 - (int)threadIdx.x; k < TT + R - 1; k += RUA_BLOCK) {
     const int64_t t = t0 - (R - 1) + k;
     const bool ok = t >= 0 && t < Pk.T;
     tb.pboff[k] = ok ? Pk.boff[t] : 0;
@@ -403,11 +606,11 @@ __device__ __forceinline__ void tile_tables(const rua_layout& Pk, const rua_layo
 template <int VEC, bool TO_PACK, int TTL, int TRL>
 __global__ __launch_bounds__(RUA_BLOCK) void pack_tile_lds_kernel(rua_layout Pk, rua_layout Ot, char* __restrict__ dst,
                                                               const char* __restrict__ src, int64_t row_bytes,
-                                                              int64_t lpr, int64_t tiles_per_xcd, int R, int64_t phase) {
+                                                              int64_t lpr, int64_t tiles_per_xcd, int R, int64_t phase,
+                                                              uint4 fillpat) {
   using V = typename vec_of<VEC>::type;
   constexpr int TT = 1 << TTL, TR = 1 << TRL, TILE = TR * TT;
-  static_assert(TT <= 64 && TR <= TR_MAX && RUA_BLOCK >= RUA_WAVE + TT + TILE_SHIFT_MAX,
-                "one lane per rank in wave 0, per time step in waves 1..");
+  static_assert(TT <= TT_MAX && TR <= TR_MAX, "TileTables holds the tile's ranks and time steps");
   __shared__ TileTables tb;
 
   int64_t tile = blockIdx.x;                  // (block-uniform) one contiguous span of tiles per XCD, as in the row mover
@@ -468,6 +671,8 @@ __global__ __launch_bounds__(RUA_BLOCK) void pack_tile_lds_kernel(rua_layout Pk,
       if (live) stage[RUA_SLOT(rank, j, piece)] = ld_row<V, false>(src + prow * row_bytes + (int64_t)piece * VEC);
     }
     __syncthreads();
+    const bool padded = (Pk.tile_t_log2 & TILE_FULL_GRID) != 0;      // (R == 1 then: the host asks for plain windows)
+    const V fillv = fill_of<VEC>(fillpat);
 #pragma unroll 4
     for (int idx = threadIdx.x; idx < n_major; idx += RUA_BLOCK) {
       const int pos = idx / (int)lpr, piece = idx - pos * (int)lpr;
@@ -475,10 +680,133 @@ __global__ __launch_bounds__(RUA_BLOCK) void pack_tile_lds_kernel(rua_layout Pk,
       RUA_CELL(rank, j, k, orow, prow, live);
       (void)prow;
       if (live) st_row<V, false>(dst + orow * row_bytes + (int64_t)piece * VEC, stage[RUA_SLOT(rank, j, piece)]);
+      else if (padded && tb.ofill[rank] >= 0 && t_ >= tb.olen[rank] && t_ < Ot.T_phys) {
+        // a slot of the padded destination that holds no token: LEFT keeps its tokens in front (slot = step), RIGHT
+        // at the end of the logical width (the dead steps len .. T_log - 1 are the slots 0 .. T_log - len - 1 in front)
+        const int64_t slot = (Ot.kind == RUA_RIGHT && t_ < Ot.T_log) ? t_ - tb.olen[rank] : t_;
+        st_row<V, false>(dst + (tb.ofill[rank] + slot) * row_bytes + (int64_t)piece * VEC, fillv);
+      }
     }
   }
 #undef RUA_CELL
 #undef RUA_SLOT
+}
+
+// [r5] The same transpose for rows of ONE 8- or 4-byte vector (1-D int64 / fp32 payloads), SIXTEEN BYTES PER LANE.  At these
+// widths the kernel above is bound by instructions, not bytes: a lane moves one row per trip (a global load, an LDS write,
+// an LDS read, a global store and ~60 instructions of cell arithmetic for 8 bytes) — 2.5 ms for 500 M 8-byte rows,
+// 2.0 ms for as many 4-byte rows.  Here a lane takes CPL = 16 / RB consecutive cells along the side's CONTIGUOUS axis — steps
+// of one rank on the batch-major side, ranks of one step on the PackedSequence's — as one 16-byte global access (any
+// dword-aligned address will do on gfx950) and CPL row-sized LDS accesses; a group that straddles the end of a sequence
+// or of a time step falls back to its cells one by one.  Tiles: 32 ranks x 64 steps (8-byte rows), 64 x 64 (4-byte).
+template <int RB, bool TO_PACK, int TTL, int TRL>
+__global__ __launch_bounds__(RUA_BLOCK) void pack_tile_vec_kernel(rua_layout Pk, rua_layout Ot, char* __restrict__ dst,
+                                                                  const char* __restrict__ src, int64_t tiles_per_xcd,
+                                                                  uint4 fillpat) {
+  using E = typename vec_of<RB>::type;
+  constexpr int CPL = 16 / RB, TT = 1 << TTL, TR = 1 << TRL;
+  constexpr int JG_LOG2 = TTL - (RB == 8 ? 1 : 2), RG_LOG2 = TRL - (RB == 8 ? 1 : 2);     // groups per rank / per step
+  static_assert(RB == 8 || RB == 4, "rows of one 8- or 4-byte vector");
+  union Vec { u32x4 v; E e[CPL]; };
+  __shared__ TileTables tb;
+  __shared__ E stage[TR * (TT + 1)];             // one padding cell per rank: the transposed walk strides over TT + 1 cells
+  int64_t tile = blockIdx.x;
+  if (tiles_per_xcd > 0) {
+    tile = (int64_t)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= tiles_per_xcd || tile >= Pk.n_tiles) return;
+  }
+  int64_t r0, t0;
+  tile_tables<TTL, TRL>(Pk, Ot, tile, tb, r0, t0);
+  __syncthreads();
+  const bool padded = (Pk.tile_t_log2 & TILE_FULL_GRID) != 0;
+  Vec fillv;
+  fillv.v = fill_of<16>(fillpat);
+  const int64_t on = Ot.n_rows, pn = Pk.n_rows;
+  // cell (rank, j): step t0 + j of the rank's sequence; batch-major row obase[rank] + j, PackedSequence row pboff[j] + r0 + rank
+#define RUA_LIVE(rank, j) (t0 + (j) < tb.olen[rank] && r0 + (rank) < tb.pbsz[j] && tb.obase[rank] + (j) < on && tb.pboff[j] + r0 + (rank) < pn)
+#define RUA_STG(rank, j) stage[(rank) * (TT + 1) + (j)]
+  // ---- the batch-major side: a group = CPL consecutive steps of one rank
+  auto major_pass = [&](auto&& both, auto&& one) {
+    for (int idx = threadIdx.x; idx < (TR << JG_LOG2); idx += RUA_BLOCK) {
+      const int rank = idx >> JG_LOG2, j = (idx & ((1 << JG_LOG2) - 1)) * CPL;
+      bool all = true;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) all = all && RUA_LIVE(rank, j + c);
+      if (all) both(rank, j);
+      else {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) one(rank, j + c, RUA_LIVE(rank, j + c));
+      }
+    }
+  };
+  // ---- the PackedSequence's side: a group = CPL consecutive ranks of one step
+  auto packed_pass = [&](auto&& both, auto&& one) {
+    for (int idx = threadIdx.x; idx < (TT << RG_LOG2); idx += RUA_BLOCK) {
+      const int j = idx >> RG_LOG2, rank = (idx & ((1 << RG_LOG2) - 1)) * CPL;
+      bool all = true;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) all = all && RUA_LIVE(rank + c, j);
+      if (all) both(rank, j);
+      else {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) one(rank + c, j, RUA_LIVE(rank + c, j));
+      }
+    }
+  };
+  if (TO_PACK) {
+    major_pass(
+        [&](int rank, int j) {
+          Vec v;
+          v.v = *reinterpret_cast<const u32x4_a4*>(src + (tb.obase[rank] + j) * RB);
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) RUA_STG(rank, j + c) = v.e[c];
+        },
+        [&](int rank, int j, bool live) {
+          if (live) RUA_STG(rank, j) = *reinterpret_cast<const E*>(src + (tb.obase[rank] + j) * RB);
+        });
+    __syncthreads();
+    packed_pass(
+        [&](int rank, int j) {
+          Vec v;
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) v.e[c] = RUA_STG(rank + c, j);
+          *reinterpret_cast<u32x4_a4*>(dst + (tb.pboff[j] + r0 + rank) * RB) = v.v;
+        },
+        [&](int rank, int j, bool live) {
+          if (live) *reinterpret_cast<E*>(dst + (tb.pboff[j] + r0 + rank) * RB) = RUA_STG(rank, j);
+        });
+  } else {
+    packed_pass(
+        [&](int rank, int j) {
+          Vec v;
+          v.v = *reinterpret_cast<const u32x4_a4*>(src + (tb.pboff[j] + r0 + rank) * RB);
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) RUA_STG(rank + c, j) = v.e[c];
+        },
+        [&](int rank, int j, bool live) {
+          if (live) RUA_STG(rank, j) = *reinterpret_cast<const E*>(src + (tb.pboff[j] + r0 + rank) * RB);
+        });
+    __syncthreads();
+    major_pass(
+        [&](int rank, int j) {
+          Vec v;
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) v.e[c] = RUA_STG(rank, j + c);
+          *reinterpret_cast<u32x4_a4*>(dst + (tb.obase[rank] + j) * RB) = v.v;
+        },
+        [&](int rank, int j, bool live) {
+          if (live) {
+            *reinterpret_cast<E*>(dst + (tb.obase[rank] + j) * RB) = RUA_STG(rank, j);
+          } else if (padded && tb.ofill[rank] >= 0 && t0 + j >= tb.olen[rank] && t0 + j < Ot.T_phys) {
+            // a slot of the padded destination that holds no token (see pack_tile_lds_kernel)
+            const int64_t t_ = t0 + j;
+            const int64_t slot = (Ot.kind == RUA_RIGHT && t_ < Ot.T_log) ? t_ - tb.olen[rank] : t_;
+            *reinterpret_cast<E*>(dst + (tb.ofill[rank] + slot) * RB) = fillv.e[0];
+          }
+        });
+  }
+#undef RUA_STG
+#undef RUA_LIVE
 }
 
 // roll / rev INSIDE one PackedSequence at rows of <= 32 bytes, on the same (rank x time) tiles: both sides are in the
@@ -540,9 +868,19 @@ static int launch_roll_tiles(int vec, hipStream_t s, const rua_layout& Pk, int32
   return (int)hipGetLastError();
 }
 
+// the tile shapes beyond 16 ranks: rows of ONE vector below 16 bytes (see launch_pack_tiles)
+static inline bool tile_shape_narrow(int vec, int64_t lpr, int ttl, int trl) {
+  return lpr == 1 && ((vec == 8 && trl == 5 && ttl == 6) || (vec == 4 && trl == 6 && ttl == 6) ||
+                      (vec == 2 && trl == 6 && ttl == 7) || (vec == 1 && trl == 7 && ttl == 7));
+}
+static inline bool tile_shape_exists(int vec, int64_t row_bytes, int code) {
+  const int ttl = (code & 0xff) == 0 ? 4 : (code & 0xff), trl = ((code >> 8) & 0xff) == 0 ? 4 : ((code >> 8) & 0xff);
+  return (trl == 4 && ttl >= 4 && ttl <= 6) || tile_shape_narrow(vec, (row_bytes + vec - 1) / vec, ttl, trl);
+}
+
 template <bool TO_PACK>
 static int launch_pack_tiles(int vec, hipStream_t s, const rua_layout& Pk, const rua_layout& Ot, char* dst,
-                             const char* src, int64_t row_bytes, bool xcd_span) {
+                             const char* src, int64_t row_bytes, bool xcd_span, uint4 fp) {
   const int64_t per_xcd = xcd_span ? (Pk.n_tiles + 7) / 8 : 0;
   const int64_t grid = xcd_span ? per_xcd * 8 : Pk.n_tiles;
   if (grid > 0x7fffffffLL) return RUA_ERANGE;
@@ -550,7 +888,14 @@ static int launch_pack_tiles(int vec, hipStream_t s, const rua_layout& Pk, const
   const dim3 g((unsigned)grid), b(RUA_BLOCK);
   const int ttl = (Pk.tile_t_log2 & 0xff) == 0 ? 4 : (Pk.tile_t_log2 & 0xff);      // (0: a caller of ABI <= 3, 16 x 16 tiles)
   const int trl = ((Pk.tile_t_log2 >> 8) & 0xff) == 0 ? 4 : ((Pk.tile_t_log2 >> 8) & 0xff);
-  if (ttl < 4 || ttl > 6 || trl != 4) return RUA_EINVAL;
+  // tile shapes that exist: 16 ranks x 16 / 32 / 64 steps for any vector width, and — [r5] rows of ONE vector below 16
+  // bytes — 32 x 64 (8-byte rows), 64 x 64 (4), 64 x 128 (2), 128 x 128 (1): 16 KiB of payload per tile at every width,
+  // runs of 128 .. 512 bytes on both sides
+  const bool shape16 = trl == 4 && ttl >= 4 && ttl <= 6;
+  const bool shape_narrow = tile_shape_narrow(vec, lpr, ttl, trl);
+  if (!shape16 && !shape_narrow) return RUA_EINVAL;
+  const bool full_grid = (Pk.tile_t_log2 & TILE_FULL_GRID) != 0;
+  if (full_grid && (TO_PACK || (Ot.kind != RUA_LEFT && Ot.kind != RUA_RIGHT))) return RUA_EINVAL;
   // the batch-major side's runs start on 128-byte lines (TileTables): R rows per line, if the host built the table for
   // it, the rows divide a line and the payload's own address does not spoil it (its offset inside a line, in rows)
   int R = (int)((Pk.tile_t_log2 >> 16) & 0xff);
@@ -560,7 +905,7 @@ static int launch_pack_tiles(int vec, hipStream_t s, const rua_layout& Pk, const
   // windows trade whole lines on the batch-major side for fragments on the PackedSequence's, so they gain 2-20 % for
   // P.cat and LOSE 6-15 % for the pack, whose packed-side fragments would then be the stores (same-box A/B of both
   // directions at 16 / 32 / 64-byte rows: profiles/r04_tile_shift_ab.txt)
-  if (TO_PACK || R < 2 || R > TILE_SHIFT_MAX || (R & (R - 1)) != 0 || R * row_bytes != 128 || (major & 127) % (uintptr_t)row_bytes != 0) R = 1;
+  if (TO_PACK || full_grid || R < 2 || R > TILE_SHIFT_MAX || (R & (R - 1)) != 0 || R * row_bytes != 128 || (major & 127) % (uintptr_t)row_bytes != 0) R = 1;
   else phase = (int64_t)((major & 127) / (uintptr_t)row_bytes);
 #ifdef RUA_TILE_NO_SHIFT          // developer A/B build
   R = 1; phase = 0;
@@ -568,12 +913,21 @@ static int launch_pack_tiles(int vec, hipStream_t s, const rua_layout& Pk, const
   const size_t lds = (size_t)((((int64_t)1 << (ttl + trl)) + ((int64_t)1 << trl)) * lpr) * vec;   // the staged tile + one padding row per rank
   if (lds > (48u << 10)) return RUA_EINVAL;                            // (the host picks the tile by row width: 32 KiB staged at most)
 #define RUA_LAUNCH_T(VEC, TTLV, TRLV) \
-  hipLaunchKernelGGL((pack_tile_lds_kernel<VEC, TO_PACK, TTLV, TRLV>), g, b, lds, s, Pk, Ot, dst, src, row_bytes, lpr, per_xcd, R, phase)
+  hipLaunchKernelGGL((pack_tile_lds_kernel<VEC, TO_PACK, TTLV, TRLV>), g, b, lds, s, Pk, Ot, dst, src, row_bytes, lpr, per_xcd, R, phase, fp)
 #define RUA_LAUNCH(VEC)                                                             \
-  switch (ttl) {             /* (32 ranks per tile were measured too: slower at every width, not instantiated) */ \
+  switch (ttl) {             /* (32 ranks per tile were measured too at >= 16-byte rows: slower, not instantiated) */ \
     case 4: RUA_LAUNCH_T(VEC, 4, 4); break;                                         \
     case 5: RUA_LAUNCH_T(VEC, 5, 4); break;                                         \
     default: RUA_LAUNCH_T(VEC, 6, 4); break;                                        \
+  }
+  if (shape_narrow) {
+    switch (vec) {
+      case 8: hipLaunchKernelGGL((pack_tile_vec_kernel<8, TO_PACK, 6, 5>), g, b, 0, s, Pk, Ot, dst, src, per_xcd, fp); break;
+      case 4: hipLaunchKernelGGL((pack_tile_vec_kernel<4, TO_PACK, 6, 6>), g, b, 0, s, Pk, Ot, dst, src, per_xcd, fp); break;
+      case 2: RUA_LAUNCH_T(2, 7, 6); break;
+      default: RUA_LAUNCH_T(1, 7, 7); break;
+    }
+    return (int)hipGetLastError();
   }
   switch (vec) {
     case 16: RUA_LAUNCH(16); break;
@@ -609,6 +963,29 @@ static int check_layout(const rua_layout* L, bool is_dst) {
 }
 
 constexpr int NARROW_RPT = 4;
+constexpr int NARROW_CH = 8;         // rows in flight per lane of move_rows_narrow_kernel
+
+template <bool SCATTER, bool NT>
+static int launch_narrow(int vec, int64_t n_rows, hipStream_t s, const rua_layout& D, const rua_layout& S, int32_t tmap,
+                         int64_t targ, char* dst, const char* src, uint4 fp, int64_t pad_row, bool xcd_span) {
+  const int64_t per_tile = (int64_t)RUA_BLOCK * NARROW_CH;
+  const int64_t ntiles = (n_rows + per_tile - 1) / per_tile;
+  const int64_t per_xcd = xcd_span ? (ntiles + 7) / 8 : 0;
+  const int64_t grid = xcd_span ? per_xcd * 8 : ntiles;
+  if (grid > 0x7fffffffLL) return RUA_ERANGE;
+  const dim3 g((unsigned)grid), b(RUA_BLOCK);
+#define RUA_LAUNCH_N(VEC) \
+  hipLaunchKernelGGL((move_rows_narrow_kernel<VEC, SCATTER, NT, NARROW_CH>), g, b, 0, s, D, S, tmap, targ, dst, src, fp, pad_row, per_xcd)
+  switch (vec) {
+    case 16: RUA_LAUNCH_N(16); break;
+    case 8:  RUA_LAUNCH_N(8); break;
+    case 4:  RUA_LAUNCH_N(4); break;
+    case 2:  RUA_LAUNCH_N(2); break;
+    default: RUA_LAUNCH_N(1); break;
+  }
+#undef RUA_LAUNCH_N
+  return (int)hipGetLastError();
+}
 
 template <bool SCATTER, bool NT>
 static int launch_move(int vec, int64_t n_rows, hipStream_t s, const rua_layout& D, const rua_layout& S, int32_t tmap,
@@ -700,17 +1077,24 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
   }
   hipStream_t s = (hipStream_t)stream;
   // narrow rows between a PackedSequence and a batch-major layout: (rank x time) tiles
-  const int span_flags = RUA_MOVE_XCD_SPAN_ON | RUA_MOVE_XCD_SPAN_OFF | RUA_MOVE_NO_TAIL8;
+  const int span_flags = RUA_MOVE_XCD_SPAN_ON | RUA_MOVE_XCD_SPAN_OFF | RUA_MOVE_NO_TAIL8 | RUA_MOVE_NO_NARROW;
   if ((flags & ~span_flags) == 0 && tmap == RUA_T_SHIFT && tmap_arg == 0 && row_bytes <= TILE_MAX_ROW_BYTES) {
     const bool to_pack = dst->kind == RUA_PACK && (src->kind == RUA_CAT || src->kind == RUA_LEFT || src->kind == RUA_RIGHT);
-    const bool from_pack = src->kind == RUA_PACK && dst->kind == RUA_CAT;   // padded destinations need the fill pass
+    // [r5] a padded destination takes the tiles too when the caller asks for the FULL (sequence x step) grid
+    // (rua_layout::tile_t_log2 bit 24): every slot is then written, tokens and fill, in the one pass
+    const bool full_grid = src->kind == RUA_PACK && (src->tile_t_log2 & TILE_FULL_GRID) != 0;
+    const bool from_pack = src->kind == RUA_PACK && (dst->kind == RUA_CAT || (full_grid && pad_row < 0 &&
+                                                     (dst->kind == RUA_LEFT || dst->kind == RUA_RIGHT)));
     const rua_layout* pk = to_pack ? dst : src;
-    if ((to_pack || from_pack) && pk->tile_start && pk->bsz && pk->n_tiles > 0 && pk->boff) {
-      bool span = pk->n_tiles >= (to_pack ? MOVE_SPAN_MIN_TILES : TILE_SPAN_MIN_TILES_FROM_PACK);
+    // (a table built for a tile shape this vector width has no kernel for — rows of 8 bytes at a base that is only
+    // 4-byte aligned, say — is simply not used)
+    if ((to_pack || from_pack) && (pk->tile_start || full_grid) && pk->bsz && pk->n_tiles > 0 && pk->boff &&
+        (!full_grid || (!to_pack && dst->kind != RUA_CAT)) && tile_shape_exists(vec, row_bytes, pk->tile_t_log2)) {
+      bool span = pk->n_tiles >= (to_pack || full_grid ? MOVE_SPAN_MIN_TILES : TILE_SPAN_MIN_TILES_FROM_PACK);
       if (flags & RUA_MOVE_XCD_SPAN_ON) span = true;
       if (flags & RUA_MOVE_XCD_SPAN_OFF) span = false;
-      return to_pack ? launch_pack_tiles<true>(vec, s, *dst, *src, (char*)dst_data, (const char*)src_data, row_bytes, span)
-                     : launch_pack_tiles<false>(vec, s, *src, *dst, (char*)dst_data, (const char*)src_data, row_bytes, span);
+      return to_pack ? launch_pack_tiles<true>(vec, s, *dst, *src, (char*)dst_data, (const char*)src_data, row_bytes, span, fp)
+                     : launch_pack_tiles<false>(vec, s, *src, *dst, (char*)dst_data, (const char*)src_data, row_bytes, span, fp);
     }
   }
   const bool big = (double)dst->n_rows * (double)row_bytes >= (double)(512ll << 20);
@@ -738,6 +1122,47 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
   bool xcd_span = (nr + tile_rows - 1) / tile_rows >= (padded_dst ? MOVE_SPAN_MIN_TILES : MOVE_SPAN_MIN_TILES_DENSE);
   if (flags & RUA_MOVE_XCD_SPAN_ON) xcd_span = true;
   if (flags & RUA_MOVE_XCD_SPAN_OFF) xcd_span = false;
+  // [r5] narrow rows between two batch-major layouts, rows a multiple of 4 bytes: the segmented memcpy (seq_copy_kernel)
+  {
+    const bool major_d = dst->kind == RUA_CAT || dst->kind == RUA_LEFT || dst->kind == RUA_RIGHT;
+    const bool major_s = src->kind == RUA_CAT || src->kind == RUA_LEFT || src->kind == RUA_RIGHT;
+    const bool same_lens = dst->lens == src->lens && dst->len_add == src->len_add;
+    // the longest sequence either side can hold: the storage's own T for the padded layouts, the caller's hint for a
+    // CattedSequence (rua_layout::T_log, 0 = unknown).  One wave walks a sequence whole: none may be a large share
+    const int64_t long_d = dst->kind == RUA_CAT ? dst->T_log : dst->T_phys;
+    const int64_t long_s = src->kind == RUA_CAT ? src->T_log : src->T_phys;
+    const int64_t longest = long_d > long_s ? long_d : long_s;
+    const bool balanced = long_d > 0 && long_s > 0 && dst->B >= 4096 && longest <= nr / 1024;
+    if (major_d && major_s && !(flags & (RUA_MOVE_SCATTER | RUA_MOVE_NO_NARROW)) && tsel == 0 && pad_row < 0 &&
+        row_bytes <= 64 && (row_bytes & 3) == 0 && (((uintptr_t)dst_data | (uintptr_t)src_data) & 3) == 0 &&
+        dst->B == src->B && (tmap == RUA_T_SHIFT || (tmap == RUA_T_ROLL && same_lens)) && balanced &&
+        (dst->kind != RUA_CAT || dst->off || !dst->lens) && (src->kind != RUA_CAT || src->off || !src->lens)) {
+      const int64_t waves = (dst->B + SEQ_PER_WAVE - 1) / SEQ_PER_WAVE;
+      const int64_t grid = (waves + RUA_WAVES_PER_BLOCK - 1) / RUA_WAVES_PER_BLOCK;
+      if (grid > 0x7fffffffLL) return RUA_ERANGE;
+      if (nt) hipLaunchKernelGGL(seq_copy_kernel<true>, dim3((unsigned)grid), dim3(RUA_BLOCK), 0, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp);
+      else hipLaunchKernelGGL(seq_copy_kernel<false>, dim3((unsigned)grid), dim3(RUA_BLOCK), 0, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp);
+      return (int)hipGetLastError();
+    }
+  }
+  // [r5] rows of one vector (1-D payloads: 1 .. 16 bytes): a lane per row from resolution to store, eight rows in flight
+  // per lane (move_rows_narrow_kernel).  The roll tiles below keep 16-byte rows inside one PackedSequence.
+  const bool one_vec = row_bytes == vec && !(flags & RUA_MOVE_NO_NARROW) && tsel == 0;
+  if (one_vec) {
+    const int64_t per_tile = (int64_t)RUA_BLOCK * NARROW_CH;
+    bool span = (nr + per_tile - 1) / per_tile >= (padded_dst ? MOVE_SPAN_MIN_TILES : MOVE_SPAN_MIN_TILES_DENSE);
+    if (flags & RUA_MOVE_XCD_SPAN_ON) span = true;
+    if (flags & RUA_MOVE_XCD_SPAN_OFF) span = false;
+    const bool roll_tiles = vec == 16 && dst->kind == RUA_PACK && src->kind == RUA_PACK && dst->tile_start && dst->bsz &&
+                            dst->boff == src->boff && !(flags & RUA_MOVE_SCATTER);
+    if (!roll_tiles) {
+      if (flags & RUA_MOVE_SCATTER)
+        return nt ? launch_narrow<true, true>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, fp, pad_row, span)
+                  : launch_narrow<true, false>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, fp, pad_row, span);
+      return nt ? launch_narrow<false, true>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, fp, pad_row, span)
+                : launch_narrow<false, false>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, fp, pad_row, span);
+    }
+  }
   if (flags & RUA_MOVE_SCATTER)
     return nt ? launch_move<true, true>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, false, tile_rows, xcd_span, tail8)
               : launch_move<true, false>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, false, tile_rows, xcd_span, tail8);
