@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RUA_ABI_VERSION 4
+#define RUA_ABI_VERSION 5
 
 /* argument errors (negative so they cannot collide with hipError_t) */
 #define RUA_EINVAL   (-1)  /* bad enum / null pointer / negative size      */
@@ -53,7 +53,12 @@ typedef struct rua_layout {
                               bits 16-23: R = 128 / row bytes (2, 4 or 8) when the table was built for windows that
                               begin up to R - 1 steps early — tile_start[c] counts the ranks alive at step
                               c * TT - (R - 1), and there are ceil((T + R - 1) / TT) chunks — so that the kernel may
-                              align every rank's batch-major runs to 128-byte lines; 0 = plain windows */
+                              align every rank's batch-major runs to 128-byte lines; 0 = plain windows;
+                              bit 24 (ABI 5): no table — the tiles cover the whole (sequence x step) grid of a padded
+                              DESTINATION, ceil(B / ranks) tiles per chunk of steps, n_tchunks = ceil(T_phys / steps):
+                              P.left() / P.right() at narrow rows write tokens and fill in one pass;
+                              bit 25 (ABI 5): the table counts tiles of ONE time step x (1 << bits 8-15) ranks
+                              (n_tchunks = T): a roll inside the PackedSequence moves every step's rows as one run */
   int64_t n_rows;          /* storage rows: CAT/PACK: sum(len); LEFT/RIGHT: B*T_phys; LIST: M */
   int64_t B;               /* number of sequences */
   int64_t T_phys;          /* LEFT/RIGHT: rows per sequence in storage (data.size(1)) */

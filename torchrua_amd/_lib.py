@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported first: maps the HIP runtime our li
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RUA_LIB_PATH') or os.path.join(_HERE, 'librua_hip.so')   # env: developer A/B of builds
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 # enum rua_kind
 CAT, LEFT, PACK, RIGHT, LIST = 0, 1, 2, 3, 4
 # enum rua_tmap

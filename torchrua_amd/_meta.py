@@ -459,18 +459,52 @@ NARROW_ROW_BYTES = 64      # rows up to this get the tile table (rua_move.hip: T
 TILE_MIN_LIVE_INV = 4       # ... when at least one cell in this many is a live token
 
 
-def tile_shape_log2(row_bytes: int) -> Tuple[int, int]:
+# out of a PackedSequence (P.cat(), P.left()) the batch-major side is the one WRITTEN: taller tiles make its runs longer
+_FROM_PACK_SHAPES = {8: (7, 4), 4: (7, 5)} if os.environ.get('RUA_TILE_FROM_PACK', '1') != '0' else {}
+
+
+def tile_shape_log2(row_bytes: int, from_pack: bool = False) -> Tuple[int, int]:
     """(log2 time steps, log2 ranks) of a (rank x time) tile by row width (rua_move.hip: pack_tile_lds_kernel).  [r5] Rows
     of ONE vector below 16 bytes — 1-D payloads of 8 / 4 / 2 / 1-byte elements — get more ranks (and steps) per tile, so
     that a tile still carries 16 KiB and both sides still move runs of 128 .. 512 bytes: 32 x 64, 64 x 64, 64 x 128,
     128 x 128.  (The kernel falls back to the row mover when the payload's address is less aligned than its rows.)"""
     narrow = {8: (6, 5), 4: (6, 6), 2: (7, 6), 1: (7, 7)}.get(row_bytes)
+    if from_pack and row_bytes in _FROM_PACK_SHAPES:
+        narrow = _FROM_PACK_SHAPES[row_bytes]
     if narrow is not None:
         return narrow
     return (6 if row_bytes <= 16 else 5 if row_bytes <= 32 else 4), 4
 
 
 TILE_FULL_GRID = 1 << 24      # rua_layout::tile_t_log2: the tiles cover the whole (sequence x step) grid of a padded destination
+TILE_STEP_ROWS = 1 << 25      # ... the table counts tiles of ONE time step x (1 << trl) ranks (a roll inside a PackedSequence)
+STEP_TILE_BYTES = 16 << 10
+STEP_MAX_ROW_BYTES = 32       # wider rows roll at 5.8 - 6.3 TB/s on the row mover already
+
+
+def lay_pack_steps(p, row_bytes: int, shift: int) -> Optional['Lay']:
+    """The PACK layout of `p` with the table of one-step tiles that `P.roll(shift)` moves a PackedSequence of narrow rows
+    on (rua_move.hip: pack_roll_steps_kernel) — or None when that is not the way to go: rows wider than 32 bytes or not
+    a shift that makes most ranks wrap, or steps so short that the tiles would be mostly empty."""
+    T = p.batch_sizes.numel()
+    if not 0 < row_bytes <= STEP_MAX_ROW_BYTES or T == 0 or abs(shift) * 8 > T:
+        return None
+    trl = max(4, (STEP_TILE_BYTES // row_bytes).bit_length() - 1)
+    dev = p.data.device
+    key = f'tiling:{dev}:0:{trl}:steps'
+    t = _memo_get(p.batch_sizes, key)
+    if t is None:
+        t = _memo_put(p.batch_sizes, key, PackTiling(p.batch_sizes, pack_bsz_dev(p), dev, 0, trl))
+    n_rows = int(p.data.size(0))
+    if n_rows * TILE_MIN_LIVE_INV < (t.n_tiles << trl):
+        return None
+    lay = lay_pack(p)
+    fields = {name: getattr(lay.c, name) for name, _ in L.RuaLayout._fields_}
+    fields.update(bsz=L.ptr(t.bsz), tile_start=L.ptr(t.tile_start), n_tchunks=t.n_tchunks, n_tiles=t.n_tiles,
+                  tile_t_log2=(trl << 8) | TILE_STEP_ROWS)
+    out = Lay(list(lay.keep) + [t.bsz, t.tile_start], max_len=lay.max_len, **fields)
+    out._no_empty, out._n_empty = lay._no_empty, lay._n_empty
+    return out
 
 
 def tile_line_rows(row_bytes: int) -> int:
@@ -515,7 +549,7 @@ def pack_tiling(p, ttl: int, trl: int, line_rows: int = 1) -> 'PackTiling':
 
 def lay_pack(p, lens: Optional[Tensor] = None, len_add: int = 0, boff: Optional[Tensor] = None,
              T: Optional[int] = None, n_rows: Optional[int] = None, row_bytes: Optional[int] = None,
-             full_grid_T: Optional[int] = None) -> Lay:
+             full_grid_T: Optional[int] = None, from_pack: bool = False) -> Lay:
     lens = pack_lens(p) if lens is None else _as_lens(lens)
     boff = pack_boff(p) if boff is None else boff
     T = p.batch_sizes.numel() if T is None else T
@@ -530,13 +564,13 @@ def lay_pack(p, lens: Optional[Tensor] = None, len_add: int = 0, boff: Optional[
             and T == p.batch_sizes.numel() and len_add == 0 and T > 0):
         # [r5] the SOURCE of a pad at narrow rows (P.left() / P.right()): tiles over the destination's whole
         # (sequence x step) grid — tokens and fill in one pass; no table: every chunk holds ceil(B / ranks per tile) tiles
-        ttl, trl = tile_shape_log2(row_bytes)
+        ttl, trl = tile_shape_log2(row_bytes)          # (the taller tiles lose 1-6 % here: r5j/from_pack_ab.txt)
         nseq = pack_nseq(p)
         n_tchunks = (max(full_grid_T, T) + (1 << ttl) - 1) >> ttl
         extra.update(n_tchunks=n_tchunks, n_tiles=n_tchunks * ((nseq + (1 << trl) - 1) >> trl),
                      tile_t_log2=ttl | (trl << 8) | TILE_FULL_GRID)
     elif row_bytes is not None and 0 < row_bytes <= NARROW_ROW_BYTES and T == p.batch_sizes.numel() and len_add == 0:
-        ttl, trl = tile_shape_log2(row_bytes)
+        ttl, trl = tile_shape_log2(row_bytes, from_pack)
         t = pack_tiling(p, ttl, trl, tile_line_rows(row_bytes))       # narrow rows: hand the (rank x time) tile table to the mover ...
         # ... unless the tiles would be mostly dead cells: one giant sequence among short ones (its tail is one live rank
         # in sixteen), or a batch of singletons (one live step in 16..64).  Below a quarter of live cells the generic

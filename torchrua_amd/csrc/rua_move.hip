@@ -391,44 +391,93 @@ __global__ __launch_bounds__(RUA_BLOCK) void move_rows_narrow_kernel(rua_layout 
 // own index arithmetic: 6.3 ms for C.left() of 500 M 8-byte rows (1.9 TB/s), 4.2 ms for C.roll.  Here a wave takes
 // SEQ_PER_WAVE consecutive sequences (their lengths and offsets arrive in one coalesced load, lane i holding sequence
 // i's), and streams every run with 16-byte lanes at whatever dword-aligned address it starts (gfx950 takes a dwordx4
-// there), four vectors in flight per lane.  For rows that are a multiple of 4 bytes; the launcher takes it when no
+// there), four vectors in flight per lane; runs whose two ends are not a multiple of 4 bytes apart (rows of 1 or 2
+// bytes: bool masks, int16) go through a byte shift in registers (copy_bytes_any).  The launcher takes it when no
 // sequence can be a large share of the launch (one wave walks a whole sequence).
 constexpr int SEQ_PER_WAVE = 8;
-template <bool NT>
-__device__ __forceinline__ void wave_copy_bytes(char* __restrict__ d, const char* __restrict__ s, int64_t nbytes, int lane) {
-  constexpr int UN = 4;
+// A run of bytes copied by NTHR threads with 16-byte lanes, WHATEVER the two addresses' alignment: the destination is
+// brought to a dword boundary by a few single bytes, then every lane stores an aligned-to-4 dwordx4 assembled from FIVE
+// aligned source dwords shifted by the two addresses' distance mod 4 (v_alignbyte: rows of 1 or 2 bytes, 6, 18 ...),
+// or loaded as it is when that distance is zero (rows that are a multiple of 4 bytes).
+template <bool NT, int NTHR>
+__device__ __forceinline__ void copy_bytes_any(char* __restrict__ d, const char* __restrict__ s, int64_t nbytes, int tid) {
+  if (nbytes <= 0) return;
+  int head = (int)((4 - ((uintptr_t)d & 3)) & 3);
+  if (head > nbytes) head = (int)nbytes;
+  if (tid < head) d[tid] = s[tid];
+  d += head; s += head; nbytes -= head;
+  const int m = (int)((uintptr_t)s & 3);
+  const char* sa = s - m;                                          // dword-aligned; sa + m = s
   const int64_t nvec = nbytes >> 4;
-  for (int64_t v0 = 0; v0 < nvec; v0 += RUA_WAVE * UN) {
+  constexpr int UN = 4;
+  for (int64_t v0 = 0; v0 < nvec; v0 += NTHR * UN) {
     u32x4 x[UN];
+    uint32_t e[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const int64_t v = v0 + u * RUA_WAVE + lane;
-      if (v < nvec) x[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4*>(s + (v << 4)))
-                              : *reinterpret_cast<const u32x4_a4*>(s + (v << 4));
+      const int64_t v = v0 + u * NTHR + tid;
+      e[u] = 0;
+      if (v < nvec) {
+        x[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4*>(sa + (v << 4)))
+                  : *reinterpret_cast<const u32x4_a4*>(sa + (v << 4));
+        if (m) e[u] = *reinterpret_cast<const uint32_t*>(sa + (v << 4) + 16);      // (holds bytes of this very run)
+      }
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const int64_t v = v0 + u * RUA_WAVE + lane;
+      const int64_t v = v0 + u * NTHR + tid;
       if (v < nvec) {
-        if (NT) __builtin_nontemporal_store(x[u], reinterpret_cast<u32x4_a4*>(d + (v << 4)));
-        else *reinterpret_cast<u32x4_a4*>(d + (v << 4)) = x[u];
+        u32x4 o = x[u];
+        if (m) {
+          o.x = __builtin_amdgcn_alignbyte(x[u].y, x[u].x, m);
+          o.y = __builtin_amdgcn_alignbyte(x[u].z, x[u].y, m);
+          o.z = __builtin_amdgcn_alignbyte(x[u].w, x[u].z, m);
+          o.w = __builtin_amdgcn_alignbyte(e[u], x[u].w, m);
+        }
+        if (NT) __builtin_nontemporal_store(o, reinterpret_cast<u32x4_a4*>(d + (v << 4)));
+        else *reinterpret_cast<u32x4_a4*>(d + (v << 4)) = o;
       }
     }
   }
-  const int tail = (int)(nbytes & 15) >> 2;                          // 0 .. 3 dwords behind the last whole vector
-  if (lane < tail) *reinterpret_cast<uint32_t*>(d + (nvec << 4) + lane * 4) = *reinterpret_cast<const uint32_t*>(s + (nvec << 4) + lane * 4);
+  const int tail = (int)(nbytes & 15);
+  if (tid < tail) d[(nvec << 4) + tid] = s[(nvec << 4) + tid];
 }
 template <bool NT>
+__device__ __forceinline__ void wave_copy_bytes(char* __restrict__ d, const char* __restrict__ s, int64_t nbytes, int lane) {
+  copy_bytes_any<NT, RUA_WAVE>(d, s, nbytes, lane);
+}
+// ... and filled: the pattern repeats every element (1, 2, 4, 8 or 16 bytes) and a run starts on an element boundary, so
+// a dword-aligned vector of it is the pattern itself (elements wider than a dword: the run's start is a multiple of the
+// element, hence the vector's phase is a multiple of 4 inside the element — rotate by it), single bytes are indexed by
+// their address.
+template <bool NT>
 __device__ __forceinline__ void wave_fill_bytes(char* __restrict__ d, int64_t nbytes, u32x4 pat, int lane) {
+  if (nbytes <= 0) return;
+  // (byte k of the run holds pattern byte k mod 16: the run starts on an element boundary and 16 is a multiple of it)
+  auto pat_byte = [&](int k) -> char {
+    const uint32_t w = (k & 8) ? ((k & 4) ? pat.w : pat.z) : ((k & 4) ? pat.y : pat.x);
+    return (char)(w >> (8 * (k & 3)));
+  };
+  int head = (int)((4 - ((uintptr_t)d & 3)) & 3);
+  if (head > nbytes) head = (int)nbytes;
+  if (lane < head) d[lane] = pat_byte(lane & 15);
+  char* d4 = d + head;
+  nbytes -= head;
+  u32x4 rot = pat;                                                 // the pattern as seen from byte `head` of the run
+  if (head) {
+    const uint32_t w[4] = {pat.x, pat.y, pat.z, pat.w};
+    rot.x = __builtin_amdgcn_alignbyte(w[1], w[0], head);
+    rot.y = __builtin_amdgcn_alignbyte(w[2], w[1], head);
+    rot.z = __builtin_amdgcn_alignbyte(w[3], w[2], head);
+    rot.w = __builtin_amdgcn_alignbyte(w[0], w[3], head);
+  }
   const int64_t nvec = nbytes >> 4;
   for (int64_t v = lane; v < nvec; v += RUA_WAVE) {
-    if (NT) __builtin_nontemporal_store(pat, reinterpret_cast<u32x4_a4*>(d + (v << 4)));
-    else *reinterpret_cast<u32x4_a4*>(d + (v << 4)) = pat;
+    if (NT) __builtin_nontemporal_store(rot, reinterpret_cast<u32x4_a4*>(d4 + (v << 4)));
+    else *reinterpret_cast<u32x4_a4*>(d4 + (v << 4)) = rot;
   }
-  const int tail = (int)(nbytes & 15) >> 2;
-  // (the pattern repeats every element and a run starts on an element boundary; elements wider than a dword keep
-  // their phase because a run's length in bytes is a multiple of the element too)
-  if (lane < tail) *reinterpret_cast<uint32_t*>(d + (nvec << 4) + lane * 4) = pat[lane & 3];
+  const int tail = (int)(nbytes & 15);
+  if (lane < tail) d4[(nvec << 4) + lane] = pat_byte((head + lane) & 15);
 }
 
 template <bool NT>
@@ -535,10 +584,13 @@ struct TileTables {
   int64_t olen[TR_MAX];   // the sequence's length (0: no such sequence)
   int shift[TR_MAX];      // the rank's time shift s in [0, R)
   int64_t ofill[TR_MAX];  // padded destination (full-grid tiles): storage row of the sequence's slot 0, -1: no such sequence
+  int nlive_t[TR_MAX];    // [r5] steps of the tile the rank's sequence holds a token at: clamp(len - t0, 0, TT), clipped to the storage
+  int nlive_r[TT_MAX + TILE_SHIFT_MAX];   // ranks of the tile alive at the step: clamp(bsz - r0, 0, TR), clipped to the storage
   int64_t pboff[TT_MAX + TILE_SHIFT_MAX];  // first PackedSequence row of time step t0 - (R - 1) + k
   int64_t pbsz[TT_MAX + TILE_SHIFT_MAX];   // sequences alive at that step (0 before 0 and past T)
 };
 constexpr int TILE_FULL_GRID = 1 << 24;   // rua_layout::tile_t_log2 bit 24: tiles cover the whole (sequence x step) grid
+constexpr int TILE_STEP_ROWS = 1 << 25;   // ... bit 25: tiles of ONE time step x (1 << bits 8-15) ranks (pack_roll_steps_kernel)
 
 template <int TTL, int TRL>
 __device__ __forceinline__ void tile_tables(const rua_layout& Pk, const rua_layout& Ot, int64_t tile, TileTables& tb,
@@ -588,13 +640,20 @@ __device__ __forceinline__ void tile_tables(const rua_layout& Pk, const rua_layo
     tb.obase[i] = base - s + t0;                  // batch-major row of the rank's window start (a whole-line boundary)
     tb.olen[i] = len;
     tb.ofill[i] = slot0;
+    int64_t nl = len - t0;                          // (plain windows only: the callers that shift do not read these)
+    if (Ot.n_rows - (base + t0) < nl) nl = Ot.n_rows - (base + t0);
+    tb.nlive_t[i] = nl < 0 ? 0 : nl > TT ? TT : (int)nl;
   }
   // the time steps t0 - (R - 1) .. t0 + TT - 1 (threads from the far end: the first ones hold a rank already)
   for (int k = RUA_BLOCK - 1 - (int)threadIdx.x; k < TT + R - 1; k += RUA_BLOCK) {
     const int64_t t = t0 - (R - 1) + k;
     const bool ok = t >= 0 && t < Pk.T;
-    tb.pboff[k] = ok ? Pk.boff[t] : 0;
+    const int64_t first = ok ? Pk.boff[t] : 0;
+    tb.pboff[k] = first;
     tb.pbsz[k] = ok ? Pk.bsz[t] : 0;
+    int64_t nl = tb.pbsz[k] - r0;
+    if (Pk.n_rows - (first + r0) < nl) nl = Pk.n_rows - (first + r0);
+    tb.nlive_r[k] = nl < 0 ? 0 : nl > TR ? TR : (int)nl;
   }
 }
 
@@ -721,9 +780,8 @@ __global__ __launch_bounds__(RUA_BLOCK) void pack_tile_vec_kernel(rua_layout Pk,
   const bool padded = (Pk.tile_t_log2 & TILE_FULL_GRID) != 0;
   Vec fillv;
   fillv.v = fill_of<16>(fillpat);
-  const int64_t on = Ot.n_rows, pn = Pk.n_rows;
   // cell (rank, j): step t0 + j of the rank's sequence; batch-major row obase[rank] + j, PackedSequence row pboff[j] + r0 + rank
-#define RUA_LIVE(rank, j) (t0 + (j) < tb.olen[rank] && r0 + (rank) < tb.pbsz[j] && tb.obase[rank] + (j) < on && tb.pboff[j] + r0 + (rank) < pn)
+#define RUA_LIVE(rank, j) ((j) < tb.nlive_t[rank] && (rank) < tb.nlive_r[j])
 #define RUA_STG(rank, j) stage[(rank) * (TT + 1) + (j)]
   // ---- the batch-major side: a group = CPL consecutive steps of one rank
   auto major_pass = [&](auto&& both, auto&& one) {
@@ -851,6 +909,64 @@ __global__ __launch_bounds__(RUA_BLOCK) void pack_roll_tile_kernel(rua_layout Pk
   }
 }
 
+// [r5] roll INSIDE one PackedSequence at narrow rows, time step by time step.  out[boff[t] + r] = in[boff[ts] + r] with
+// ts = (t - s) mod len_r: for every rank that does not wrap at step t, ts = t - s is the SAME step, and those ranks are a
+// prefix [0, bsz[max(t, ts)]) — so a step's rows are ONE contiguous run copied from ONE contiguous run, plus the few
+// ranks that wrap (those whose sequence ends between the two steps; all ranks of the first |s| steps), which are
+// gathered row by row.  A tile = one time step x (16 KiB / row bytes) ranks (the host's table: rua_layout::tile_start
+// with TILE_STEP_ROWS set), moved with 16 bytes per lane whatever the row width.  The row kernels resolve every row by
+// itself: 5.2 ms for 500 M 8-byte rows (1.5 TB/s).
+template <bool NT>
+__global__ __launch_bounds__(RUA_BLOCK) void pack_roll_steps_kernel(rua_layout Pk, int64_t shift, char* __restrict__ dst,
+                                                                    const char* __restrict__ src, int64_t rb, int trl,
+                                                                    int64_t tiles_per_xcd) {
+  int64_t tile = blockIdx.x;
+  if (tiles_per_xcd > 0) {
+    tile = (int64_t)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= tiles_per_xcd) return;
+  }
+  if (tile >= Pk.n_tiles) return;
+  int64_t t = 0, hi = Pk.n_tchunks;                       // largest t with tile_start[t] <= tile (block-uniform)
+  while (hi - t > 1) {
+    const int64_t mid = (t + hi) >> 1;
+    if (Pk.tile_start[mid] <= tile) t = mid; else hi = mid;
+  }
+  const int64_t r0 = (tile - Pk.tile_start[t]) << trl;
+  int64_t n = Pk.bsz[t] - r0;
+  if (n > ((int64_t)1 << trl)) n = (int64_t)1 << trl;
+  const int64_t drow0 = Pk.boff[t] + r0;
+  if (n <= 0 || drow0 + n > Pk.n_rows) return;
+  // the ranks that do not wrap: alive at step ts = t - shift as well (a prefix of the ranks)
+  const int64_t ts = t - shift;
+  int64_t nd = 0, srow0 = 0;
+  if (ts >= 0 && ts < Pk.T) {
+    nd = Pk.bsz[ts] - r0;
+    if (nd > n) nd = n;
+    if (nd < 0) nd = 0;
+    srow0 = Pk.boff[ts] + r0;
+    if (srow0 + nd > Pk.n_rows) nd = 0;
+  }
+  if (nd > 0) copy_bytes_any<NT, RUA_BLOCK>(dst + drow0 * rb, src + srow0 * rb, nd * rb, threadIdx.x);
+  // the ranks that wrap at this step, one row per thread
+  const bool dw4 = (rb & 3) == 0 && (((uintptr_t)dst | (uintptr_t)src) & 3) == 0;
+  for (int64_t i = nd + threadIdx.x; i < n; i += RUA_BLOCK) {
+    const int64_t r = r0 + i;
+    int64_t lo = 0, hh = Pk.T;                             // len = #{t : bsz[t] > r}
+    while (lo < hh) {
+      const int64_t mid = (lo + hh) >> 1;
+      if (Pk.bsz[mid] > r) lo = mid + 1; else hh = mid;
+    }
+    const int64_t tsr = apply_tmap(RUA_T_ROLL, shift, t, lo, lo);
+    if (tsr < 0 || tsr >= lo) continue;
+    const int64_t srow = Pk.boff[tsr] + r;
+    if (srow >= Pk.n_rows) continue;
+    const char* sp = src + srow * rb;
+    char* dp = dst + (drow0 + i) * rb;
+    if (dw4) { for (int w = 0; w < (int)(rb >> 2); ++w) reinterpret_cast<uint32_t*>(dp)[w] = reinterpret_cast<const uint32_t*>(sp)[w]; }
+    else { for (int w = 0; w < (int)rb; ++w) dp[w] = sp[w]; }
+  }
+}
+
 static int launch_roll_tiles(int vec, hipStream_t s, const rua_layout& Pk, int32_t tmap, int64_t targ, char* dst,
                              const char* src, int64_t row_bytes, uint4 fp, bool xcd_span) {
   const int64_t per_xcd = xcd_span ? (Pk.n_tiles + 7) / 8 : 0;
@@ -871,6 +987,7 @@ static int launch_roll_tiles(int vec, hipStream_t s, const rua_layout& Pk, int32
 // the tile shapes beyond 16 ranks: rows of ONE vector below 16 bytes (see launch_pack_tiles)
 static inline bool tile_shape_narrow(int vec, int64_t lpr, int ttl, int trl) {
   return lpr == 1 && ((vec == 8 && trl == 5 && ttl == 6) || (vec == 4 && trl == 6 && ttl == 6) ||
+                      (vec == 8 && trl == 4 && ttl == 7) || (vec == 4 && trl == 5 && ttl == 7) ||   // out of a PackedSequence
                       (vec == 2 && trl == 6 && ttl == 7) || (vec == 1 && trl == 7 && ttl == 7));
 }
 static inline bool tile_shape_exists(int vec, int64_t row_bytes, int code) {
@@ -922,8 +1039,14 @@ static int launch_pack_tiles(int vec, hipStream_t s, const rua_layout& Pk, const
   }
   if (shape_narrow) {
     switch (vec) {
-      case 8: hipLaunchKernelGGL((pack_tile_vec_kernel<8, TO_PACK, 6, 5>), g, b, 0, s, Pk, Ot, dst, src, per_xcd, fp); break;
-      case 4: hipLaunchKernelGGL((pack_tile_vec_kernel<4, TO_PACK, 6, 6>), g, b, 0, s, Pk, Ot, dst, src, per_xcd, fp); break;
+      // (the taller tiles — 16 x 128 at 8 bytes, 32 x 128 at 4 — are what the host asks for OUT of a PackedSequence: the
+      // batch-major side is then the one written, and its runs are 1 KiB / 512 B instead of 512 / 256)
+      case 8: if (ttl == 7) hipLaunchKernelGGL((pack_tile_vec_kernel<8, TO_PACK, 7, 4>), g, b, 0, s, Pk, Ot, dst, src, per_xcd, fp);
+              else hipLaunchKernelGGL((pack_tile_vec_kernel<8, TO_PACK, 6, 5>), g, b, 0, s, Pk, Ot, dst, src, per_xcd, fp);
+              break;
+      case 4: if (ttl == 7) hipLaunchKernelGGL((pack_tile_vec_kernel<4, TO_PACK, 7, 5>), g, b, 0, s, Pk, Ot, dst, src, per_xcd, fp);
+              else hipLaunchKernelGGL((pack_tile_vec_kernel<4, TO_PACK, 6, 6>), g, b, 0, s, Pk, Ot, dst, src, per_xcd, fp);
+              break;
       case 2: RUA_LAUNCH_T(2, 7, 6); break;
       default: RUA_LAUNCH_T(1, 7, 7); break;
     }
@@ -1089,7 +1212,8 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
     // (a table built for a tile shape this vector width has no kernel for — rows of 8 bytes at a base that is only
     // 4-byte aligned, say — is simply not used)
     if ((to_pack || from_pack) && (pk->tile_start || full_grid) && pk->bsz && pk->n_tiles > 0 && pk->boff &&
-        (!full_grid || (!to_pack && dst->kind != RUA_CAT)) && tile_shape_exists(vec, row_bytes, pk->tile_t_log2)) {
+        (!full_grid || (!to_pack && dst->kind != RUA_CAT)) && !(pk->tile_t_log2 & TILE_STEP_ROWS) &&
+        tile_shape_exists(vec, row_bytes, pk->tile_t_log2)) {
       bool span = pk->n_tiles >= (to_pack || full_grid ? MOVE_SPAN_MIN_TILES : TILE_SPAN_MIN_TILES_FROM_PACK);
       if (flags & RUA_MOVE_XCD_SPAN_ON) span = true;
       if (flags & RUA_MOVE_XCD_SPAN_OFF) span = false;
@@ -1122,7 +1246,23 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
   bool xcd_span = (nr + tile_rows - 1) / tile_rows >= (padded_dst ? MOVE_SPAN_MIN_TILES : MOVE_SPAN_MIN_TILES_DENSE);
   if (flags & RUA_MOVE_XCD_SPAN_ON) xcd_span = true;
   if (flags & RUA_MOVE_XCD_SPAN_OFF) xcd_span = false;
-  // [r5] narrow rows between two batch-major layouts, rows a multiple of 4 bytes: the segmented memcpy (seq_copy_kernel)
+  // [r5] a roll inside one PackedSequence, time step by time step, when the caller handed over the table of one-step tiles
+  if (dst->kind == RUA_PACK && src->kind == RUA_PACK && (dst->tile_t_log2 & TILE_STEP_ROWS) && dst->tile_start && dst->bsz &&
+      dst->boff && dst->boff == src->boff && dst->sorted == src->sorted && dst->len_add == 0 && src->len_add == 0 &&
+      dst->T == src->T && dst->T > 0 && dst->n_tchunks == dst->T && dst->n_tiles > 0 && tmap == RUA_T_ROLL && pad_row < 0 &&
+      (flags & ~(RUA_MOVE_XCD_SPAN_ON | RUA_MOVE_XCD_SPAN_OFF)) == 0) {
+    bool span = dst->n_tiles >= MOVE_SPAN_MIN_TILES_DENSE;
+    if (flags & RUA_MOVE_XCD_SPAN_ON) span = true;
+    if (flags & RUA_MOVE_XCD_SPAN_OFF) span = false;
+    const int64_t per_xcd = span ? (dst->n_tiles + 7) / 8 : 0;
+    const int64_t grid = span ? per_xcd * 8 : dst->n_tiles;
+    if (grid > 0x7fffffffLL) return RUA_ERANGE;
+    const int trl = (dst->tile_t_log2 >> 8) & 0xff;
+    if (nt) hipLaunchKernelGGL(pack_roll_steps_kernel<true>, dim3((unsigned)grid), dim3(RUA_BLOCK), 0, s, *dst, tmap_arg, d, c, row_bytes, trl, per_xcd);
+    else hipLaunchKernelGGL(pack_roll_steps_kernel<false>, dim3((unsigned)grid), dim3(RUA_BLOCK), 0, s, *dst, tmap_arg, d, c, row_bytes, trl, per_xcd);
+    return (int)hipGetLastError();
+  }
+  // [r5] narrow rows between two batch-major layouts: the segmented memcpy (seq_copy_kernel)
   {
     const bool major_d = dst->kind == RUA_CAT || dst->kind == RUA_LEFT || dst->kind == RUA_RIGHT;
     const bool major_s = src->kind == RUA_CAT || src->kind == RUA_LEFT || src->kind == RUA_RIGHT;
@@ -1134,8 +1274,7 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
     const int64_t longest = long_d > long_s ? long_d : long_s;
     const bool balanced = long_d > 0 && long_s > 0 && dst->B >= 4096 && longest <= nr / 1024;
     if (major_d && major_s && !(flags & (RUA_MOVE_SCATTER | RUA_MOVE_NO_NARROW)) && tsel == 0 && pad_row < 0 &&
-        row_bytes <= 64 && (row_bytes & 3) == 0 && (((uintptr_t)dst_data | (uintptr_t)src_data) & 3) == 0 &&
-        dst->B == src->B && (tmap == RUA_T_SHIFT || (tmap == RUA_T_ROLL && same_lens)) && balanced &&
+        row_bytes <= 64 && dst->B == src->B && (tmap == RUA_T_SHIFT || (tmap == RUA_T_ROLL && same_lens)) && balanced &&
         (dst->kind != RUA_CAT || dst->off || !dst->lens) && (src->kind != RUA_CAT || src->off || !src->lens)) {
       const int64_t waves = (dst->B + SEQ_PER_WAVE - 1) / SEQ_PER_WAVE;
       const int64_t grid = (waves + RUA_WAVES_PER_BLOCK - 1) / RUA_WAVES_PER_BLOCK;
@@ -1154,6 +1293,7 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
     if (flags & RUA_MOVE_XCD_SPAN_ON) span = true;
     if (flags & RUA_MOVE_XCD_SPAN_OFF) span = false;
     const bool roll_tiles = vec == 16 && dst->kind == RUA_PACK && src->kind == RUA_PACK && dst->tile_start && dst->bsz &&
+                            !(dst->tile_t_log2 & TILE_STEP_ROWS) &&
                             dst->boff == src->boff && !(flags & RUA_MOVE_SCATTER);
     if (!roll_tiles) {
       if (flags & RUA_MOVE_SCATTER)
@@ -1171,7 +1311,7 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
                                 dst->bsz && dst->boff && dst->boff == src->boff && dst->sorted == src->sorted &&
                                 dst->len_add == 0 && src->len_add == 0 && dst->T == src->T && dst->T > 0;
   // ... and on the (rank x time) tiles when the caller handed the tile table over (pack_roll_tile_kernel)
-  if (narrow_same_pack && dst->tile_start && dst->n_tiles > 0 && dst->lens && dst->sorted &&
+  if (narrow_same_pack && dst->tile_start && !(dst->tile_t_log2 & TILE_STEP_ROWS) && dst->n_tiles > 0 && dst->lens && dst->sorted &&
       pad_row < 0 && (flags & ~(RUA_MOVE_XCD_SPAN_ON | RUA_MOVE_XCD_SPAN_OFF)) == 0 &&
       (tmap == RUA_T_ROLL || tmap == RUA_T_REV_S || tmap == RUA_T_REV_D || tmap == RUA_T_SHIFT)) {
     bool span = dst->n_tiles >= MOVE_SPAN_MIN_TILES;

@@ -92,6 +92,9 @@ def _same_layout_move(self: Z, tmap: int, arg: int, name: str, pad_row: int = -1
             M.adopt_pack(shell, lens, boff, bsz_dev)
             dst = M.lay_pack(shell, lens=lens, boff=boff, n_rows=int(self.data.size(0)))
             return shell._replace(data=O.move(self.data, O.MovePlan(dst, lay, self.data.shape, tmap, arg, name=name)))
+        if isinstance(self, P) and tmap == K.T_ROLL:
+            # narrow rows: every time step's rows move as ONE run (the ranks that wrap apart) — _meta.lay_pack_steps
+            lay = M.lay_pack_steps(self, M.row_bytes(self.data, 1), arg) or lay
         plan = O.MovePlan(lay, lay, self.data.shape, tmap, arg, name=name)
     return self._replace(data=O.move(self.data, plan))
 
