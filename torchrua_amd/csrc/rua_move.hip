@@ -333,6 +333,107 @@ __global__ __launch_bounds__(BLOCK) void move_rows_kernel(rua_layout D, rua_layo
 }
 
 // ---------------------------------------------------------------------------------------------
+// [r5] GATHERS of rows that are a multiple of 4 but not of 16 bytes (H = 500 in bf16: 1 000-byte rows; 500-byte rows in
+// fp32 ...).  Such rows start off 16-byte boundaries, and a row-granular mover moves them with misaligned 16-byte lanes on
+// both sides: 4.0 TB/s for the pack at 1 000-byte rows, 4.3 even for a streaming copy, where 1 024-byte rows move at
+// 6.0 - 6.3.  But a tile of consecutive DESTINATION rows is ONE contiguous span of bytes that starts on a 16-byte boundary
+// (the tile holds a multiple of 16 rows).  So the tile goes through LDS: every source row is fetched with ALIGNED 16-byte
+// loads — the aligned vectors that overlap it, its first and last vector holding a few bytes of its neighbours — and laid
+// down in LDS at its own offset in dword pieces; then the whole span is stored with aligned 16-byte lanes.  Fill rows are
+// laid down as the pattern.  Both sides of HBM see aligned full lanes; what is off-boundary happens inside LDS.
+constexpr int SPAN_TILE_BYTES = 16 << 10;
+template <bool NT>
+__global__ __launch_bounds__(RUA_BLOCK) void move_rows_span_kernel(rua_layout D, rua_layout S, int32_t tmap, int64_t targ,
+                                                                   char* __restrict__ dst, const char* __restrict__ src,
+                                                                   int rb, int tile_rows, uint4 fillpat, int64_t pad_row,
+                                                                   int64_t tiles_per_xcd) {
+  __shared__ int64_t s_ld[RUA_BLOCK];
+  __shared__ __attribute__((aligned(16))) uint32_t stage[SPAN_TILE_BYTES / 4];
+  int64_t tile = blockIdx.x;
+  if (tiles_per_xcd > 0) tile = (int64_t)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+  const int64_t tile0 = tile * tile_rows;
+  const int64_t left = D.n_rows - tile0;
+  if (left <= 0 || (tiles_per_xcd > 0 && (int64_t)(blockIdx.x >> 3) >= tiles_per_xcd)) return;
+  const int nrows = left < tile_rows ? (int)left : tile_rows;
+  const bool same_pack = D.kind == RUA_PACK && S.kind == RUA_PACK && D.bsz && D.boff == S.boff && D.sorted == S.sorted &&
+                         D.len_add == 0 && S.len_add == 0 && D.T == S.T;
+  {
+    const int i = threadIdx.x, lane1 = threadIdx.x & (RUA_WAVE - 1), w0 = i - lane1;
+    const int nw = nrows - w0 < RUA_WAVE ? nrows - w0 : RUA_WAVE;
+    if (nw > 0) {
+      const int64_t other = resolve_wave_rows<false>(D, S, tmap, targ, pad_row, tile0 + w0, nw, lane1, same_pack);
+      if (i < nrows) s_ld[i] = other;
+    }
+  }
+  __syncthreads();
+  // ---- the rows into LDS: item = (row, aligned 16-byte vector l of the source that overlaps it)
+  const int vpr = ((rb + 12) >> 4) + 1;                     // vectors that can overlap a row that starts 0 .. 12 bytes in
+  const int n_items = nrows * vpr;
+  const uint32_t pat[4] = {fillpat.x, fillpat.y, fillpat.z, fillpat.w};
+  constexpr int UN = 4;
+  for (int it0 = threadIdx.x; it0 < n_items; it0 += RUA_BLOCK * UN) {
+    u32x4 x[UN];
+    int k0[UN], base[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int idx = it0 + u * RUA_BLOCK;
+      k0[u] = -1000000;                                     // (nothing to lay down)
+      if (idx >= n_items) continue;
+      const int row = idx / vpr, l = idx - row * vpr;
+      const int64_t ld = s_ld[row];
+      base[u] = row * rb;
+      if (ld < 0) {                                         // a fill row: the pattern, phase = the row's own offset
+        if ((l << 4) < rb) { k0[u] = l << 4; x[u] = u32x4{pat[0], pat[1], pat[2], pat[3]}; }
+        continue;
+      }
+      const int64_t A = ld * (int64_t)rb;
+      const int shift = (int)(A & 15);
+      const int kk = (l << 4) - shift;                      // the vector holds bytes kk .. kk + 15 of the row
+      if (kk >= rb || kk + 16 <= 0) continue;
+      const char* p = src + (A - shift) + ((int64_t)l << 4);
+      if (kk + 16 <= rb || ld + 1 < S.n_rows) {             // (the bytes behind the row belong to the next row: readable)
+        x[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)) : *reinterpret_cast<const u32x4*>(p);
+      } else {                                              // the storage's last row: stop at its end
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int q = 0; q < 4; ++q) if (kk + 4 * q < rb) w[q] = reinterpret_cast<const uint32_t*>(p)[q];
+        x[u] = u32x4{w[0], w[1], w[2], w[3]};
+      }
+      k0[u] = kk;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (k0[u] < -16) continue;
+      const uint32_t w[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+      if (((k0[u] | rb | base[u]) & 7) == 0) {              // 8-byte pieces (rows of 8 mod 16 bytes: always)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int k = k0[u] + 8 * q;
+          if (k >= 0 && k < rb) *reinterpret_cast<u32x2*>(&stage[(base[u] + k) >> 2]) = u32x2{w[2 * q], w[2 * q + 1]};
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int k = k0[u] + 4 * q;
+          if (k >= 0 && k < rb) stage[(base[u] + k) >> 2] = w[q];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- the span out: aligned 16-byte lanes
+  const int nbytes = nrows * rb;
+  char* d = dst + tile0 * (int64_t)rb;
+  const int nvec = nbytes >> 4;
+  for (int v = threadIdx.x; v < nvec; v += RUA_BLOCK) {
+    const u32x4 o = *reinterpret_cast<const u32x4*>(&stage[v << 2]);
+    if (NT) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(d + (v << 4)));
+    else *reinterpret_cast<u32x4*>(d + (v << 4)) = o;
+  }
+  const int tail = (nbytes & 15) >> 2;
+  if ((int)threadIdx.x < tail) reinterpret_cast<uint32_t*>(d + (nvec << 4))[threadIdx.x] = stage[(nvec << 2) + threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------------
 // [r5] Rows of ONE vector — 1, 2, 4, 8 or 16 bytes: 1-D payloads (int64 token ids, fp32 scalars, bool masks), the
 // commonest thing `C.new([...]).left()` is called on.  The generic kernel gives such a row a lane in phase 1 and a lane in
 // phase 2 and a workgroup 256 rows: 2 KiB per workgroup at 8-byte rows behind a chain of dependent index loads — 5.8 ms
@@ -394,11 +495,12 @@ __global__ __launch_bounds__(RUA_BLOCK) void move_rows_narrow_kernel(rua_layout 
 // there), four vectors in flight per lane; runs whose two ends are not a multiple of 4 bytes apart (rows of 1 or 2
 // bytes: bool masks, int16) go through a byte shift in registers (copy_bytes_any).  The launcher takes it when no
 // sequence can be a large share of the launch (one wave walks a whole sequence).
-constexpr int SEQ_PER_WAVE = 8;
+constexpr int SEQ_PER_WAVE = 8;        // at narrow rows; rows from 256 bytes up (odd widths) give a wave ONE sequence
 // A run of bytes copied by NTHR threads with 16-byte lanes, WHATEVER the two addresses' alignment: the destination is
 // brought to a dword boundary by a few single bytes, then every lane stores an aligned-to-4 dwordx4 assembled from FIVE
 // aligned source dwords shifted by the two addresses' distance mod 4 (v_alignbyte: rows of 1 or 2 bytes, 6, 18 ...),
-// or loaded as it is when that distance is zero (rows that are a multiple of 4 bytes).
+// or loaded as it is when that distance is zero (rows that are a multiple of 4 bytes).  (Aligning BOTH sides to 16 bytes —
+// two aligned loads per lane and a shift — was measured and is slower: C.left() of 8-byte rows 2.3 -> 3.6 ms, r5n.)
 template <bool NT, int NTHR>
 __device__ __forceinline__ void copy_bytes_any(char* __restrict__ d, const char* __restrict__ s, int64_t nbytes, int tid) {
   if (nbytes <= 0) return;
@@ -409,7 +511,7 @@ __device__ __forceinline__ void copy_bytes_any(char* __restrict__ d, const char*
   const int m = (int)((uintptr_t)s & 3);
   const char* sa = s - m;                                          // dword-aligned; sa + m = s
   const int64_t nvec = nbytes >> 4;
-  constexpr int UN = 4;
+  constexpr int UN = NTHR == RUA_WAVE ? 8 : 4;          // vectors in flight per lane
   for (int64_t v0 = 0; v0 < nvec; v0 += NTHR * UN) {
     u32x4 x[UN];
     uint32_t e[UN];
@@ -483,13 +585,13 @@ __device__ __forceinline__ void wave_fill_bytes(char* __restrict__ d, int64_t nb
 template <bool NT>
 __global__ __launch_bounds__(RUA_BLOCK) void seq_copy_kernel(rua_layout D, rua_layout S, int32_t tmap, int64_t targ,
                                                              char* __restrict__ dst, const char* __restrict__ src,
-                                                             int64_t rb, uint4 fillpat) {
+                                                             int64_t rb, uint4 fillpat, int spw) {
   const int lane = threadIdx.x & (RUA_WAVE - 1);
   const int64_t wave_id = ((int64_t)blockIdx.x * RUA_BLOCK + threadIdx.x) >> 6;
-  const int64_t b0 = wave_id * SEQ_PER_WAVE;
+  const int64_t b0 = wave_id * spw;
   if (b0 >= D.B) return;                                            // wave-uniform
   const int64_t bl = b0 + lane;
-  const bool have = lane < SEQ_PER_WAVE && bl < D.B;
+  const bool have = lane < spw && bl < D.B;
   int64_t my_dlen = 0, my_slen = 0, my_dbase = 0, my_sbase = 0;
   if (have) {
     my_dlen = seq_len(D, bl);
@@ -502,7 +604,7 @@ __global__ __launch_bounds__(RUA_BLOCK) void seq_copy_kernel(rua_layout D, rua_l
   const u32x4 pat = fill_of<16>(fillpat);
   const bool padded = D.kind == RUA_LEFT || D.kind == RUA_RIGHT;
 #pragma unroll 1
-  for (int i = 0; i < SEQ_PER_WAVE; ++i) {
+  for (int i = 0; i < spw; ++i) {
     const int64_t b = b0 + i;
     if (b >= D.B) break;                                            // wave-uniform
     int64_t dlen = __shfl(my_dlen, i, RUA_WAVE), slen = __shfl(my_slen, i, RUA_WAVE);
@@ -1273,14 +1375,19 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
     const int64_t long_s = src->kind == RUA_CAT ? src->T_log : src->T_phys;
     const int64_t longest = long_d > long_s ? long_d : long_s;
     const bool balanced = long_d > 0 && long_s > 0 && dst->B >= 4096 && longest <= nr / 1024;
+    // (rows wider than 64 bytes that are not a multiple of 16 were tried here too: one wave per sequence streams at the
+    // walk's 4.5 - 5.4 TB/s whatever the alignment, below what tiles in destination order give: move_rows_span_kernel)
     if (major_d && major_s && !(flags & (RUA_MOVE_SCATTER | RUA_MOVE_NO_NARROW)) && tsel == 0 && pad_row < 0 &&
         row_bytes <= 64 && dst->B == src->B && (tmap == RUA_T_SHIFT || (tmap == RUA_T_ROLL && same_lens)) && balanced &&
         (dst->kind != RUA_CAT || dst->off || !dst->lens) && (src->kind != RUA_CAT || src->off || !src->lens)) {
-      const int64_t waves = (dst->B + SEQ_PER_WAVE - 1) / SEQ_PER_WAVE;
+      // sequences per wave: about 16 KiB of tokens (8 at narrow rows, 1 from a few hundred bytes per row up)
+      const int64_t seq_bytes = nr / (dst->B > 0 ? dst->B : 1) * row_bytes;
+      const int spw = seq_bytes >= 8192 ? 1 : seq_bytes >= 4096 ? 2 : seq_bytes >= 2048 ? 4 : SEQ_PER_WAVE;
+      const int64_t waves = (dst->B + spw - 1) / spw;
       const int64_t grid = (waves + RUA_WAVES_PER_BLOCK - 1) / RUA_WAVES_PER_BLOCK;
       if (grid > 0x7fffffffLL) return RUA_ERANGE;
-      if (nt) hipLaunchKernelGGL(seq_copy_kernel<true>, dim3((unsigned)grid), dim3(RUA_BLOCK), 0, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp);
-      else hipLaunchKernelGGL(seq_copy_kernel<false>, dim3((unsigned)grid), dim3(RUA_BLOCK), 0, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp);
+      if (nt) hipLaunchKernelGGL(seq_copy_kernel<true>, dim3((unsigned)grid), dim3(RUA_BLOCK), 0, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, spw);
+      else hipLaunchKernelGGL(seq_copy_kernel<false>, dim3((unsigned)grid), dim3(RUA_BLOCK), 0, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, spw);
       return (int)hipGetLastError();
     }
   }
@@ -1318,6 +1425,26 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
     if (flags & RUA_MOVE_XCD_SPAN_ON) span = true;
     if (flags & RUA_MOVE_XCD_SPAN_OFF) span = false;
     return launch_roll_tiles(vec, s, *dst, tmap, tmap_arg, d, c, row_bytes, fp, span);
+  }
+  // [r5] a gather of rows that are a multiple of 4 but not of 16 bytes: the destination tile goes through LDS and leaves as
+  // one aligned span (move_rows_span_kernel)
+  if ((row_bytes & 15) != 0 && (row_bytes & 3) == 0 && row_bytes >= 64 && row_bytes <= SPAN_TILE_BYTES / 4 &&
+      ((uintptr_t)dst_data & 15) == 0 && ((uintptr_t)src_data & 15) == 0 && tsel == 0 && !(flags & RUA_MOVE_NO_TAIL8)) {
+    // rows per tile: a multiple of 2 (rows of 8 mod 16 bytes) or 4 (4 / 12 mod 16), so that every tile starts on a
+    // 16-byte boundary; as many as fit 16 KiB of LDS (16 rows of 1 000 bytes, 8 of 2 000), one resolving lane each
+    const int step = (row_bytes & 7) ? 4 : 2;
+    int trows = (int)(SPAN_TILE_BYTES / row_bytes) / step * step;
+    if (trows > RUA_BLOCK) trows = RUA_BLOCK / step * step;
+    const int64_t ntiles = (nr + trows - 1) / trows;
+    bool span = ntiles >= (padded_dst ? MOVE_SPAN_MIN_TILES : MOVE_SPAN_MIN_TILES_DENSE);
+    if (flags & RUA_MOVE_XCD_SPAN_ON) span = true;
+    if (flags & RUA_MOVE_XCD_SPAN_OFF) span = false;
+    const int64_t per_xcd = span ? (ntiles + 7) / 8 : 0;
+    const int64_t grid = span ? per_xcd * 8 : ntiles;
+    if (grid > 0x7fffffffLL) return RUA_ERANGE;
+    if (nt) hipLaunchKernelGGL(move_rows_span_kernel<true>, dim3((unsigned)grid), dim3(RUA_BLOCK), 0, s, *dst, *src, tmap, tmap_arg, d, c, (int)row_bytes, trows, fp, pad_row, per_xcd);
+    else hipLaunchKernelGGL(move_rows_span_kernel<false>, dim3((unsigned)grid), dim3(RUA_BLOCK), 0, s, *dst, *src, tmap, tmap_arg, d, c, (int)row_bytes, trows, fp, pad_row, per_xcd);
+    return (int)hipGetLastError();
   }
   return nt ? launch_move<false, true>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, narrow_same_pack, tile_rows, xcd_span, tail8)
             : launch_move<false, false>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, narrow_same_pack, tile_rows, xcd_span, tail8);
