@@ -165,3 +165,26 @@ def test_dtype_and_device_movers():
         out = z.to(dtype=torch.bfloat16, device=torch.device('cpu'))
         assert type(out) is cls and out.data.dtype == torch.bfloat16 and out.data.device.type == 'cpu'
         assert type(z.cpu()) is cls and not z.detach().data.requires_grad and z.detach().data.data_ptr() == z.data.data_ptr()
+
+
+def test_launches_follow_the_tensors_device(monkeypatch):
+    """torch (and so the reference) runs an op on the device its tensors live on, whatever the thread's
+    current device; a HIP launch goes to the current device, so `_lib.stream_ptr` makes the tensors' device current
+    for the ONE launch and `_lib.check` — which wraps every launch — hands the old one back, also when the launch fails."""
+    import pytest
+    import torch
+    from torchrua_amd import _lib
+    state, calls = {'cur': 0}, []
+    monkeypatch.setattr(torch.cuda, 'current_device', lambda: state['cur'])
+    monkeypatch.setattr(torch.cuda, 'set_device', lambda d: (calls.append(d), state.__setitem__('cur', d)))
+    monkeypatch.setattr(torch._C, '_cuda_getCurrentRawStream', lambda idx: 1000 + idx)
+    assert _lib.stream_ptr(torch.device('cuda', 1)) == 1001 and state['cur'] == 1 and calls == [1]
+    _lib.check(0, 'launch')
+    assert state['cur'] == 0 and calls == [1, 0]
+    assert _lib.stream_ptr(torch.device('cuda', 0)) == 1000 and _lib.stream_ptr(torch.device('cuda')) == 1000
+    _lib.check(0, 'launch')
+    assert calls == [1, 0]                                   # the tensors' device was current already: nothing switched
+    _lib.stream_ptr(torch.device('cuda', 1))
+    with pytest.raises(_lib.RuaError):
+        _lib.check(-1, 'launch')
+    assert state['cur'] == 0

@@ -286,3 +286,30 @@ def test_chains_with_a_host_mirror_never_sync():
         torch.cuda.set_sync_debug_mode('default')
     assert torch.equal(c2.data, data) and torch.equal(p2.data, p.data) and size[0][:2] == (500, int(lens.max()))
     assert all(bool(torch.isfinite(o).all()) for o in outs)
+
+
+def test_ops_run_on_the_stream_and_device_of_their_tensors():
+    """VERDICT r4 #8.  Two streams of one card: work enqueued under `torch.cuda.stream(side)` lands on `side` (ordered
+    after a delay kernel there) and equals the main stream's result.  Two cards (self-skipping part): tensors on cuda:1
+    while cuda:0 is current — torch runs such ops where the tensors live, and so does this library."""
+    g = torch.Generator().manual_seed(3)
+    lens = torch.randint(1, 40, (300,), generator=g)
+    data = torch.randn(int(lens.sum()), 24, generator=g)
+    c = ta.C(data.to(DEV), lens.to(DEV))
+    want = ta.reduce_max(c.pack())
+    side = torch.cuda.Stream(DEV)
+    side.wait_stream(torch.cuda.current_stream(DEV))
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(20_000_000)                                   # the side stream is busy: its work is ordered behind this
+        got = ta.reduce_max(ta.C(c.data, c.token_sizes).pack())
+        assert not side.query()                                         # ... and was enqueued there, not on the main stream
+    side.synchronize()
+    assert torch.equal(got, want)
+    if torch.cuda.device_count() >= 2:
+        d1 = torch.device('cuda', 1)
+        assert torch.cuda.current_device() == 0
+        c1 = ta.C(data.to(d1), lens.to(d1))
+        out = ta.reduce_max(c1.pack())
+        assert out.device == d1 and torch.cuda.current_device() == 0
+        assert torch.equal(out.cpu(), want.cpu())
+        assert torch.equal(c1.left().data.cpu(), c.left().data.cpu())

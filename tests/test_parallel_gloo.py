@@ -72,18 +72,18 @@ def _worker(rank, world, port, B, H, q):
         dist.destroy_process_group()
 
 
-def _run(B):
+def _run(B, world=2):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, 5, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, 5, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = sorted(q.get(timeout=120) for _ in procs)
+    results = sorted(q.get(timeout=240) for _ in procs)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
-    assert results == [(0, True), (1, True)]
+    assert results == [(r, True) for r in range(world)]
 
 
 def test_two_rank_gather_even():
@@ -92,3 +92,34 @@ def test_two_rank_gather_even():
 
 def test_two_rank_gather_ragged():
     _run(37)       # 19 + 18 sequences: the ragged all_gather path
+
+
+def test_eight_rank_gather_even():
+    """cfg5's rank count (8 x contiguous batch shards, one all-gather of the reduced rows), rehearsed over gloo."""
+    _run(64 * 8, world=8)
+
+
+def test_eight_rank_gather_ragged():
+    _run(509 * 8 + 3, world=8)       # shards of 510 / 509 sequences: the ragged all-gather with eight ranks
+
+
+def test_bench_refuses_or_accepts_eight_ranks_as_self_launch_documents(tmp_path):
+    """`python bench.py --gpus 8` on a machine that shows fewer than eight GPUs must exit non-zero naming the shortfall
+    (self_launch: never a line for another rank count); with RUA_BENCH_DEVICE set — every rank pinned to one card, the
+    rehearsal mode — the check is waived and the ranks are started (here there is no card at all, so they fail at their
+    first GPU call: what matters is that the launcher got as far as starting them and reports THEIR failure)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'RUA_BENCH_DEVICE')}
+    if torch.cuda.device_count() < 8:
+        out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '0'],
+                             capture_output=True, text=True, timeout=300, cwd=root, env=env)
+        assert out.returncode != 0 and '--gpus 8' in out.stderr and 'GPU' in out.stderr
+        assert not [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    if torch.cuda.device_count() == 0:
+        env.update(RUA_BENCH_DEVICE='0', RUA_BENCH_BACKEND='gloo')
+        out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '0',
+                              '--batch', '64', '--hidden', '8'], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+        assert out.returncode != 0 and 'exited with' in out.stderr          # the children were started and failed by themselves
+        assert not [ln for ln in out.stdout.splitlines() if ln.startswith('{')]

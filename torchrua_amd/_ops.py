@@ -277,7 +277,29 @@ class _Reduce(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad: Tensor):
         data, out = ctx.saved_tensors
+        if torch.is_grad_enabled() and ctx.op in (L.MAX, L.MIN, L.LOGSUMEXP):
+            # [r5] a graph of this backward is being recorded (create_graph=True).  The reference's reductions are ATen
+            # compositions and differentiate any number of times (reduce.py:34-61: torch.segment_reduce; logsumexp = detached
+            # max, exp, segment sum, log); the fused kernel's output carries no graph, so HERE the gradient is spelled with
+            # differentiable pieces: the per-sequence broadcast (the backward of sum, whose own adjoint is the reduction)
+            # and torch's elementwise ops — [N, H] temporaries, paid only by callers who ask for second derivatives
+            return _composed_reduce_grad(grad, data, out, ctx.lay, ctx.op, ctx.ties), None, None, None, None
         return _ReduceBwd.apply(grad, data, out, ctx.lay, ctx.op, ctx.ties), None, None, None, None
+
+
+def _composed_reduce_grad(grad: Tensor, data: Tensor, out: Tensor, lay: M.Lay, op: int, ties: Optional[Tensor]) -> Tensor:
+    """d reduce / d data as a differentiable function of (grad, data, out): max / min / logsumexp under create_graph."""
+    def spread(v: Tensor) -> Tensor:                 # every sequence's row of `v` over the sequence's storage rows
+        return _ReduceBwd.apply(v.contiguous(), data.detach(), out.detach(), lay, L.SUM, None)
+
+    if op == L.LOGSUMEXP:
+        return spread(grad) * (data - spread(out)).exp()
+    o = spread(out.detach())
+    x = data.detach()
+    hit = (x == o) | ((x != x) & (o != o))
+    g32 = grad.to(ties.dtype)
+    share = torch.where(g32 > 0, g32 / ties.clamp_min(1), g32).to(grad.dtype)     # torch.segment_reduce's tie rule
+    return spread(share) * hit
 
 
 class _ReduceBwd(torch.autograd.Function):
@@ -286,7 +308,9 @@ class _ReduceBwd(torch.autograd.Function):
     gradient once — no [N, H] temporaries.  [r4] For SUM and MEAN the map cotangent -> gradient is linear (a broadcast
     of every segment's row over the segment's rows, divided by the length for MEAN) and its adjoint is the reduction
     itself, so these two are differentiable any number of times, like the reference's (torch.segment_reduce,
-    reduce.py:44-49); the others differentiate once."""
+    reduce.py:44-49).  [r5] max / min / logsumexp: under create_graph=True _Reduce.backward composes the gradient from
+    differentiable pieces instead of calling this kernel (_composed_reduce_grad), so they are twice differentiable too;
+    prod differentiates once (the reference's does not: a stated gap)."""
 
     @staticmethod
     def forward(ctx, grad: Tensor, data: Tensor, out: Tensor, lay: M.Lay, op: int, ties: Optional[Tensor]):
@@ -312,8 +336,9 @@ class _ReduceBwd(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gg: Tensor):
         if ctx.op not in (L.SUM, L.MEAN):
-            raise RuntimeError('torchrua_amd: the reductions max / min / prod / logsumexp differentiate once; second-order '
-                               'gradients exist for sum and mean (and for every cast, select and gather)')
+            raise RuntimeError('torchrua_amd: prod (and the fused max / min / logsumexp kernel outside create_graph) '
+                               'differentiate once; second-order gradients exist for sum, mean, max, min and logsumexp '
+                               '(and for every cast, select and gather)')
         return reduce(gg.contiguous(), ctx.lay, ctx.op, ctx.hidden, None), None, None, None, None, None
 
 
