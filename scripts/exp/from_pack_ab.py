@@ -31,15 +31,23 @@ for dtype in (torch.int64, torch.float32):
     p = c.pack()
     nb = n * data.element_size()
     T = int(lens.max())
-    for name, fn, alg in (('P.cat', lambda: p.cat(), 2 * nb), ('P.left', lambda: p.left(), nb + B * T * data.element_size())):
+    def repack():
+        M.forget(c.token_sizes)
+        return ta.with_host_sizes(data, lens).pack()
+
+    for name, fn, alg in (('P.cat', lambda: p.cat(), 2 * nb), ('P.left', lambda: p.left(), nb + B * T * data.element_size()),
+                          ('pack', lambda: c.pack(), 2 * nb)):
         res = {}
         for tag, shapes in (('tall', TALL), ('square', {})):
             M._FROM_PACK_SHAPES = shapes
+            M._TALL_BOTH_WAYS = True
             fn()
         torch.cuda.synchronize()
         for tag, shapes in (('tall', TALL), ('square', {})) * 5:
             M._FROM_PACK_SHAPES = shapes
+            M._TALL_BOTH_WAYS = True
             res.setdefault(tag, []).append(once(fn))
         print(f'{str(dtype):14s} {name:7s} ' + '  '.join(f'{k}: {sorted(v)[2]:.3f} ms {alg / sorted(v)[2] / 1e9:.2f} TB/s' for k, v in res.items()), flush=True)
     del data, c, p
 M._FROM_PACK_SHAPES = TALL
+M._TALL_BOTH_WAYS = False

@@ -463,13 +463,16 @@ TILE_MIN_LIVE_INV = 4       # ... when at least one cell in this many is a live 
 _FROM_PACK_SHAPES = {8: (7, 4), 4: (7, 5)} if os.environ.get('RUA_TILE_FROM_PACK', '1') != '0' else {}
 
 
+_TALL_BOTH_WAYS = False        # (developer A/B: scripts/exp/from_pack_ab.py)
+
+
 def tile_shape_log2(row_bytes: int, from_pack: bool = False) -> Tuple[int, int]:
     """(log2 time steps, log2 ranks) of a (rank x time) tile by row width (rua_move.hip: pack_tile_lds_kernel).  [r5] Rows
     of ONE vector below 16 bytes — 1-D payloads of 8 / 4 / 2 / 1-byte elements — get more ranks (and steps) per tile, so
     that a tile still carries 16 KiB and both sides still move runs of 128 .. 512 bytes: 32 x 64, 64 x 64, 64 x 128,
     128 x 128.  (The kernel falls back to the row mover when the payload's address is less aligned than its rows.)"""
     narrow = {8: (6, 5), 4: (6, 6), 2: (7, 6), 1: (7, 7)}.get(row_bytes)
-    if from_pack and row_bytes in _FROM_PACK_SHAPES:
+    if (from_pack or _TALL_BOTH_WAYS) and row_bytes in _FROM_PACK_SHAPES:
         narrow = _FROM_PACK_SHAPES[row_bytes]
     if narrow is not None:
         return narrow

@@ -866,8 +866,9 @@ __global__ __launch_bounds__(RUA_BLOCK) void pack_tile_vec_kernel(rua_layout Pk,
                                                                   uint4 fillpat) {
   using E = typename vec_of<RB>::type;
   constexpr int CPL = 16 / RB, TT = 1 << TTL, TR = 1 << TRL;
-  constexpr int JG_LOG2 = TTL - (RB == 8 ? 1 : 2), RG_LOG2 = TRL - (RB == 8 ? 1 : 2);     // groups per rank / per step
-  static_assert(RB == 8 || RB == 4, "rows of one 8- or 4-byte vector");
+  constexpr int CPL_LOG2 = RB == 16 ? 0 : RB == 8 ? 1 : 2;
+  constexpr int JG_LOG2 = TTL - CPL_LOG2, RG_LOG2 = TRL - CPL_LOG2;     // groups per rank / per step
+  static_assert(RB == 16 || RB == 8 || RB == 4, "rows of one 16-, 8- or 4-byte vector");
   union Vec { u32x4 v; E e[CPL]; };
   __shared__ TileTables tb;
   __shared__ E stage[TR * (TT + 1)];             // one padding cell per rank: the transposed walk strides over TT + 1 cells
@@ -1138,6 +1139,12 @@ static int launch_pack_tiles(int vec, hipStream_t s, const rua_layout& Pk, const
     case 4: RUA_LAUNCH_T(VEC, 4, 4); break;                                         \
     case 5: RUA_LAUNCH_T(VEC, 5, 4); break;                                         \
     default: RUA_LAUNCH_T(VEC, 6, 4); break;                                        \
+  }
+  // 16-byte rows INTO a PackedSequence take the lane-group kernel too (one cell per lane, relative liveness tables: +4 %
+  // over the staged kernel, r5r); out of one the staged kernel's line-aligned windows are worth more (-5 % without them)
+  if (TO_PACK && vec == 16 && lpr == 1 && trl == 4 && ttl == 6 && !full_grid) {
+    hipLaunchKernelGGL((pack_tile_vec_kernel<16, TO_PACK, 6, 4>), g, b, 0, s, Pk, Ot, dst, src, per_xcd, fp);
+    return (int)hipGetLastError();
   }
   if (shape_narrow) {
     switch (vec) {

@@ -1107,7 +1107,9 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_walk_kernel(rua_layout 
 // swept step by step — i.e. the PackedSequence in its own storage order.  In-process A/B at the north-star shape
 // (profiles/r05_backward_ab_tiles.txt): sum 3.25-3.33 ms against the walk's 3.25, max 7.8-8.5 against 6.8, logsumexp
 // 7.3-7.6 against 6.8, with or without a span of tiles per XCD.  Sweeping the storage row by row with the sequence's rows
-// gathered per row (the mover's ZERO map) writes at 3.0 TB/s.  The walk stays.
+// gathered per row (the mover's ZERO map) writes at 3.0 TB/s.  A contiguous span of RANKS per XCD (spans of equal row
+// counts, so that an XCD writes one run of rows per time step): sum +2 %, max -1 %, logsumexp -2 %
+// (profiles/r05_backward_ab_xcd_spans.txt).  The walk stays, ranks dealt round-robin.
 // backward over a PackedSequence with narrow rows: adjacent ranks side by side (see seg_reduce_ranks_kernel)
 template <typename T, int EPL, int OP, int TIES>
 __global__ __launch_bounds__(RUA_WAVE) void seg_backward_ranks_kernel(rua_layout L, const T* __restrict__ data,
