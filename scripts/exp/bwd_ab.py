@@ -26,9 +26,9 @@ def load_variant(path):
 HEAD = L.load()
 OLD = os.path.join(ROOT, 'scripts/exp/libs/librua_1826d80.so')
 VARIANTS = [('head', HEAD)]          # name, library
-OLD = os.environ.get('RUA_AB_LIB', OLD)     # another build of the library to compare with (make OUT=... BUILD=...)
-if os.path.exists(OLD):
-    VARIANTS.append((os.path.basename(OLD), load_variant(OLD)))
+for path in os.environ.get('RUA_AB_LIB', OLD).split(','):     # other builds of the library to compare with (make OUT=... BUILD=...)
+    if os.path.exists(path):
+        VARIANTS.append((os.path.basename(path)[-16:], load_variant(path)))
 
 
 def use(v):

@@ -1140,8 +1140,10 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_backward_ranks_kernel(rua_layout
 // order, and rows of padded layouts that hold no token are written as zeros in the same pass (the caller need not
 // pre-zero the gradient).  Walk-per-sequence form (seg_backward_kernel): max over C 4.7 TB/s at 1 KiB rows.
 constexpr int BROWS_MAX = 256;
-template <typename T, int EPL, int OP, bool NT>
-__global__ __launch_bounds__(RUA_BLOCK) void seg_backward_rows_kernel(rua_layout L, const T* __restrict__ data,
+// (8 waves per SIMD, forced: max / min sit ON the 64-VGPR line and the allocator lands on 63 .. 66 from one edit to the
+// next — 7 waves per SIMD cost 7-11 % at the north-star shape, two spilled dwords cost nothing measurable: r5u/bwd_ab.txt)
+template <typename T, int EPL, int OP, bool NT, bool WIDE = false>
+__global__ __launch_bounds__(RUA_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void seg_backward_rows_kernel(rua_layout L, const T* __restrict__ data,
                                                                       const T* __restrict__ out,
                                                                       const T* __restrict__ gout, T* __restrict__ gin,
                                                                       int64_t H, int lp_log2, int cpr, int tile_rows,
@@ -1246,7 +1248,7 @@ __global__ __launch_bounds__(RUA_BLOCK) void seg_backward_rows_kernel(rua_layout
   // all four rows), so every wave still has UB loads in flight and holds ONE chunk of the sequence's rows
   const int nblocks = (nrows + UB * rpw - 1) / (UB * rpw);
   for (int unit = wave; unit < nblocks * cpr; unit += RUA_WAVES_PER_BLOCK) {
-    const int blk = cpr == 1 ? unit : unit / cpr, c = unit - blk * cpr;
+    const int blk = WIDE ? unit / cpr : unit, c = WIDE ? unit - blk * cpr : 0;      // (WIDE: rows wider than one chunk)
     const int g0 = blk * UB;
     const int rA = g0 * rpw;
     const int rB = (rA + UB * rpw < nrows ? rA + UB * rpw : nrows) - 1;
@@ -1273,10 +1275,13 @@ __global__ __launch_bounds__(RUA_BLOCK) void seg_backward_rows_kernel(rua_layout
       if (!colok) continue;
       const Pack pg = *reinterpret_cast<const Pack*>(gs + col);
       A f[EPL], o[EPL];                                // f: what a hit (max / min), or every element, receives
-      if (need_x) {
-        const Pack po = *reinterpret_cast<const Pack*>(os + col);
+      Pack po;                                         // (max / min keep `out` PACKED and widen it at the compare: the
+      if (need_x) {                                    //  kernel sits on the 64-VGPR line — 8 waves per SIMD or 7)
+        po = *reinterpret_cast<const Pack*>(os + col);
+        if (!is_ext) {
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) o[e] = elem<T>::up(po.v[e]);
+          for (int e = 0; e < EPL; ++e) o[e] = elem<T>::up(po.v[e]);
+        }
       }
       if (is_ext) {
         const Cnt pc = *reinterpret_cast<const Cnt*>(ties + bs * H + col);
@@ -1304,7 +1309,10 @@ __global__ __launch_bounds__(RUA_BLOCK) void seg_backward_rows_kernel(rua_layout
             const A x = elem<T>::up(px[u].v[e]);
             A gi;
             if (OP == RUA_LOGSUMEXP) gi = f[e] * exp_shifted(x, o[e]);
-            else gi = ((x == o[e]) || (x != x && o[e] != o[e])) ? f[e] : (A)0;
+            else {
+              const A oe = elem<T>::up(po.v[e]);
+              gi = ((x == oe) || (x != x && oe != oe)) ? f[e] : (A)0;
+            }
             rs.v[e] = elem<T>::down(gi);
           }
         }
@@ -1941,8 +1949,12 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
     const dim3 gg((unsigned)grid), bb(RUA_BLOCK);
     using A = typename elem<T>::acc;
 #define RUA_BROWS(OPV, NTV)                                                                                         \
-  hipLaunchKernelGGL((seg_backward_rows_kernel<T, FULL, OPV, NTV>), gg, bb, 0, s, L, (const T*)data, (const T*)out,  \
-                     (const T*)gout, (T*)gin, H, lp_log2, (int)n_chunks, tile_rows, per_xcd, tie_rule, (const A*)ties)
+  if (n_chunks == 1)                                                                                                \
+    hipLaunchKernelGGL((seg_backward_rows_kernel<T, FULL, OPV, NTV, false>), gg, bb, 0, s, L, (const T*)data, (const T*)out,  \
+                       (const T*)gout, (T*)gin, H, lp_log2, 1, tile_rows, per_xcd, tie_rule, (const A*)ties);       \
+  else                                                                                                              \
+    hipLaunchKernelGGL((seg_backward_rows_kernel<T, FULL, OPV, NTV, true>), gg, bb, 0, s, L, (const T*)data, (const T*)out,  \
+                       (const T*)gout, (T*)gin, H, lp_log2, (int)n_chunks, tile_rows, per_xcd, tie_rule, (const A*)ties)
 #define RUA_BROWS_OP(NTV)                                 \
   switch (op) {                                           \
     case RUA_SUM: RUA_BROWS(RUA_SUM, NTV); break;         \
