@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RUA_ABI_VERSION 5
+#define RUA_ABI_VERSION 6
 
 /* argument errors (negative so they cannot collide with hipError_t) */
 #define RUA_EINVAL   (-1)  /* bad enum / null pointer / negative size      */
@@ -190,12 +190,13 @@ enum rua_op {
  * `perm` (may be NULL) indirects CAT rows: row = perm[off[b]+t] — the sorted-by-destination
  * form of scatter_* (reduce.py:6-31).
  * Empty sequence -> `empty_bits` (the reference's `initial`: 0, 1, or the global min/max).
- * If `extreme` != NULL (MAX/MIN/LOGSUMEXP; 67 uint64 of scratch, initialised by the library) the call reproduces
- * the reference's `initial = tensor.min()` / `.max()` (reduce.py:35,40,57) without its extra pass over the data:
- * the reduce only raises flags in extreme[64] — bit 0: some element is NaN (then `initial` is NaN and poisons every
- * segment), bit 1: some segment is empty — and a second walk for the global extreme (into extreme[0..63]) runs, on
- * the device's own decision, only when a segment is empty.  rua_fill_empty then patches the output; with no NaN
- * and no empty segment (the common case) both extra launches exit at once.
+ * If `extreme` != NULL (MAX/MIN/LOGSUMEXP; RUA_EXTREME_WORDS uint64 of scratch, initialised by the library) the call
+ * reproduces the reference's `initial = tensor.min()` / `.max()` (reduce.py:35,40,57) without its extra pass over the
+ * data: every wave of the reduce folds the OPPOSITE extreme of the rows it reads into one of the 1 024 hashed slots
+ * extreme[0..1023] (one atomic per wave) and raises flags in extreme[1024] — bit 0: some element is NaN (then `initial`
+ * is NaN and poisons every segment), bit 1: some segment is empty.  rua_fill_empty then patches the output, every workgroup its share; with no NaN and no
+ * empty segment (the common case) its workgroups read one word and leave.  (ABI <= 5 took a second walk over the
+ * payload when a segment was empty; ABI 6 never reads the payload twice.)
  * include_self: 0 overwrite | 1 `out` already holds values that take part (scatter_* include_self) |
  *               2 rows of empty sequences are left untouched (torch.index_reduce semantics).
  * split_rows > 0 (with `ws` of rua_reduce_ws_bytes(lay->n_rows, H, dtype, split_rows) bytes) cuts sequences
@@ -208,15 +209,15 @@ enum rua_op {
  * of the sequence equal it (with include_self == 1 the old row is folded into the result but not counted; rows that
  * include_self == 2 leaves untouched are not written: pre-zero the buffer) — what the backward needs, for free in the pass that
  * reads the payload anyway (rua_segment_reduce_backward with include_self = RUA_TIES_FINAL then takes ONE walk).
- * Two bits may be OR-ed into `op` (here, in rua_pack_reduce and in rua_fill_empty) by a caller that keeps ONE
- * persistent `extreme` scratch of 67 uint64 per stream, zeroed once when it was allocated:
+ * One bit may be OR-ed into `op` (here, in rua_pack_reduce and in rua_fill_empty) by a caller that keeps ONE persistent
+ * `extreme` scratch of RUA_EXTREME_WORDS uint64 per stream, zeroed once when it was allocated:
  *   RUA_OP_SCRATCH_CLEAN  the scratch arrives zeroed: no initialising launch; rua_fill_empty (which must then be
- *                         called with the same bit) hands it back zeroed — its last workgroup resets it;
- *   RUA_OP_NO_EMPTY       the second walk is not armed here: the caller knows that no sequence is empty, or hands
- *                         rua_fill_empty the payload so that it takes the walk itself.
- * With both, max / min / logsumexp cost the reduce plus ONE trailing launch instead of three. */
+ *                         called with the same bit) hands it back zeroed.
+ * (0x200 was RUA_OP_NO_EMPTY up to ABI 5 — "do not arm the second walk" — and is ignored now.  Dropping the trailing
+ * launch altogether — the reduce's last wave patching the output, found by tickets — was built and measured in round 5:
+ * no gain at the BASELINE shapes, a loss where waves are short; profiles/r05_self_patch_ab.txt.) */
+#define RUA_EXTREME_WORDS    1027
 #define RUA_OP_SCRATCH_CLEAN 0x100
-#define RUA_OP_NO_EMPTY      0x200
 /* rua_segment_reduce over a CattedSequence with rows narrower than 1 KiB: the caller KNOWS the lengths and vouches
  * that no sequence is far above the average (torchrua_amd: at most 8 x the average, or 64 rows).  When the sequences
  * are short (16 .. 64 rows on average by row width) every row slot of a wave then takes a sequence of its own — one
@@ -283,15 +284,12 @@ int rua_scatter_self_grad(const int64_t* counts, int64_t S, int64_t H, const voi
                           const void* grad_out, const void* aux, void* grad_self, int32_t dtype, int32_t op,
                           int32_t include_self, void* stream);
 
-/* After rua_segment_reduce / rua_pack_reduce with `extreme` (MAX/MIN/LOGSUMEXP): write the global extreme into the
- * rows of empty sequences, or NaN into every row when the NaN flag is up (the reference's initial=NaN behaviour).
- * With `data` (and `perm`) — the reduce's own inputs — this call ALSO takes the rare second walk for the global
- * extreme when a segment is empty (one launch — the workgroup that finishes the walk last patches the rows — instead of a
- * launch of its own): pass
- * RUA_OP_NO_EMPTY to the reduce so that it does not arm the walk itself.  data == NULL: the reduce did it, or
- * nothing is empty. */
+/* After rua_segment_reduce / rua_pack_reduce with `extreme` (MAX/MIN/LOGSUMEXP): write the
+ * global extreme — the reduce left it in the scratch — into the rows of empty sequences, or NaN into every row when
+ * the NaN flag is up (the reference's initial=NaN behaviour).  Every workgroup patches its share of the batch.
+ * (ABI <= 5 also took `data` and `perm` for a second walk over the payload; there is none any more.) */
 int rua_fill_empty(const rua_layout* lay, void* out, int64_t H, int32_t dtype, int32_t op,
-                   void* extreme, const void* data, const int64_t* perm, void* stream);
+                   void* extreme, void* stream);
 
 /* Bucket `index` (values in [0,S); others are ignored): counts[S], off[S] (exclusive scan) and perm[M] such that
  * perm[off[s] .. off[s]+counts[s]) are the rows i with index[i] == s IN ASCENDING ORDER — a stable radix sort on the

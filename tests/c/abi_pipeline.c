@@ -60,7 +60,7 @@ int main(void) {
   float* d_data = upload(data, (size_t)N * H * sizeof *data);
   float* d_pack = dmalloc((size_t)N * H * 4), *d_sum = dmalloc((size_t)B * H * 4), *d_max = dmalloc((size_t)B * H * 4);
   float* d_ties = dmalloc((size_t)B * H * 4), *d_gin = dmalloc((size_t)N * H * 4), *d_gout = dmalloc((size_t)B * H * 4);
-  uint64_t* d_ext = dmalloc(67 * 8);
+  uint64_t* d_ext = dmalloc(RUA_EXTREME_WORDS * 8);
   CHECK(rua_pack_prepare(d_lens, d_sorted, B, T, d_uns, d_bsz, d_boff, d_off, d_ws, s));
 
   rua_layout cat, pack;
@@ -74,7 +74,7 @@ int main(void) {
   CHECK(rua_move_rows(&pack, &cat, RUA_T_SHIFT, 0, d_pack, d_data, H * sizeof(float), NULL, -1, 0, s));
   CHECK(rua_segment_reduce(&pack, NULL, d_pack, d_sum, H, RUA_F32, RUA_SUM, 0, 0, NULL, 0, NULL, NULL, s));
   CHECK(rua_segment_reduce(&cat, NULL, d_data, d_max, H, RUA_F32, RUA_MAX, 0, 0, d_ext, 0, NULL, d_ties, s));
-  CHECK(rua_fill_empty(&cat, d_max, H, RUA_F32, RUA_MAX, d_ext, NULL, NULL, s));
+  CHECK(rua_fill_empty(&cat, d_max, H, RUA_F32, RUA_MAX, d_ext, s));
 
   /* ---- backward of max: cotangent b + 1 for sequence b, ties from the forward */
   float* gout = malloc((size_t)B * H * sizeof *gout);

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f'{n} declared in include/rua.h but not exported'
     assert sorted(_lib.SYMBOLS) == names, 'ctypes table and header disagree'
     loaded = _lib.load()
-    assert loaded.rua_abi_version() == _lib.ABI_VERSION == 5
+    assert loaded.rua_abi_version() == _lib.ABI_VERSION == 6
     assert loaded.rua_build_target() == b'gfx950'
     assert loaded.rua_scan_ws_elems(1) >= 1 and loaded.rua_scan_ws_elems(1 << 20) >= 512
 

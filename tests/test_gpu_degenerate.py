@@ -208,9 +208,9 @@ def test_narrow_p_cat_into_a_view_that_starts_inside_a_line(H, dtype, skip):
 @pytest.mark.parametrize('H,dtype', [(64, torch.float32), (16, torch.bfloat16), (3, torch.float64)])
 def test_mostly_empty_batch_under_max_min_logsumexp(H, dtype):
     """Nine sequences in ten are empty: their rows take the reference's `initial` — the global minimum / maximum of the
-    payload (reduce.py:35,40,57).  When the host knows how many rows that is (megabytes: _ops.PARALLEL_PATCH_BYTES) they
-    are patched by a launch of their own, otherwise by the last workgroup of the merged trailing launch; same values
-    either way, for a CattedSequence and a PackedSequence, against the oracle."""
+    payload (reduce.py:35,40,57), which the reduce tracks itself; the trailing launch patches them with every workgroup,
+    whether or not the host knows the lengths (rounds 2-4: one workgroup, after a second walk over the payload).  For a
+    CattedSequence and a PackedSequence, against the oracle."""
     import numpy as np
     from helpers import orc
     g = torch.Generator().manual_seed(7 + H)
@@ -231,3 +231,34 @@ def test_mostly_empty_batch_under_max_min_logsumexp(H, dtype):
     for z in (host, host.pack()):
         ref = orc.segment_max(f, lens.numpy()).astype(np.float64)
         np.testing.assert_allclose(ta.reduce_max(z).double().cpu().numpy(), ref, rtol=2e-5 + ulp, atol=2e-5 + ulp)
+
+
+@pytest.mark.parametrize('H,dtype', [(8, torch.bfloat16), (8, torch.float32), (4, torch.float32)])
+def test_four_sequences_per_wave_with_the_split_armed(H, dtype):
+    """Lengths on the device only and 300 rows per sequence on average: nobody vouches for the longest sequence, so the
+    long-sequence split is armed (`_meta.reduce_split_rows`) — up to round 4 that sent rows of <= 32 bytes back to one wave
+    per sequence.  Now the four-per-wave kernel cuts long sequences itself (seg_reduce_ranks_kernel<SPLIT>: part 0 in
+    place, the rest through the work list of the tail and combine kernels): a 700 000-row sequence, a 9 000-row one, empty
+    ones and ordinary ones in the same launch, against the oracle's sequential folds."""
+    import numpy as np
+    from helpers import orc
+    from torchrua_amd import _meta as M
+    from torchrua_amd.layout import describe
+    g = torch.Generator().manual_seed(300 + H)
+    B = 36_000
+    lens = torch.randint(200, 401, (B,), generator=g)
+    lens[3], lens[4], lens[B - 1], lens[B - 2] = 0, 1, 0, 9_000
+    lens[12_345] = 700_000
+    N = int(lens.sum())
+    data = (torch.randn(N, H, generator=g) * 0.5).to(dtype)
+    f = data.double().numpy() if dtype == torch.float64 else data.float().numpy()
+    dd = data.to(DEV)
+    z = ta.C(dd, lens.to(DEV))
+    assert M.reduce_split_rows(describe(z), H * dtype.itemsize) > 0, 'the split is expected to be armed here'
+    ulp = {torch.float32: 0.0, torch.bfloat16: 2.0 ** -8}[dtype]
+    for name in ('sum', 'max', 'min', 'logsumexp'):
+        ref = getattr(orc, f'segment_{name}')(f, lens.numpy()).astype(np.float64)
+        for _ in range(2):          # (twice: the scratch and the work list come back clean)
+            got = getattr(ta, f'reduce_{name}')(z).double().cpu().numpy()
+            scale = float(np.abs(f).max()) * (int(lens.max()) if name == 'sum' else 1)
+            np.testing.assert_allclose(got, ref, rtol=2e-5 + ulp, atol=2e-5 * scale + ulp + 1e-6, err_msg=name)

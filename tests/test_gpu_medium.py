@@ -20,6 +20,12 @@ SHAPES = [  # B, lo, hi, hidden, dtype
     (90, 1, 80, (250,), torch.float32),         # the same width in fp32
     (150, 1, 60, (13,), torch.bfloat16),        # 26-byte rows: 2-byte lanes
     (40, 1, 50, (1004,), torch.bfloat16),       # 2 008-byte rows (8 mod 16, two column chunks)
+    # [r5, late] rows of whole 16-byte vectors that are not a multiple of a 128-byte line, above 1 KiB: the LDS-staged
+    # span kernel (eight rows of 2 000 bytes per tile; two of 6 000; 5 000-byte rows are 8 mod 16 again)
+    (60, 1, 70, (1000,), torch.bfloat16),
+    (50, 1, 40, (260,), torch.float32),         # 1 040-byte rows
+    (30, 1, 30, (3000,), torch.bfloat16),       # 6 000-byte rows: two per tile
+    (30, 1, 30, (2500,), torch.bfloat16),       # 5 000-byte rows (8 mod 16) beyond 4 KiB
     # [r5] narrow rows at sizes that reach the round-5 kernels (B >= 4096 for the segmented memcpy between batch-major
     # layouts, enough live cells for the 32 x 64 .. 128 x 128 transposing tiles, the full-grid pads out of a
     # PackedSequence, the step-by-step roll): 1-D payloads of 8 / 4 / 2 / 1-byte elements, and 12 .. 64-byte rows

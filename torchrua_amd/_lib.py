@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported first: maps the HIP runtime our li
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RUA_LIB_PATH') or os.path.join(_HERE, 'librua_hip.so')   # env: developer A/B of builds
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 # enum rua_kind
 CAT, LEFT, PACK, RIGHT, LIST = 0, 1, 2, 3, 4
 # enum rua_tmap
@@ -25,7 +25,8 @@ BWD_TIES_POSITIVE = 0x200  # ... OR-ed in (max/min): torch.segment_reduce's tie 
 MOVE_SCATTER = 1
 MOVE_NT_ON, MOVE_NT_OFF = 2, 4       # rua.h: force / forbid non-temporal payload accesses
 MOVE_NO_NARROW = 2048               # rua.h: developer A/B — rows of one vector through the generic kernel
-OP_SCRATCH_CLEAN, OP_NO_EMPTY = 0x100, 0x200     # rua.h: bits OR-ed into `op` (persistent zeroed extreme scratch)
+OP_SCRATCH_CLEAN = 0x100                          # rua.h: bit OR-ed into `op` (persistent zeroed extreme scratch)
+EXTREME_WORDS = 1027                               # rua.h: RUA_EXTREME_WORDS
 OP_SHORT_SEQS = 0x400      # rua.h: a CattedSequence of short sequences, none far above the average (a hint)
 # enum rua_dtype / rua_op
 F32, BF16, F16, F64 = 0, 1, 2, 3
@@ -77,8 +78,7 @@ SYMBOLS = {
                                             c_void_p]),
     'rua_scatter_self_grad': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_int32, c_int32, c_int32, c_void_p]),
-    'rua_fill_empty': (c_int, [POINTER(RuaLayout), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
-                               c_void_p]),
+    'rua_fill_empty': (c_int, [POINTER(RuaLayout), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     'rua_bucket_ws_elems': (c_int64, [c_int64, c_int64]),
     'rua_index_buckets': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rua_host_sort_desc': (c_int, [c_void_p, c_int64, c_void_p, c_int32]),

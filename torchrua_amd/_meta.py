@@ -143,32 +143,6 @@ def max_len(token_sizes: Tensor) -> int:
     return _memo_put(token_sizes, 'max', int(h.detach().numpy().max()) if h.numel() else 0)
 
 
-def known_no_empty(token_sizes: Optional[Tensor]) -> bool:
-    """True when the host can tell WITHOUT a device sync that every sequence holds at least one row."""
-    if token_sizes is None:
-        return False
-    hit = _memo_get(token_sizes, 'min')
-    if hit is None:
-        if token_sizes.is_cuda and _memo_get(token_sizes, 'host') is None:
-            return False
-        h = host_lens(token_sizes)
-        hit = _memo_put(token_sizes, 'min', int(h.detach().numpy().min()) if h.numel() else 1)
-    return hit > 0
-
-
-def known_n_empty(token_sizes: Optional[Tensor]) -> Optional[int]:
-    """How many sequences are empty, when the host can tell WITHOUT a device sync (None otherwise)."""
-    if token_sizes is None:
-        return None
-    hit = _memo_get(token_sizes, 'n_empty')
-    if hit is None:
-        if token_sizes.is_cuda and _memo_get(token_sizes, 'host') is None:
-            return None
-        h = host_lens(token_sizes)
-        hit = _memo_put(token_sizes, 'n_empty', int((h.detach().numpy() <= 0).sum()) if h.numel() else 0)
-    return hit
-
-
 def total_len(token_sizes: Tensor) -> int:
     hit = _memo_get(token_sizes, 'sum')
     if hit is not None:
@@ -390,7 +364,7 @@ def known_max_len(token_sizes: Optional[Tensor]) -> Optional[int]:
 
 class Lay:
     """A rua_layout plus the tensors its pointers borrow (kept alive with it)."""
-    __slots__ = ('c', 'keep', 'kind', 'n_rows', 'B', 'max_len', '_no_empty', 'heavy_tail', '_n_empty')
+    __slots__ = ('c', 'keep', 'kind', 'n_rows', 'B', 'max_len', 'heavy_tail')
 
     def __init__(self, keep: List[Optional[Tensor]], max_len: Optional[int] = None, **fields):
         self.c = L.RuaLayout(**fields)
@@ -399,27 +373,10 @@ class Lay:
         self.n_rows = fields['n_rows']
         self.B = fields['B']
         self.max_len = max_len      # longest sequence, when the host knows it for free
-        self._no_empty = False      # bool, or a callable that decides on first use (set by the lay_* builders)
         self.heavy_tail = False     # the buckets of a scatter_*: sizes counted on the device, ONE hot bucket is ordinary
-        self._n_empty = None        # int, None (unknown), or a callable that counts on first use (lay_cat / lay_pack)
 
     def ref(self):
         return ctypes.byref(self.c)
-
-    @property
-    def n_empty(self) -> Optional[int]:
-        """Empty sequences, when the host knows their number without a device sync (only max / min / logsumexp ask)."""
-        if callable(self._n_empty):
-            self._n_empty = self._n_empty()
-        return self._n_empty
-
-    @property
-    def no_empty(self) -> bool:
-        """The host knows WITHOUT a device sync that every sequence holds at least one row (decided on first use:
-        only max / min / logsumexp ask)."""
-        if callable(self._no_empty):
-            self._no_empty = bool(self._no_empty())
-        return self._no_empty
 
 
 def lay_cat(lens: Optional[Tensor], B: int, n_rows: int, len_add: int = 0) -> Lay:
@@ -430,11 +387,8 @@ def lay_cat(lens: Optional[Tensor], B: int, n_rows: int, len_add: int = 0) -> La
     off = dev_off(lens)
     mx = known_max_len(lens)
     longest = None if mx is None else mx + len_add
-    lay = Lay([lens, off], max_len=longest, kind=L.CAT, n_rows=n_rows, B=B, lens=L.ptr(lens), len_add=len_add,
-              off=L.ptr(off), T_log=longest or 0)            # (T_log of a CAT layout: the longest sequence, 0 = unknown)
-    lay._no_empty = (lambda: known_no_empty(lens)) if len_add >= 0 else False
-    lay._n_empty = (lambda: known_n_empty(lens)) if len_add == 0 else None
-    return lay
+    return Lay([lens, off], max_len=longest, kind=L.CAT, n_rows=n_rows, B=B, lens=L.ptr(lens), len_add=len_add,
+               off=L.ptr(off), T_log=longest or 0)           # (T_log of a CAT layout: the longest sequence, 0 = unknown)
 
 
 def lay_padded(kind: int, lens: Optional[Tensor], B: int, T_phys: int, T_log: int, len_add: int = 0,
@@ -450,9 +404,7 @@ def lay_padded(kind: int, lens: Optional[Tensor], B: int, T_phys: int, T_log: in
             keep.append(off)
             f['off'] = L.ptr(off)
     mx = len_add if lens is None else known_max_len(lens)
-    lay = Lay(keep, max_len=mx if lens is None or mx is None else mx + len_add, **f)
-    lay._no_empty = (len_add > 0) if lens is None else ((lambda: known_no_empty(lens)) if len_add >= 0 else False)
-    return lay
+    return Lay(keep, max_len=mx if lens is None or mx is None else mx + len_add, **f)
 
 
 NARROW_ROW_BYTES = 64      # rows up to this get the tile table (rua_move.hip: TILE_MAX_ROW_BYTES)
@@ -505,9 +457,7 @@ def lay_pack_steps(p, row_bytes: int, shift: int) -> Optional['Lay']:
     fields = {name: getattr(lay.c, name) for name, _ in L.RuaLayout._fields_}
     fields.update(bsz=L.ptr(t.bsz), tile_start=L.ptr(t.tile_start), n_tchunks=t.n_tchunks, n_tiles=t.n_tiles,
                   tile_t_log2=(trl << 8) | TILE_STEP_ROWS)
-    out = Lay(list(lay.keep) + [t.bsz, t.tile_start], max_len=lay.max_len, **fields)
-    out._no_empty, out._n_empty = lay._no_empty, lay._n_empty
-    return out
+    return Lay(list(lay.keep) + [t.bsz, t.tile_start], max_len=lay.max_len, **fields)
 
 
 def tile_line_rows(row_bytes: int) -> int:
@@ -582,14 +532,9 @@ def lay_pack(p, lens: Optional[Tensor] = None, len_add: int = 0, boff: Optional[
             keep += [t.bsz, t.tile_start]
             extra.update(bsz=L.ptr(t.bsz), tile_start=L.ptr(t.tile_start), n_tchunks=t.n_tchunks, n_tiles=t.n_tiles,
                          tile_t_log2=t.code)
-    lay = Lay(keep, max_len=T, kind=L.PACK, n_rows=n_rows, B=pack_nseq(p),
-              lens=L.ptr(lens), len_add=len_add, boff=L.ptr(boff), T=T, sorted=L.ptr(p.sorted_indices),
-              unsorted=L.ptr(p.unsorted_indices), **extra)
-    # batch_sizes[0] counts the sequences that hold a row (a host tensor): all of them, unless some are empty
-    lay._no_empty = len_add == 0 and T == p.batch_sizes.numel() and T > 0 and pack_B(p) == pack_nseq(p)
-    if len_add == 0 and T == p.batch_sizes.numel():
-        lay._n_empty = pack_nseq(p) - (pack_B(p) if T > 0 else 0)
-    return lay
+    return Lay(keep, max_len=T, kind=L.PACK, n_rows=n_rows, B=pack_nseq(p),
+               lens=L.ptr(lens), len_add=len_add, boff=L.ptr(boff), T=T, sorted=L.ptr(p.sorted_indices),
+               unsorted=L.ptr(p.unsorted_indices), **extra)
 
 
 class _StagingRing:

@@ -128,32 +128,29 @@ class _ListGather(torch.autograd.Function):
 # ------------------------------------------------------------------ reductions
 # max / min / logsumexp track the reference's global `initial` through a small scratch (rua.h: `extreme`).  One
 # persistent, zeroed scratch per (device, stream): the reduce needs no initialising launch (RUA_OP_SCRATCH_CLEAN) and
-# rua_fill_empty's last workgroup hands it back zeroed — stream order makes that safe for one stream, hence the key.
+# rua_fill_empty hands it back zeroed — stream order makes that safe for one stream, hence the key.
 _scratch = {}
 # the reduce and its trailing rua_fill_empty share the scratch and must reach the stream back to back: ctypes drops the
 # GIL around each call, so a second host thread enqueueing on the SAME stream could slip its own reduce in between
 _scratch_pair = threading.Lock()
 
 
-def extreme_scratch(dev, lay: M.Lay) -> Tuple[Tensor, int]:
+def extreme_scratch(dev) -> Tuple[Tensor, int]:
     key = (dev.index, torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if dev.index is None else dev.index))
     if torch.cuda.is_current_stream_capturing():
         # inside a graph capture ALWAYS a buffer of the capture's own (zeroed by the legacy initialising launch), even
         # when this stream already has a persistent one: a graph that baked the shared scratch in could be replayed on
         # another stream while eager max / min runs on this one, and the two would race on its flag and ticket words
-        return torch.empty(67, dtype=torch.long, device=dev), (L.OP_NO_EMPTY if lay.no_empty else 0)
+        return torch.empty(L.EXTREME_WORDS, dtype=torch.long, device=dev), 0
     buf = _scratch.get(key)
     if buf is None:
-        buf = _scratch[key] = torch.zeros(67, dtype=torch.long, device=dev)
-    return buf, L.OP_SCRATCH_CLEAN | (L.OP_NO_EMPTY if lay.no_empty else 0)
+        buf = _scratch[key] = torch.zeros(L.EXTREME_WORDS, dtype=torch.long, device=dev)
+    return buf, L.OP_SCRATCH_CLEAN
 
 
 def forget_extreme_scratch(dev) -> None:
     for key in [k for k in _scratch if k[0] == dev.index]:
         del _scratch[key]
-
-
-PARALLEL_PATCH_BYTES = 4 << 20      # empty rows the host knows of, from which on they are patched by a launch of their own
 
 
 _EMPTY = {L.SUM: 0.0, L.MEAN: 0.0, L.PROD: 1.0, L.MAX: 0.0, L.MIN: 0.0, L.LOGSUMEXP: float('-inf')}
@@ -219,38 +216,29 @@ def launch_reduce(lay: M.Lay, data: Tensor, op: int, out: Optional[Tensor] = Non
         raise L.RuaError('reduce target must be a contiguous [B, *hidden] tensor of the payload dtype')
     extreme, op_bits = None, 0
     if reference_initial and op in (L.MAX, L.MIN, L.LOGSUMEXP) and include_self == 0:
-        extreme, op_bits = extreme_scratch(dev, lay)
+        extreme, op_bits = extreme_scratch(dev)
     tail_ok = include_self != 1 and (data.data_ptr() | out.data_ptr()) % 8 == 0      # the launcher's own condition
     split, ws = split_workspace(lay, H, data.dtype, dev, tail_ok=tail_ok)
     short = short_seqs_hint(lay, H * data.dtype.itemsize) if perm is None and not split else 0
-    # the empty rows are patched by the LAST workgroup of the merged trailing launch (no grid barrier: DESIGN §3.2) — fine
-    # for the odd empty sequence, ~30 GB/s for a batch that is mostly empty.  When the host KNOWS that megabytes of rows
-    # will be patched it takes the two-launch form instead: the reduce arms the walk for the global extreme itself and
-    # rua_fill_empty, without the payload, patches with every workgroup (max over a 90 % empty batch: 5.1 -> ~1 ms)
-    parallel_patch = False
-    if extreme is not None and not (op_bits & L.OP_NO_EMPTY):
-        ne = lay.n_empty
-        parallel_patch = ne is not None and ne * H * data.dtype.itemsize >= PARALLEL_PATCH_BYTES
+    # (the reduce leaves the global extreme in the scratch — every wave folds the opposite extreme of the rows it reads —
+    # so the trailing rua_fill_empty needs no second walk: every workgroup patches its share of the batch, whether or
+    # not the host knows how many sequences are empty)
     if _kernel_hook:
         _kernel_hook(name, True)
     paired = extreme is not None
     if paired:
         _scratch_pair.acquire()
     try:
-        # (the second walk for the global extreme, should a segment be empty, rides in rua_fill_empty's launch: the
-        # reduce is told not to arm it, and fill_empty gets the payload unless the host knows nothing is empty)
         L.check(lib.rua_segment_reduce(lay.ref(), L.ptr(perm), L.ptr(data), L.ptr(out), H, L.DTYPES[data.dtype],
-                                       op | op_bits | (L.OP_NO_EMPTY if extreme is not None and not parallel_patch else 0) | short,
+                                       op | op_bits | short,
                                        include_self,
                                        _bits(_EMPTY[op], data.dtype), L.ptr(extreme), split, L.ptr(ws), L.ptr(ties_out),
                                        L.stream_ptr(dev)), 'rua_segment_reduce')
         if _kernel_hook:
             _kernel_hook(name, False)
         if extreme is not None:
-            walk = not (op_bits & L.OP_NO_EMPTY) and not parallel_patch
             L.check(lib.rua_fill_empty(lay.ref(), L.ptr(out), H, L.DTYPES[data.dtype], op | (op_bits & L.OP_SCRATCH_CLEAN),
-                                       L.ptr(extreme), L.ptr(data) if walk else None, L.ptr(perm) if walk else None,
-                                       L.stream_ptr(dev)), 'rua_fill_empty')
+                                       L.ptr(extreme), L.stream_ptr(dev)), 'rua_fill_empty')
     except L.RuaError:
         forget_extreme_scratch(dev)        # a refused launch may have left the flags raised
         raise

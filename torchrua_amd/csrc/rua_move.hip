@@ -404,7 +404,9 @@ __global__ __launch_bounds__(RUA_BLOCK) void move_rows_span_kernel(rua_layout D,
     for (int u = 0; u < UN; ++u) {
       if (k0[u] < -16) continue;
       const uint32_t w[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
-      if (((k0[u] | rb | base[u]) & 7) == 0) {              // 8-byte pieces (rows of 8 mod 16 bytes: always)
+      if (((k0[u] | rb | base[u]) & 15) == 0) {             // whole vectors (rows of a multiple of 16 bytes: always)
+        if (k0[u] >= 0 && k0[u] < rb) *reinterpret_cast<u32x4*>(&stage[(base[u] + k0[u]) >> 2]) = x[u];
+      } else if (((k0[u] | rb | base[u]) & 7) == 0) {       // 8-byte pieces (rows of 8 mod 16 bytes: always)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const int k = k0[u] + 8 * q;
@@ -1435,23 +1437,34 @@ extern "C" int rua_move_rows(const rua_layout* dst, const rua_layout* src, int32
   }
   // [r5] a gather of rows that are a multiple of 4 but not of 16 bytes: the destination tile goes through LDS and leaves as
   // one aligned span (move_rows_span_kernel)
-  if ((row_bytes & 15) != 0 && (row_bytes & 3) == 0 && row_bytes >= 64 && row_bytes <= SPAN_TILE_BYTES / 4 &&
+  // ([r5, late] and of rows that ARE a multiple of 16 bytes but not of a 128-byte line — 2 000-byte rows, H = 1 000 in
+  // bf16: the row mover's 16-byte lanes are aligned there, but every wave instruction straddles one line more than it
+  // fills and every row boundary is two partial lines; as a span the tile is stored in whole lines)
+  const bool off16 = (row_bytes & 15) != 0 && (row_bytes & 3) == 0;
+  // (from 1 KiB up: at 640 / 656-byte rows the row mover is level or ahead — 5.41 / 5.40 against 5.36 / 5.00 TB/s for the
+  // pack, profiles/r05_span16_ab.txt)
+  const bool off128 = (row_bytes & 15) == 0 && (row_bytes & 127) != 0 && row_bytes > 1024;
+  if ((off16 || off128) && row_bytes >= 64 && row_bytes <= SPAN_TILE_BYTES / 2 &&
       ((uintptr_t)dst_data & 15) == 0 && ((uintptr_t)src_data & 15) == 0 && tsel == 0 && !(flags & RUA_MOVE_NO_TAIL8)) {
     // rows per tile: a multiple of 2 (rows of 8 mod 16 bytes) or 4 (4 / 12 mod 16), so that every tile starts on a
-    // 16-byte boundary; as many as fit 16 KiB of LDS (16 rows of 1 000 bytes, 8 of 2 000), one resolving lane each
-    const int step = (row_bytes & 7) ? 4 : 2;
+    // 16-byte boundary (any number of rows of whole vectors: only the two ends of a tile are partial lines then); as many
+    // as fit 16 KiB of LDS (16 rows of 1 000 bytes, 8 of 2 000), one resolving lane each
+    int step = (row_bytes & 7) ? 4 : 2;
+    if (off128) step = 1;
     int trows = (int)(SPAN_TILE_BYTES / row_bytes) / step * step;
     if (trows > RUA_BLOCK) trows = RUA_BLOCK / step * step;
-    const int64_t ntiles = (nr + trows - 1) / trows;
-    bool span = ntiles >= (padded_dst ? MOVE_SPAN_MIN_TILES : MOVE_SPAN_MIN_TILES_DENSE);
-    if (flags & RUA_MOVE_XCD_SPAN_ON) span = true;
-    if (flags & RUA_MOVE_XCD_SPAN_OFF) span = false;
-    const int64_t per_xcd = span ? (ntiles + 7) / 8 : 0;
-    const int64_t grid = span ? per_xcd * 8 : ntiles;
-    if (grid > 0x7fffffffLL) return RUA_ERANGE;
-    if (nt) hipLaunchKernelGGL(move_rows_span_kernel<true>, dim3((unsigned)grid), dim3(RUA_BLOCK), 0, s, *dst, *src, tmap, tmap_arg, d, c, (int)row_bytes, trows, fp, pad_row, per_xcd);
-    else hipLaunchKernelGGL(move_rows_span_kernel<false>, dim3((unsigned)grid), dim3(RUA_BLOCK), 0, s, *dst, *src, tmap, tmap_arg, d, c, (int)row_bytes, trows, fp, pad_row, per_xcd);
-    return (int)hipGetLastError();
+    if (trows > 0) {        // (a line-aligned tile of some widths would not fit the 16 KiB: the row mover takes those)
+      const int64_t ntiles = (nr + trows - 1) / trows;
+      bool span = ntiles >= (padded_dst ? MOVE_SPAN_MIN_TILES : MOVE_SPAN_MIN_TILES_DENSE);
+      if (flags & RUA_MOVE_XCD_SPAN_ON) span = true;
+      if (flags & RUA_MOVE_XCD_SPAN_OFF) span = false;
+      const int64_t per_xcd = span ? (ntiles + 7) / 8 : 0;
+      const int64_t grid = span ? per_xcd * 8 : ntiles;
+      if (grid > 0x7fffffffLL) return RUA_ERANGE;
+      if (nt) hipLaunchKernelGGL(move_rows_span_kernel<true>, dim3((unsigned)grid), dim3(RUA_BLOCK), 0, s, *dst, *src, tmap, tmap_arg, d, c, (int)row_bytes, trows, fp, pad_row, per_xcd);
+      else hipLaunchKernelGGL(move_rows_span_kernel<false>, dim3((unsigned)grid), dim3(RUA_BLOCK), 0, s, *dst, *src, tmap, tmap_arg, d, c, (int)row_bytes, trows, fp, pad_row, per_xcd);
+      return (int)hipGetLastError();
+    }
   }
   return nt ? launch_move<false, true>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, narrow_same_pack, tile_rows, xcd_span, tail8)
             : launch_move<false, false>(vec, nr, s, *dst, *src, tmap, tmap_arg, d, c, row_bytes, fp, pad_row, narrow_same_pack, tile_rows, xcd_span, tail8);

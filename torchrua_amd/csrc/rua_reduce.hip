@@ -5,12 +5,11 @@
 #include "rua_dev.h"
 
 namespace rua {
-constexpr int EXTREME_SLOTS_ENTRY = 64;
+constexpr int EXTREME_WORDS_ENTRY = RUA_EXTREME_WORDS;     // 1 024 slots, flags, the reset ticket, one spare
 constexpr int BWD_TIES_POSITIVE = 2;      // bit 1 of the kernels' extra_count (rua_reduce_impl.h)
 __global__ void extreme_init_entry_kernel(unsigned long long* ext, int want_max_of_data) {
-  const int i = threadIdx.x;
   (void)want_max_of_data;                       // the slots are zero-neutral for the maximum and the minimum alike
-  if (i <= EXTREME_SLOTS_ENTRY + 2) ext[i] = 0ull;   // slots, flags, ticket, barrier
+  for (int i = threadIdx.x; i < EXTREME_WORDS_ENTRY; i += blockDim.x) ext[i] = 0ull;   // slots, flags, ticket
 }
 #define RUA_DECL(NAME)                                                                                              \
   int reduce_##NAME(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data, void* out,  \
@@ -20,7 +19,7 @@ __global__ void extreme_init_entry_kernel(unsigned long long* ext, int want_max_
                       const void* out, const void* gout, void* gin, int64_t H, int extra_count, int64_t split,    \
                       void* ws, void* ties, bool ties_final, const void* self_in, bool fill_padding);              \
   int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, void* ext,        \
-                        int reset, const void* data, const int64_t* perm);                                       \
+                        int reset);                                                                              \
   int self_grad_##NAME(hipStream_t s, const int64_t* counts, int64_t S, int64_t H, const void* self_in,            \
                        const void* out, const void* gout, const void* aux, void* gself, int op, int inc);
 RUA_DECL(f32) RUA_DECL(bf16) RUA_DECL(f16) RUA_DECL(f64)
@@ -115,7 +114,7 @@ int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* d
   if (lay->B == 0 || H == 0) return 0;
   if (!out || (lay->n_rows > 0 && !data)) return RUA_EINVAL;
   const bool clean = (op & RUA_OP_SCRATCH_CLEAN) != 0;
-  const int hints = ((op & RUA_OP_NO_EMPTY) ? 1 : 0) | ((op & RUA_OP_SHORT_SEQS) ? 2 : 0);     // dispatch_reduce's hints
+  const int hints = (op & RUA_OP_SHORT_SEQS) ? 2 : 0;     // dispatch_reduce's hints
   op &= 0xff;
   if (ties && op != RUA_MAX && op != RUA_MIN) return RUA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
@@ -124,7 +123,7 @@ int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* d
     return reduce_int(dtype, op, s, *lay, perm, data, out, H, include_self, split_rows, ws);
   }
   if (extreme && !clean && (op == RUA_MAX || op == RUA_MIN || op == RUA_LOGSUMEXP)) {
-    hipLaunchKernelGGL(extreme_init_entry_kernel, dim3(1), dim3(128), 0, s, (unsigned long long*)extreme,
+    hipLaunchKernelGGL(extreme_init_entry_kernel, dim3(1), dim3(256), 0, s, (unsigned long long*)extreme,
                        op == RUA_MIN ? 1 : 0);
   }
   switch (dtype) {
@@ -147,10 +146,10 @@ int rua_pack_reduce(const rua_layout* src, const rua_layout* pack, const void* d
   if (!out || !pack_data || !data) return RUA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const bool clean = (op & RUA_OP_SCRATCH_CLEAN) != 0;
-  const int hints = (op & RUA_OP_NO_EMPTY) ? 1 : 0;
+  const int hints = 0;
   op &= 0xff;
   if (extreme && !clean && (op == RUA_MAX || op == RUA_MIN || op == RUA_LOGSUMEXP))
-    hipLaunchKernelGGL(extreme_init_entry_kernel, dim3(1), dim3(128), 0, s, (unsigned long long*)extreme,
+    hipLaunchKernelGGL(extreme_init_entry_kernel, dim3(1), dim3(256), 0, s, (unsigned long long*)extreme,
                        op == RUA_MIN ? 1 : 0);
   switch (dtype) {
     case RUA_F32: return reduce_f32(op, s, *src, nullptr, data, out, H, 0, empty_bits, extreme, split_rows, ws, pack, pack_data, nullptr, hints);
@@ -162,9 +161,8 @@ int rua_pack_reduce(const rua_layout* src, const rua_layout* pack, const void* d
 }
 
 int rua_fill_empty(const rua_layout* lay, void* out, int64_t H, int32_t dtype, int32_t op, void* extreme,
-                   const void* data, const int64_t* perm, void* stream) {
+                   void* stream) {
   if (!lay || H < 0 || !extreme) return RUA_EINVAL;
-  if (perm && lay->kind != RUA_CAT) return RUA_EINVAL;
   const int reset = (op & RUA_OP_SCRATCH_CLEAN) ? 1 : 0;
   op &= 0xff;
   if (op != RUA_MAX && op != RUA_MIN && op != RUA_LOGSUMEXP) return RUA_EINVAL;
@@ -174,10 +172,10 @@ int rua_fill_empty(const rua_layout* lay, void* out, int64_t H, int32_t dtype, i
   hipStream_t s = (hipStream_t)stream;
   const int wmax = op == RUA_MIN ? 1 : 0;
   switch (dtype) {
-    case RUA_F32: return fill_empty_f32(s, *lay, out, H, wmax, extreme, reset, data, perm);
-    case RUA_BF16: return fill_empty_bf16(s, *lay, out, H, wmax, extreme, reset, data, perm);
-    case RUA_F16: return fill_empty_f16(s, *lay, out, H, wmax, extreme, reset, data, perm);
-    case RUA_F64: return fill_empty_f64(s, *lay, out, H, wmax, extreme, reset, data, perm);
+    case RUA_F32: return fill_empty_f32(s, *lay, out, H, wmax, extreme, reset);
+    case RUA_BF16: return fill_empty_bf16(s, *lay, out, H, wmax, extreme, reset);
+    case RUA_F16: return fill_empty_f16(s, *lay, out, H, wmax, extreme, reset);
+    case RUA_F64: return fill_empty_f64(s, *lay, out, H, wmax, extreme, reset);
     default: return RUA_EINVAL;
   }
 }

@@ -21,7 +21,7 @@ namespace rua {
 #define RUA_UNROLL_T 8
 #endif
 constexpr int UNROLL_T = RUA_UNROLL_T;
-constexpr int EXTREME_SLOTS = 64;  // contention spreading for the global min/max tracker
+constexpr int EXTREME_SLOTS = 1024;  // contention spreading for the global min/max tracker (fold_flags)
 
 // ---------------------------------------------------------------- element conversion
 template <typename T> struct elem;
@@ -187,6 +187,13 @@ __device__ __forceinline__ void tie_update(A& acc, A& cnt, A x, A c) {
 template <typename A, int EPL>
 struct Fold {
   A acc[EPL], aux[EPL];   // aux: running sum for LOGSUMEXP (acc holds the running max)
+  // [r5] max / min / logsumexp: the OPPOSITE extreme of everything this lane has folded (the minimum under max and
+  // logsumexp, the maximum under min) — the reference's `initial` (reduce.py:35,40,57: tensor.min() / .max()) for the
+  // segments that turn out empty.  One scalar per lane, one v_minimum3 / v_maximum3 per two elements in loops that wait
+  // for HBM anyway (NaN-propagating like the fold itself: one instruction, and a NaN anywhere raises the poison flag,
+  // which decides everything); fold_flags hands the wave's value to the scratch, so no second walk over the payload
+  // is ever needed.
+  A opp;
 };
 
 template <typename A, int EPL, int OP>
@@ -197,6 +204,7 @@ __device__ __forceinline__ void fold_init(Fold<A, EPL>& f) {
              : op_is_min(OP) ? acc_inf<A>() : (A)0;
     f.aux[e] = (A)0;
   }
+  f.opp = op_is_min(OP) ? -acc_inf<A>() : acc_inf<A>();
 }
 
 // fold rows [t_lo, t_hi) of the unit's sequence
@@ -284,6 +292,11 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
 #pragma unroll
           for (int c = 0; c < CPW; ++c)
             if (!(row[u] >= 0 && (CPW == 1 || col + c * CW < H))) p[u][c] = ninf;
+        bool all_there = true;                     // (the bulk of a sequence: every row of the chunk is there)
+#pragma unroll
+        for (int u = 0; u < UT; ++u)
+#pragma unroll
+          for (int c = 0; c < CPW; ++c) all_there &= (row[u] >= 0 && (CPW == 1 || col + c * CW < H));
 #pragma unroll
         for (int ce = 0; ce < EPL * CPW; ++ce) {
           const int c = ce / EPL, e = ce % EPL;
@@ -293,6 +306,15 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
           for (int u = 0; u < UT; ++u) {
             x[u] = elem<T>::up(p[u][c].v[e]);
             cm = nmax(cm, x[u]);
+          }
+          // the opposite extreme counts the rows that are there only (the others were made -inf above)
+          if (all_there) {
+#pragma unroll
+            for (int u = 0; u < UT; ++u) f.opp = nmin(f.opp, x[u]);
+          } else {
+#pragma unroll
+            for (int u = 0; u < UT; ++u)
+              if (row[u] >= 0 && (CPW == 1 || col + c * CW < H)) f.opp = nmin(f.opp, x[u]);
           }
           // NaN-propagating and sticky: once an element is NaN the running max stays NaN (that is how the
           // reference's NaN-poisoned `initial` is detected: fold_flags) and the sum turns NaN
@@ -324,6 +346,7 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
             if (CPW > 1 && col + c * CW >= H) continue;
             const A x = elem<T>::up(p[u][c].v[e]);
             m[ce] = MX ? nmax(m[ce], x) : nmin(m[ce], x);
+            f.opp = MX ? nmin(f.opp, x) : nmax(f.opp, x);
           }
         }
         bool any_nan = false;
@@ -374,8 +397,8 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
             const A x = elem<T>::up(p[u][c].v[e]);
             if (OP == RUA_SUM || OP == RUA_MEAN) f.acc[ce] += x;
             else if (OP == RUA_PROD) f.acc[ce] *= x;
-            else if (OP == RUA_MAX) f.acc[ce] = nmax(f.acc[ce], x);   // v_maximum3_f32: NaN-propagating like torch
-            else if (OP == RUA_MIN) f.acc[ce] = nmin(f.acc[ce], x);
+            else if (OP == RUA_MAX) { f.acc[ce] = nmax(f.acc[ce], x); f.opp = nmin(f.opp, x); }   // v_maximum3_f32: NaN-propagating like torch
+            else if (OP == RUA_MIN) { f.acc[ce] = nmin(f.acc[ce], x); f.opp = nmax(f.opp, x); }
           }
         }
       }
@@ -473,14 +496,32 @@ __device__ __forceinline__ void fold_store(const Unit<T, EPL>& U, Fold<typename 
 }
 
 // The reference's `initial` for max / min / logsumexp is a GLOBAL extreme of the data (reduce.py:35,40: tensor.min()
-// resp. tensor.max()).  It only shows in two rare cases, so the hot loops do not track it; they raise flags
-// (extreme[EXTREME_SLOTS]) instead, after the wave's fold:
-//   bit 0  some element is NaN (the running max/min is NaN-propagating, so a NaN accumulator says so; for
-//          logsumexp the accumulator is the running max, which inf - inf cannot turn NaN): `initial` is NaN and
-//          poisons EVERY segment — rua_fill_empty writes NaN everywhere;
-//   bit 1  some segment is empty: seg_extreme_kernel (launched after the reduce, exits at once otherwise) takes a
-//          second walk over the data for the global extreme, rua_fill_empty writes it into the empty segments.
-// The flag word is read before the atomic: once it is set nobody touches it again.
+// resp. tensor.max()).  It only shows in two rare cases.  After its fold every wave
+//   * raises flags in extreme[EXTREME_SLOTS]:
+//       bit 0  some element is NaN (the running max/min is NaN-propagating, so a NaN accumulator says so; for
+//              logsumexp the accumulator is the running max, which inf - inf cannot turn NaN): `initial` is NaN and
+//              poisons EVERY segment — NaN is written everywhere;
+//       bit 1  some segment is empty: it takes the global extreme.
+//     The flag word is read before the atomic: once it is set nobody touches it again.
+//   * [r5] folds the opposite extreme of the rows IT read (Fold::opp) into one of 1 024 hashed slots with ONE
+//     fire-and-forget atomic: the global extreme is complete when the reduce is, so nobody walks the payload a second
+//     time (rounds 1-4: a lazy second walk, by the trailing launch's workgroups; and the empty rows of a mostly-empty
+//     batch were then patched by ONE workgroup).  Zero-neutral in both directions (a scratch that arrives zeroed needs
+//     no initialising launch): the maximum is kept as its ordered bits, the minimum as their complement, both under
+//     atomicMax.
+//     Why 1 024 slots, and why nothing cleverer: same-address atomics execute at the memory side, one per ~11 ns and
+//     address at best, and a wave's slot on the CU is not free until its atomic is acknowledged.  With 64 slots cfg3's
+//     16 384 waves queued 256 deep (segment_max 108 -> 117 us), 200 000 one-wave sequences 3 000 deep (0.34 ms of
+//     queueing where the payload takes 0.05).  LOOKING at the slot first and sending only what beats it made it worse
+//     every way it was tried: an agent-scope load is served at the memory side too (at the wave's end: 118 us; in front
+//     of the row loop, where the in-order return of loads holds the first payload rows behind it: 158 us), a
+//     non-temporal load of a line that atomics keep dropping from L2 250 us.  Neighbouring workgroups take slots on
+//     different 128-byte lines (stride 17 words).  profiles/r05_initial_ab.txt.
+// What patches the output afterwards: fill_empty_kernel (a trailing launch, every workgroup its share).
+__device__ __forceinline__ int extreme_slot() {
+  return (int)(((unsigned)blockIdx.x * 17u + (threadIdx.x >> 6) * 5u) & (unsigned)(EXTREME_SLOTS - 1));
+}
+
 template <typename A, int EPL, int OP>
 __device__ __forceinline__ void fold_flags(const Fold<A, EPL>& f, unsigned long long* __restrict__ extreme,
                                            int lane, bool empty_unit) {
@@ -488,8 +529,21 @@ __device__ __forceinline__ void fold_flags(const Fold<A, EPL>& f, unsigned long 
   bool nan = false;
 #pragma unroll
   for (int e = 0; e < EPL; ++e) nan |= (f.acc[e] != f.acc[e]);
+  A opp = f.opp;
+#pragma unroll
+  for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {
+    const A o = __shfl_xor(opp, d, RUA_WAVE);
+    opp = op_is_min(OP) ? nmax(opp, o) : nmin(opp, o);
+  }
   const unsigned long long want = (__any(nan) ? 1ull : 0ull) | (__any(empty_unit) ? 2ull : 0ull);
-  if (want == 0ull || lane != 0) return;
+  if (lane != 0) return;
+  // (a wave that read nothing still holds the start value: nothing to hand over; a NaN raised the poison flag and
+  // decides everything)
+  if (opp == opp && opp != (op_is_min(OP) ? -acc_inf<A>() : acc_inf<A>())) {
+    const unsigned long long bits = (unsigned long long)ordered_bits(opp);
+    atomicMax(&extreme[extreme_slot()], op_is_min(OP) ? bits : ~bits);
+  }
+  if (want == 0ull) return;
   const unsigned long long have = __atomic_load_n(&extreme[EXTREME_SLOTS], __ATOMIC_RELAXED);
   if ((have & want) != want) atomicOr(&extreme[EXTREME_SLOTS], want);
 }
@@ -611,12 +665,17 @@ __global__ __launch_bounds__(RUA_WAVE * TEAM_MAX) void seg_reduce_team_kernel(
 }
 
 // reduce over a PackedSequence with narrow rows: adjacent ranks side by side (see make_unit)
-template <typename T, int EPL, int OP, bool NT>
+// [r5] SPLIT (glog > 0 only): a sequence longer than W.split rows is cut into parts exactly as seg_reduce_kernel cuts it —
+// this wave folds part 0 and publishes the rest to the work list of seg_reduce_tail_kernel / seg_reduce_combine_kernel,
+// launched next — so lengths that live on the device only (the split is armed whenever nobody can vouch for them) keep
+// the four-per-wave form at rows of <= 32 bytes instead of falling back to one wave per sequence (2.2 / 4.1 TB/s).
+template <typename T, int EPL, int OP, bool NT, bool SPLIT = false>
 __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_ranks_kernel(rua_layout L, const T* __restrict__ data,
                                                                     T* __restrict__ out, int64_t H, int lp_log2,
                                                                     int include_self, T empty_val,
                                                                     unsigned long long* __restrict__ extreme,
-                                                                    typename elem<T>::acc* __restrict__ ties, int glog) {
+                                                                    typename elem<T>::acc* __restrict__ ties, int glog,
+                                                                    SplitWs W) {
   using A = typename elem<T>::acc;
   const int lane = threadIdx.x;
   const Unit<T, EPL> U = make_unit<T, EPL, false, 1, true>(L, L, nullptr, blockIdx.x, 0, H, lp_log2, lane, glog);
@@ -635,16 +694,38 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_ranks_kernel(rua_layout L
     int64_t total = (U.rsub == 0 && (lane & ((1 << lp_log2) - 1)) == 0 && U.live) ? U.len : 0;   // one lane per sequence
 #pragma unroll
     for (int d = RUA_WAVE / 2; d > 0; d >>= 1) total += __shfl_xor(total, d, RUA_WAVE);
-    if (t_hi * per_wave > 2 * total + (int64_t)64 * per_wave) {        // (wave-uniform)
+    if (t_hi * per_wave > 2 * total + (int64_t)64 * per_wave || (SPLIT && t_hi > W.split)) {        // (wave-uniform)
       for (int g = 0; g < per_wave; ++g) {
         const int64_t q = (int64_t)blockIdx.x * per_wave + g;
         if (q >= L.B) break;
         const Unit<T, EPL> V = make_unit<T, EPL, false, 1, false>(L, L, nullptr, q, 0, H, lp_log2, lane);
         Fold<A, EPL> fv;
         fold_init<A, EPL, OP>(fv);
-        fold_rows<T, EPL, OP, NT, false, 1, false>(V, 0, V.len, data, H, fv, L, nullptr, lane);
-        fold_wave<A, EPL, OP, false>(fv, lp_log2);
-        fold_store<T, EPL, OP, 1, false>(V, fv, out, H, include_self, empty_val, ties);
+        if (SPLIT && V.len > W.split) {                  // (as in seg_reduce_kernel: part 0 here, the rest published)
+          const int64_t nparts = (V.len + W.split - 1) / W.split;
+          int64_t pbase = 0, ibase = 0;
+          if (lane == 0) {
+            const unsigned long long old = atomicAdd(&W.ctr[0], (1ull << 32) | (unsigned long long)(nparts - 1));
+            ibase = (int64_t)(old & 0xffffffffull);
+            const int64_t li = (int64_t)(old >> 32);
+            pbase = ibase + li;
+            int64_t* e = W.long_list + li * 4;
+            e[0] = q; e[1] = 0; e[2] = nparts; e[3] = pbase;
+          }
+          pbase = __shfl(pbase, 0, RUA_WAVE);
+          ibase = __shfl(ibase, 0, RUA_WAVE);
+          for (int64_t pp = 1 + lane; pp < nparts; pp += RUA_WAVE) {
+            int64_t* e = W.items + (ibase + pp - 1) * 4;
+            e[0] = q; e[1] = 0; e[2] = pp; e[3] = pbase + pp;
+          }
+          fold_rows<T, EPL, OP, NT, false, 1, false>(V, 0, W.split, data, H, fv, L, nullptr, lane);
+          fold_wave<A, EPL, OP, false>(fv, lp_log2);
+          store_partial<A, EPL, OP>(W.partials, pbase, lane, fv);
+        } else {
+          fold_rows<T, EPL, OP, NT, false, 1, false>(V, 0, V.len, data, H, fv, L, nullptr, lane);
+          fold_wave<A, EPL, OP, false>(fv, lp_log2);
+          fold_store<T, EPL, OP, 1, false>(V, fv, out, H, include_self, empty_val, ties);
+        }
         fold_flags<A, EPL, OP>(fv, extreme, lane, V.len <= 0);
       }
       return;
@@ -692,7 +773,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_tail_kernel(rua_layout L,
 //           [w*per, (w+1)*per) in order, then wave 0 folds the 16 range results in wave order.
 // Either association depends only on the part count, so the result is bitwise reproducible.
 constexpr int COMBINE_WAVES_MAX = 16;
-constexpr int REDUCE_HINT_NO_EMPTY = 1, REDUCE_HINT_SHORT_SEQS = 2;    // dispatch_reduce's `hints`
+constexpr int REDUCE_HINT_SHORT_SEQS = 2;    // dispatch_reduce's `hints`
 constexpr int64_t RANKS_MIN_WAVES = 4096;   // adjacent-rank waves (RANKS) only when B / ranks-per-wave still fills the chip
 constexpr int COMBINE_SOLO = 32;
 constexpr int64_t COMBINE_GRID = 512;   // 2 workgroups per CU
@@ -1361,84 +1442,28 @@ __global__ __launch_bounds__(RUA_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)
   }
 }
 
-// the rare second walk (see fold_flags): global extreme of every row the layout enumerates, into the hashed slots
-template <typename T, int EPL, bool WANT_MAX>
-__global__ __launch_bounds__(RUA_WAVE) void seg_extreme_kernel(rua_layout L, const int64_t* __restrict__ perm,
-                                                               const T* __restrict__ data, int64_t H, int lp_log2,
-                                                               int64_t n_chunks,
-                                                               unsigned long long* __restrict__ extreme) {
-  using A = typename elem<T>::acc;
-  constexpr int OP2 = WANT_MAX ? RUA_MAX : RUA_MIN;
-  const unsigned long long flags = extreme[EXTREME_SLOTS];
-  if ((flags & 2ull) == 0ull || (flags & 1ull) != 0ull) return;   // nothing is empty, or NaN decides everything
-  const int lane = threadIdx.x;
-  Fold<A, EPL> f;
-  fold_init<A, EPL, OP2>(f);
-  bool any = false;
-  for (int64_t wid = blockIdx.x; wid < L.B * n_chunks; wid += gridDim.x) {
-    const int64_t q = wid / n_chunks;
-    const Unit<T, EPL> U = make_unit<T, EPL, false>(L, L, perm, q, wid - q * n_chunks, H, lp_log2, lane);
-    if (U.len <= 0) continue;
-    fold_rows<T, EPL, OP2, false, false>(U, 0, U.len, data, H, f, L, nullptr, lane);
-    any = true;
-  }
-  if (!any) return;
-  A ext = f.acc[0];
-#pragma unroll
-  for (int e = 1; e < EPL; ++e) ext = WANT_MAX ? fmaxx(ext, f.acc[e]) : fminx(ext, f.acc[e]);
-#pragma unroll
-  for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {
-    const A o = __shfl_xor(ext, d, RUA_WAVE);
-    ext = WANT_MAX ? fmaxx(ext, o) : fminx(ext, o);
-  }
-  if (lane == 0) {
-    const int slot = (int)(blockIdx.x & (EXTREME_SLOTS - 1));
-    // zero-neutral in both directions (a scratch that arrives zeroed needs no initialising launch): the maximum is
-    // kept as its ordered bits, the minimum as their complement, both under atomicMax
-    if (WANT_MAX) atomicMax(&extreme[slot], (unsigned long long)ordered_bits(ext));
-    else atomicMax(&extreme[slot], ~(unsigned long long)ordered_bits(ext));
-  }
-}
+// ---- the reference's global `initial` written where it shows (see fold_flags)
+// extreme scratch (RUA_EXTREME_WORDS = 1 027 words): [0..1023] hashed slots of the opposite extreme (zero-neutral),
+// [1024] flags, [1025] fill_empty_kernel's reset ticket, [1026] spare.
 
-// extreme scratch (67 words): [0..63] hashed slots (zero-neutral, see seg_extreme_kernel), [64] flags, [65] a ticket
-// counter, [66] extreme_fill_kernel's "who finished the walk last" ticket.
-// `reset`: the scratch is the caller's persistent, zeroed buffer (RUA_OP_SCRATCH_CLEAN): the LAST workgroup to have
-// read it (ticket) puts it back to zero, so the next call needs no initialising launch either.
+// Waves `w0, w0 + nw, ...` of `nw` take 64 sequences each per step: only empty sequences (or everything, when a NaN
+// poisoned `initial`) are written.  A lane inspects one sequence, then the wave writes the marked rows together, lanes
+// side by side along H (coalesced stores; the poisoned case rewrites the whole [B, H] output).
+// Rows of whole 16-byte pieces at 16-byte addresses are written as such (element-wide stores made a mostly-empty batch
+// 14 GB/s per workgroup: profiles/r04_shape_cliffs.txt).
 template <typename T>
 __device__ __forceinline__ void fill_empty_body(const rua_layout& L, T* __restrict__ out, int64_t H,
                                                 int want_max_of_data, const unsigned long long* __restrict__ ext,
-                                                unsigned long long flags, int64_t first_block, int64_t n_blocks);
-
-template <typename T>
-__global__ __launch_bounds__(RUA_BLOCK) void fill_empty_kernel(rua_layout L, T* __restrict__ out, int64_t H,
-                                                               int want_max_of_data,
-                                                               unsigned long long* __restrict__ ext, int reset) {
-  const unsigned long long flags = ext[EXTREME_SLOTS];
-  // the common case: nothing was raised, so nothing needs patching AND nothing needs resetting — the scratch is still
-  // all zero.  (Every workgroup used to take the reset ticket regardless: B / 256 atomics on ONE address, 0.6 ms after
-  // a reduce over 8 M short sequences, ~1-5 us at the BASELINE shapes: profiles/r04_cat_ranks_ab.txt)
-  if (flags == 0ull) return;
-  fill_empty_body<T>(L, out, H, want_max_of_data, ext, flags, blockIdx.x, gridDim.x);   // rare: a NaN or an empty segment
-  if (!reset) return;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    const unsigned long long t = atomicAdd(&ext[EXTREME_SLOTS + 1], 1ull);
-    if (t == (unsigned long long)gridDim.x - 1ull) {
-      for (int i = 0; i < EXTREME_SLOTS + 3; ++i) ext[i] = 0ull;
-      __threadfence();
-    }
-  }
-}
-
-template <typename T>
-__device__ __forceinline__ void fill_empty_body(const rua_layout& L, T* __restrict__ out, int64_t H,
-                                                int want_max_of_data, const unsigned long long* __restrict__ ext,
-                                                unsigned long long flags, int64_t first_block, int64_t n_blocks) {
+                                                unsigned long long flags, int64_t w0, int64_t nw, int lane) {
   using A = typename elem<T>::acc;
-  // decode the tracked extreme: lane i reads slot i (past this CU's L1: other workgroups' atomics wrote it), 6-step butterfly
-  const int lane = threadIdx.x & (RUA_WAVE - 1);
-  unsigned long long best = __hip_atomic_load(&ext[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // decode the tracked extreme: lane i reads slots i, i + 64, ... (past this CU's L1: other workgroups' atomics wrote
+  // them), then a 6-step butterfly
+  unsigned long long best = 0ull;
+#pragma unroll
+  for (int k = 0; k < EXTREME_SLOTS / RUA_WAVE; ++k) {
+    const unsigned long long o = __hip_atomic_load(&ext[k * RUA_WAVE + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    best = o > best ? o : best;
+  }
 #pragma unroll
   for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {
     const unsigned long long o = __shfl_xor(best, d, RUA_WAVE);
@@ -1451,19 +1476,12 @@ __device__ __forceinline__ void fill_empty_body(const rua_layout& L, T* __restri
   if (poison) val = val - val + (A)__builtin_nanf("");
   const T tv = elem<T>::down(val);
 
-  // only empty sequences (or everything, when a NaN poisoned `initial`) are written.  A lane inspects one sequence,
-  // then the wave writes the marked rows together, lanes side by side along H (coalesced stores; the poisoned case
-  // rewrites the whole [B, H] output).  Workgroups stride over the batch (the merged kernel's grid is capped).
-  // rows of whole 16-byte pieces at 16-byte addresses are written as such: when the LAST workgroup patches a batch
-  // that is mostly empty by itself (extreme_fill_kernel), element-wide stores made it 14 GB/s — 138 MB of empty rows
-  // took 10 ms where the reduce takes 0.7 (profiles/r04_shape_cliffs.txt)
   constexpr int VE = 16 / (int)sizeof(T);
   const bool wide = (H % VE) == 0 && ((uintptr_t)out & 15) == 0;
   struct alignas(16) Piece { T v[VE]; } piece;
 #pragma unroll
   for (int e = 0; e < VE; ++e) piece.v[e] = tv;
-  for (int64_t base = first_block * RUA_BLOCK; base < L.B; base += n_blocks * RUA_BLOCK) {
-    const int64_t b0 = base + (int64_t)(threadIdx.x >> 6) * RUA_WAVE;
+  for (int64_t b0 = w0 * RUA_WAVE; b0 < L.B; b0 += nw * RUA_WAVE) {
     const int64_t b = b0 + lane;
     const bool mine = b < L.B && (poison || seq_len(L, b) <= 0);
     if (wide && H / VE <= 8) {           // narrow rows: every lane writes its own sequence's row
@@ -1488,72 +1506,31 @@ __device__ __forceinline__ void fill_empty_body(const rua_layout& L, T* __restri
   }
 }
 
-// rua_fill_empty with the payload at hand (the default from round 2): ONE trailing launch does what seg_extreme_kernel
-// + fill_empty_kernel did in two.  Common case: every workgroup reads the flag word and leaves.  Some segment empty
-// (and no NaN): phase A, the workgroups walk the payload together for its global extreme; the workgroup that
-// finishes LAST (a ticket in scratch word [66]) then patches the empty segments by itself — no grid barrier: a
-// spinning barrier needs every workgroup resident at once, which concurrent launches on other streams could deny
-// (a hang is not a price for the rare path: one workgroup writes ~100 GB/s, 64 MB of empty rows in under a ms).
-constexpr int64_t EXTREME_FILL_GRID = 1024;   // workgroups of the (rare) walk; the common case only reads a flag
-template <typename T, int EPL, bool WANT_MAX>
-__global__ __launch_bounds__(RUA_BLOCK) void extreme_fill_kernel(rua_layout L, const int64_t* __restrict__ perm,
-                                                                 const T* __restrict__ data, T* __restrict__ out,
-                                                                 int64_t H, int lp_log2, int64_t n_chunks,
-                                                                 unsigned long long* __restrict__ ext, int reset) {
-  using A = typename elem<T>::acc;
-  constexpr int OP2 = WANT_MAX ? RUA_MAX : RUA_MIN;
+// The trailing launch of max / min / logsumexp.  Common case: nothing was raised — every workgroup reads the flag word
+// and leaves (the first one wipes the slots on its way: the reduce wrote them).  Otherwise EVERY workgroup patches its
+// share of the batch (the global extreme is already in the slots), and the one that finishes last — a ticket — hands
+// the scratch back zeroed (`reset`: the caller's persistent buffer, RUA_OP_SCRATCH_CLEAN).
+template <typename T>
+__global__ __launch_bounds__(RUA_BLOCK) void fill_empty_kernel(rua_layout L, T* __restrict__ out, int64_t H,
+                                                               int want_max_of_data,
+                                                               unsigned long long* __restrict__ ext, int reset) {
   const unsigned long long flags = ext[EXTREME_SLOTS];
-  if (flags == 0ull) return;      // nothing raised: nothing to patch, nothing to reset (see fill_empty_kernel)
-  {
-    if ((flags & 2ull) != 0ull && (flags & 1ull) == 0ull) {   // grid-uniform: the flags are final
-      const int lane = threadIdx.x & (RUA_WAVE - 1);
-      const int64_t gw = (int64_t)blockIdx.x * RUA_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-      const int64_t nw = (int64_t)gridDim.x * RUA_WAVES_PER_BLOCK;
-      Fold<A, EPL> f;
-      fold_init<A, EPL, OP2>(f);
-      bool any = false;
-      for (int64_t wid = gw; wid < L.B * n_chunks; wid += nw) {
-        const int64_t q = wid / n_chunks;
-        const Unit<T, EPL> U = make_unit<T, EPL, false>(L, L, perm, q, wid - q * n_chunks, H, lp_log2, lane);
-        if (U.len <= 0) continue;
-        fold_rows<T, EPL, OP2, false, false>(U, 0, U.len, data, H, f, L, nullptr, lane);
-        any = true;
-      }
-      if (any) {
-        A e0 = f.acc[0];
-#pragma unroll
-        for (int e = 1; e < EPL; ++e) e0 = WANT_MAX ? fmaxx(e0, f.acc[e]) : fminx(e0, f.acc[e]);
-#pragma unroll
-        for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {
-          const A o = __shfl_xor(e0, d, RUA_WAVE);
-          e0 = WANT_MAX ? fmaxx(e0, o) : fminx(e0, o);
-        }
-        if (lane == 0) {
-          const int slot = (int)(gw & (EXTREME_SLOTS - 1));
-          if (WANT_MAX) atomicMax(&ext[slot], (unsigned long long)ordered_bits(e0));
-          else atomicMax(&ext[slot], ~(unsigned long long)ordered_bits(e0));
-        }
-      }
-      __shared__ int s_last;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        __threadfence();
-        s_last = atomicAdd(&ext[EXTREME_SLOTS + 2], 1ull) == (unsigned long long)gridDim.x - 1ull;
-        __threadfence();
-      }
-      __syncthreads();
-      if (s_last) fill_empty_body<T>(L, out, H, WANT_MAX ? 1 : 0, ext, flags, 0, 1);   // alone, over the whole batch
-    } else {
-      fill_empty_body<T>(L, out, H, WANT_MAX ? 1 : 0, ext, flags, blockIdx.x, gridDim.x);   // NaN: no walk needed
-    }
+  if (flags == 0ull) {
+    // nothing to patch and nobody reads the slots: no ticket (every workgroup used to take one: B / 256 atomics on
+    // ONE address, 0.6 ms after a reduce over 8 M short sequences: profiles/r04_cat_ranks_ab.txt)
+    if (reset && blockIdx.x == 0)
+      for (int i = threadIdx.x; i < EXTREME_SLOTS; i += RUA_BLOCK) ext[i] = 0ull;
+    return;
   }
+  fill_empty_body<T>(L, out, H, want_max_of_data, ext, flags, (int64_t)blockIdx.x * RUA_WAVES_PER_BLOCK + (threadIdx.x >> 6),
+                     (int64_t)gridDim.x * RUA_WAVES_PER_BLOCK, threadIdx.x & (RUA_WAVE - 1));
   if (!reset) return;
   __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence();
     const unsigned long long t = atomicAdd(&ext[EXTREME_SLOTS + 1], 1ull);
     if (t == (unsigned long long)gridDim.x - 1ull) {
-      for (int i = 0; i < EXTREME_SLOTS + 3; ++i) ext[i] = 0ull;
+      for (int i = 0; i < EXTREME_SLOTS + 3; ++i) ext[i] = 0ull;      // (rare path: one thread, 8 KB)
       __threadfence();
     }
   }
@@ -1734,8 +1711,13 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
       if (lp_log2 <= 1) glog = 4 - lp_log2;       // FOUR sequences per wave at rows of <= 32 bytes (16 / 8 rows of each
       else cat_ranks = false;                     // per instruction; the wave checks its own lengths), else one wave each
     }
+    // ([r5] a batch too small to fill the chip with every row slot its own sequence — 200 000 sequences are 3 125 such
+    // waves — still fills it four to a wave at rows of <= 32 bytes: 154 -> 54 us for 200 000 x U(1,32) rows of 16 bytes)
+    if (cat_ranks && glog == 0 && lp_log2 <= 1 && (L.B >> (6 - lp_log2)) < RANKS_MIN_WAVES) glog = 4 - lp_log2;
   }
-  if (((L.kind == RUA_PACK && L.sorted) || cat_ranks) && !copy && !perm && lp_log2 < 6 && !(split > 0 && ws) &&
+  // ([r5] with the long-sequence split armed — lengths nobody vouches for — the four-per-wave form splits by itself)
+  const bool ranks_split = split > 0 && ws && cat_ranks && glog > 0 && vec_ok && split_max_extra(L.n_rows, split) > 0;
+  if (((L.kind == RUA_PACK && L.sorted) || cat_ranks) && !copy && !perm && lp_log2 < 6 && (!(split > 0 && ws) || ranks_split) &&
       (L.B >> (6 - lp_log2 - glog)) >= RANKS_MIN_WAVES) {
     // narrow rows of a PackedSequence: adjacent ranks share a wave instruction
     // (tried for a CattedSequence with 32-byte rows too — groups = adjacent sequences: 4.0 -> 2.8 TB/s at U(8,512),
@@ -1755,9 +1737,30 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
     __builtin_memcpy(&ev, &empty_bits, sizeof(T));
     const dim3 gg((unsigned)nblk), bb(RUA_WAVE);
     unsigned long long* ext = (unsigned long long*)extreme;
+    SplitWs W = {};
+    const int64_t max_u = ranks_split ? split_max_extra(L.n_rows, split) : 0;      // (one column chunk per row here)
+    if (ranks_split) {
+      if (max_u > 0x7fffffffLL) return RUA_ERANGE;
+      W = carve_ws<typename elem<T>::acc>(ws, max_u, split);
+      const hipError_t e = hipMemsetAsync(W.ctr, 0, 4 * sizeof(unsigned long long), s);
+      if (e != hipSuccess) return (int)e;
+      W.ties = ties;
+    }
 #define RUA_RANKS(EPLV, NTV, OPV)                                                                                  \
+  do { if (ranks_split) {                                                                                               \
+    if constexpr (EPLV == FULL) {                                                                                  \
+      hipLaunchKernelGGL((seg_reduce_ranks_kernel<T, EPLV, OPV, NTV, true>), gg, bb, 0, s, L, (const T*)data, (T*)out, H, \
+                         lp_log2, include_self, ev, ext, (typename elem<T>::acc*)ties, glog, W);                   \
+      hipLaunchKernelGGL((seg_reduce_tail_kernel<T, EPLV, OPV, NTV, false, 1>), dim3(split_grid(max_u)), bb, 0, s, L, \
+                         (const int64_t*)nullptr, (const T*)data, H, lp_log2, ext, L, (T*)nullptr, W);             \
+      hipLaunchKernelGGL((seg_reduce_combine_kernel<T, EPLV, OPV, 1>),                                             \
+                         dim3((unsigned)(max_u < COMBINE_GRID ? max_u : COMBINE_GRID)),                            \
+                         dim3(RUA_WAVE * COMBINE_WAVES_MAX), 0, s, L, (const int64_t*)nullptr, (T*)out, H, lp_log2, \
+                         include_self, ev, L, 0, W);                                                               \
+    }                                                                                                              \
+  } else                                                                                                           \
   hipLaunchKernelGGL((seg_reduce_ranks_kernel<T, EPLV, OPV, NTV>), gg, bb, 0, s, L, (const T*)data, (T*)out, H,    \
-                     lp_log2, include_self, ev, ext, (typename elem<T>::acc*)ties, glog)
+                     lp_log2, include_self, ev, ext, (typename elem<T>::acc*)ties, glog, W); } while (0)
 #define RUA_RANKS_OP(EPLV, NTV)                                  \
   switch (op) {                                                  \
     case RUA_SUM: RUA_RANKS(EPLV, NTV, RUA_SUM); break;          \
@@ -1819,39 +1822,15 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
 }
 
 
-// the reduce, then (max / min / logsumexp with the reference's `initial`) the conditional second walk for the
-// global extreme: every workgroup of it exits on the flag word unless some segment is empty
-constexpr int64_t EXTREME_GRID = 8192;
-
+// (rounds 1-4 launched a conditional second walk for the global extreme behind the reduce; the reduce now tracks it
+// itself — fold_flags — so this is the reduce and nothing else)
 template <typename T>
 static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,
                            void* out, int64_t H, int include_self, uint64_t empty_bits, void* extreme,
                            int64_t split, void* ws, const rua_layout* CD = nullptr, void* copy = nullptr,
                            void* ties = nullptr, int hints = 0) {
-  const bool no_empty = (hints & REDUCE_HINT_NO_EMPTY) != 0;
-  const int r = dispatch_reduce_main<T>(op, s, L, perm, data, out, H, include_self, empty_bits, extreme, split, ws, CD,
-                                        copy, ties, (hints & REDUCE_HINT_SHORT_SEQS) != 0);
-  if (r != 0 || !extreme || !(op == RUA_MAX || op == RUA_MIN || op == RUA_LOGSUMEXP)) return r;
-  if (no_empty) return r;     // the caller vouches that no sequence is empty (RUA_OP_NO_EMPTY): no second walk to arm
-  // (a PackedSequence may carry zero-length sequences too — C.pack() of lens such as [0,3,0,2] — so PACK takes the
-  // same lazy second walk: every workgroup leaves on the flag word unless a sequence was empty or a NaN showed)
-  constexpr int FULL = 16 / sizeof(T);
-  const bool vec_ok = (H % FULL == 0) && ((uintptr_t)data % 16 == 0);
-  const int64_t lpr = (H + (vec_ok ? FULL : 1) - 1) / (vec_ok ? FULL : 1);
-  int lp_log2 = 0;
-  while ((1 << lp_log2) < lpr && lp_log2 < 6) ++lp_log2;
-  const int64_t n_chunks = (lpr + RUA_WAVE - 1) / RUA_WAVE;
-  const int64_t units = L.B * n_chunks;
-  if (units <= 0) return 0;
-  const dim3 g((unsigned)(units < EXTREME_GRID ? units : EXTREME_GRID)), b(RUA_WAVE);
-  unsigned long long* ext = (unsigned long long*)extreme;
-#define RUA_EXT(EPLV, WMAX)                                                                                    \
-  hipLaunchKernelGGL((seg_extreme_kernel<T, EPLV, WMAX>), g, b, 0, s, L, perm, (const T*)data, H, lp_log2,     \
-                     n_chunks, ext)
-  if (op == RUA_MIN) { if (vec_ok) RUA_EXT(FULL, true); else RUA_EXT(1, true); }
-  else { if (vec_ok) RUA_EXT(FULL, false); else RUA_EXT(1, false); }
-#undef RUA_EXT
-  return (int)hipGetLastError();
+  return dispatch_reduce_main<T>(op, s, L, perm, data, out, H, include_self, empty_bits, extreme, split, ws, CD, copy,
+                                 ties, (hints & REDUCE_HINT_SHORT_SEQS) != 0);
 }
 
 template <typename T, int EPL>
@@ -2032,29 +2011,6 @@ static int dispatch_backward(int op, hipStream_t s, const rua_layout& L, const i
                                split, ws, ties, ties_final, self_in);
 }
 
-template <typename T>
-static int launch_extreme_fill(hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data, void* out,
-                               int64_t H, int want_max, void* ext, int reset) {
-  constexpr int FULL = 16 / sizeof(T);
-  const bool vec_ok = (H % FULL == 0) && ((uintptr_t)data % 16 == 0);
-  const int64_t lpr = (H + (vec_ok ? FULL : 1) - 1) / (vec_ok ? FULL : 1);
-  int lp_log2 = 0;
-  while ((1 << lp_log2) < lpr && lp_log2 < 6) ++lp_log2;
-  const int64_t n_chunks = (lpr + RUA_WAVE - 1) / RUA_WAVE;
-  int64_t grid = (L.B + RUA_BLOCK - 1) / RUA_BLOCK;
-  if (grid > EXTREME_FILL_GRID) grid = EXTREME_FILL_GRID;
-  if (grid < 1) grid = 1;
-  const dim3 g((unsigned)grid), b(RUA_BLOCK);
-  unsigned long long* e = (unsigned long long*)ext;
-#define RUA_EF(EPLV, WMAX)                                                                                        \
-  hipLaunchKernelGGL((extreme_fill_kernel<T, EPLV, WMAX>), g, b, 0, s, L, perm, (const T*)data, (T*)out, H, lp_log2, \
-                     n_chunks, e, reset)
-  if (want_max) { if (vec_ok) RUA_EF(FULL, true); else RUA_EF(1, true); }
-  else { if (vec_ok) RUA_EF(FULL, false); else RUA_EF(1, false); }
-#undef RUA_EF
-  return (int)hipGetLastError();
-}
-
 // ---- per-dtype entry points: each element type is compiled in its own translation unit
 // (rua_reduce_<dtype>.hip) so the ~300 kernel instantiations build in parallel
 #define RUA_DECLARE_REDUCE_DTYPE(NAME)                                                                              \
@@ -2065,7 +2021,7 @@ static int launch_extreme_fill(hipStream_t s, const rua_layout& L, const int64_t
                       const void* out, const void* gout, void* gin, int64_t H, int extra_count, int64_t split,    \
                       void* ws, void* ties, bool ties_final, const void* self_in, bool fill_padding);              \
   int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, void* ext,        \
-                        int reset, const void* data, const int64_t* perm);                                       \
+                        int reset);                                                                              \
   int self_grad_##NAME(hipStream_t s, const int64_t* counts, int64_t S, int64_t H, const void* self_in,            \
                        const void* out, const void* gout, const void* aux, void* gself, int op, int inc);
 RUA_DECLARE_REDUCE_DTYPE(f32)
@@ -2088,8 +2044,7 @@ RUA_DECLARE_REDUCE_DTYPE(f64)
                                 self_in, fill_padding);                                                            \
   }                                                                                                                 \
   int fill_empty_##NAME(hipStream_t s, const rua_layout& L, void* out, int64_t H, int want_max, void* ext,        \
-                        int reset, const void* data, const int64_t* perm) {                                      \
-    if (data) return launch_extreme_fill<T>(s, L, perm, data, out, H, want_max, ext, reset);                        \
+                        int reset) {                                                                             \
     /* (the body strides over the batch: a capped grid; in the common case every workgroup reads one flag word) */ \
     hipLaunchKernelGGL(fill_empty_kernel<T>, dim3(grid_for(L.B) < 2048u ? (grid_for(L.B) ? grid_for(L.B) : 1u) : 2048u), dim3(RUA_BLOCK), 0, s, L, (T*)out, H, want_max,  \
                        (unsigned long long*)ext, reset);                                                           \

@@ -368,7 +368,7 @@ def pack_reduce(sequence: Z, op: str = 'sum', fused: bool = None):
     dst = M.lay_pack(p, lens=lens, boff=boff, T=batch_sizes.numel(), n_rows=n)
     src = describe(sequence)
     out = torch.empty((B,) + hidden, dtype=data.dtype, device=dev)
-    extreme, op_bits = O.extreme_scratch(dev, src) if code in (K.MAX, K.MIN, K.LOGSUMEXP) else (None, 0)
+    extreme, op_bits = O.extreme_scratch(dev) if code in (K.MAX, K.MIN, K.LOGSUMEXP) else (None, 0)
     split, ws = O.split_workspace(src, H, data.dtype, dev, team_ok=False)      # (the fused kernel has no wave teams)
     if O._kernel_hook:
         O._kernel_hook('pack_reduce', True)
@@ -377,16 +377,14 @@ def pack_reduce(sequence: Z, op: str = 'sum', fused: bool = None):
         O._scratch_pair.acquire()
     try:
         K.check(lib.rua_pack_reduce(src.ref(), dst.ref(), K.ptr(data), K.ptr(pdata), K.ptr(out), H, K.DTYPES[data.dtype],
-                                    code | op_bits | (K.OP_NO_EMPTY if extreme is not None else 0),
+                                    code | op_bits,
                                     O._bits(O._EMPTY[code], data.dtype), K.ptr(extreme), split, K.ptr(ws),
                                     K.stream_ptr(dev)), 'rua_pack_reduce')
         if O._kernel_hook:
             O._kernel_hook('pack_reduce', False)
         if extreme is not None:
-            walk = not (op_bits & K.OP_NO_EMPTY)
             K.check(lib.rua_fill_empty(src.ref(), K.ptr(out), H, K.DTYPES[data.dtype], code | (op_bits & K.OP_SCRATCH_CLEAN),
-                                       K.ptr(extreme), K.ptr(data) if walk else None, None, K.stream_ptr(dev)),
-                    'rua_fill_empty')
+                                       K.ptr(extreme), K.stream_ptr(dev)), 'rua_fill_empty')
     except K.RuaError:
         O.forget_extreme_scratch(dev)
         raise
