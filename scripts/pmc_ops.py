@@ -101,7 +101,8 @@ def groups():
                 del x, out, cot
 
     def odd(H):
-        """[r5] rows of 8 (mod 16) bytes (H = 500 / 1 000 in bf16), 8 GB payloads."""
+        """[r5] rows that are not a multiple of a 128-byte line: 8 (mod 16) bytes (H = 500 in bf16), whole vectors
+        (H = 1 000, 1 080), 8 GB payloads."""
         rows = int(8e9 / (H * 2))
         B = max(1024, rows // 260)
         lens, data = ragged(H, B, 8, 512, H)
@@ -136,8 +137,8 @@ def groups():
         yield f'{tag}.C.roll(0)  [calib: streaming copy, {rb} B rows]', 2 * nb, lambda: c.roll(0)
 
     import gc
-    fams = [('ns', north_star)] + [(f'w{2 * H}', (lambda H=H: narrow(H))) for H in (16, 32)]
-    fams += [('bwd', backward)] + [(f'odd{2 * H}', (lambda H=H: odd(H))) for H in (500, 1000)]
+    fams = [('ns', north_star)] + [(f'w{2 * H}', (lambda H=H: narrow(H))) for H in (16, 32)] + [('n16', lambda: narrow(8))]
+    fams += [('bwd', backward)] + [(f'odd{2 * H}', (lambda H=H: odd(H))) for H in (500, 1000, 1080)]
     fams += [(f'w{rb}', (lambda rb=rb: tiny(rb))) for rb in (8, 4, 2, 1)]
     for fam, gen in fams:
         if ONLY and not any(fam.startswith(o) for o in ONLY):

@@ -307,7 +307,10 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
             x[u] = elem<T>::up(p[u][c].v[e]);
             cm = nmax(cm, x[u]);
           }
-          // the opposite extreme counts the rows that are there only (the others were made -inf above)
+          // the opposite extreme counts the rows that are there only (the others were made -inf above).  (A minimum per
+          // column first and ONE link into f.opp — a shorter dependency chain — was measured and is slower: cfg2
+          // reduce_logsumexp(p) 112 -> 125 us; this loop is the one reduction where the ALU shows, and the tracking costs
+          // it 8-10 % at cfg3, where a wave lives for 32 rows: profiles/r05_initial_ab.txt)
           if (all_there) {
 #pragma unroll
             for (int u = 0; u < UT; ++u) f.opp = nmin(f.opp, x[u]);
