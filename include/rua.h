@@ -81,7 +81,9 @@ typedef struct rua_layout {
   const int64_t* tptr;     /* LIST: [M]                                     */
   /* PACK, optional: a (rank x time) tile table that lets narrow-row C/L/R <-> P transposes move
    * multi-row runs on BOTH sides (rua_move_rows picks it up when rows are <= 64 bytes) .        */
-  const int64_t* bsz;        /* device copy of batch_sizes [T]                                   */
+  const int64_t* bsz;        /* PACK: device copy of batch_sizes [T].  CAT (optional, ABI 6): ONE word, the number of
+                                lengths <= 0 (rua_exclusive_scan_i64's total[1]): 0 lets max / min / logsumexp skip
+                                the tracking of the reference's global `initial` (rua_segment_reduce)            */
   const int64_t* tile_start; /* [n_tchunks + 1]: tile_start[c] = sum_{c'<c} ceil(batch_sizes[TT*c']/TR) (TT time steps, TR ranks per tile) */
   int64_t n_tchunks;         /* ceil(T / TT)                                                     */
   int64_t n_tiles;           /* tile_start[n_tchunks] (the caller knows it: batch_sizes is a host tensor) */
@@ -110,7 +112,9 @@ enum rua_tmap {
 #define RUA_MOVE_NO_NARROW 2048    /* rows of one vector (1 .. 16 bytes): the generic kernel instead of the lane-per-row one */
 
 /* K1. Exclusive prefix sum of n int64 (wavefront scan).  out[i] = sum(in[0..i)).
- * `ws` must hold rua_scan_ws_elems(n) int64.  If total != NULL, *total (device) = sum(in).
+ * `ws` must hold rua_scan_ws_elems(n) int64.  If total != NULL it points at TWO device words (ABI 6; one before):
+ * total[0] = sum(in), total[1] = #{i : in[i] <= 0} — of a length vector: the number of EMPTY sequences, which a CAT
+ * layout may hand to rua_segment_reduce (rua_layout::bsz).
  * Replaces get_offsets, utils.py:16-19 (cumsum + roll + [0]=0). */
 int64_t rua_scan_ws_elems(int64_t n);
 int rua_exclusive_scan_i64(const int64_t* in, int64_t* out, int64_t* total, int64_t n,
@@ -209,15 +213,22 @@ enum rua_op {
  * of the sequence equal it (with include_self == 1 the old row is folded into the result but not counted; rows that
  * include_self == 2 leaves untouched are not written: pre-zero the buffer) — what the backward needs, for free in the pass that
  * reads the payload anyway (rua_segment_reduce_backward with include_self = RUA_TIES_FINAL then takes ONE walk).
- * One bit may be OR-ed into `op` (here, in rua_pack_reduce and in rua_fill_empty) by a caller that keeps ONE persistent
- * `extreme` scratch of RUA_EXTREME_WORDS uint64 per stream, zeroed once when it was allocated:
- *   RUA_OP_SCRATCH_CLEAN  the scratch arrives zeroed: no initialising launch; rua_fill_empty (which must then be
- *                         called with the same bit) hands it back zeroed.
- * (0x200 was RUA_OP_NO_EMPTY up to ABI 5 — "do not arm the second walk" — and is ignored now.  Dropping the trailing
- * launch altogether — the reduce's last wave patching the output, found by tickets — was built and measured in round 5:
- * no gain at the BASELINE shapes, a loss where waves are short; profiles/r05_self_patch_ab.txt.) */
+ * Bits that may be OR-ed into `op`:
+ *   RUA_OP_SCRATCH_CLEAN  (here, in rua_pack_reduce and in rua_fill_empty) by a caller that keeps ONE persistent `extreme`
+ *                         scratch of RUA_EXTREME_WORDS uint64 per stream, zeroed once when it was allocated: the scratch
+ *                         arrives zeroed, so no initialising launch; rua_fill_empty (which must then be called with the
+ *                         same bit) hands it back zeroed.
+ *   RUA_OP_NO_EMPTY       (here and in rua_pack_reduce) the caller PROVES that no sequence is empty — lengths it holds on
+ *                         the host, a PackedSequence whose batch_sizes[0] equals its sequence count: nothing will ever
+ *                         ask for the global extreme, so the reduce does not track it (a NaN still poisons everything:
+ *                         that needs no extreme).  Up to ABI 5 the bit meant "do not arm the second walk".  The device
+ *                         can prove the same by itself: a CAT layout may carry in `bsz` a pointer to the number of
+ *                         lengths <= 0, as rua_exclusive_scan_i64 leaves it in total[1] (rua_layout, below).
+ * (Dropping the trailing launch altogether — the reduce's last wave patching the output, found by tickets — was built
+ * and measured in round 5: no gain at the BASELINE shapes, a loss where waves are short; profiles/r05_self_patch_ab.txt.) */
 #define RUA_EXTREME_WORDS    1027
 #define RUA_OP_SCRATCH_CLEAN 0x100
+#define RUA_OP_NO_EMPTY      0x200
 /* rua_segment_reduce over a CattedSequence with rows narrower than 1 KiB: the caller KNOWS the lengths and vouches
  * that no sequence is far above the average (torchrua_amd: at most 8 x the average, or 64 rows).  When the sequences
  * are short (16 .. 64 rows on average by row width) every row slot of a wave then takes a sequence of its own — one

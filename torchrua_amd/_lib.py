@@ -25,7 +25,7 @@ BWD_TIES_POSITIVE = 0x200  # ... OR-ed in (max/min): torch.segment_reduce's tie 
 MOVE_SCATTER = 1
 MOVE_NT_ON, MOVE_NT_OFF = 2, 4       # rua.h: force / forbid non-temporal payload accesses
 MOVE_NO_NARROW = 2048               # rua.h: developer A/B — rows of one vector through the generic kernel
-OP_SCRATCH_CLEAN = 0x100                          # rua.h: bit OR-ed into `op` (persistent zeroed extreme scratch)
+OP_SCRATCH_CLEAN, OP_NO_EMPTY = 0x100, 0x200      # rua.h: bits OR-ed into `op` (persistent zeroed extreme scratch; no sequence is empty: proven)
 EXTREME_WORDS = 1027                               # rua.h: RUA_EXTREME_WORDS
 OP_SHORT_SEQS = 0x400      # rua.h: a CattedSequence of short sequences, none far above the average (a hint)
 # enum rua_dtype / rua_op

@@ -76,7 +76,7 @@ def exclusive_scan(x: Tensor, want_total: bool = False):
     lib = L.load()
     n = x.numel()
     out = torch.empty(n, dtype=torch.long, device=dev)
-    total = torch.empty(1, dtype=torch.long, device=dev) if want_total else None
+    total = torch.empty(2, dtype=torch.long, device=dev) if want_total else None     # [sum, #{x <= 0}] (rua.h, ABI 6)
     ws = torch.empty(lib.rua_scan_ws_elems(n), dtype=torch.long, device=dev)
     L.check(lib.rua_exclusive_scan_i64(L.ptr(x), L.ptr(out), L.ptr(total), n, L.ptr(ws), L.stream_ptr(dev)),
             'rua_exclusive_scan_i64')
@@ -152,11 +152,33 @@ def total_len(token_sizes: Tensor) -> int:
 
 
 def dev_off(token_sizes: Tensor) -> Tensor:
-    """Exclusive offsets of a device length vector (K1), memoised."""
+    """Exclusive offsets of a device length vector (K1), memoised — and with them the scan's count of lengths <= 0
+    (`dev_n_empty`): one word on the device that lets max / min / logsumexp skip tracking the reference's global `initial`
+    when it reads 0 (rua_layout::bsz of a CAT layout)."""
     hit = _memo_get(token_sizes, 'off')
     if hit is not None:
         return hit
-    return _memo_put(token_sizes, 'off', exclusive_scan(_as_lens(token_sizes)))
+    off, total = exclusive_scan(_as_lens(token_sizes), want_total=True)
+    _memo_put(token_sizes, 'n_empty_dev', total[1:2])
+    return _memo_put(token_sizes, 'off', off)
+
+
+def dev_n_empty(token_sizes: Tensor) -> Optional[Tensor]:
+    """The one-word device tensor dev_off left behind (None when the offsets came from somewhere else)."""
+    return _memo_get(token_sizes, 'n_empty_dev')
+
+
+def known_no_empty(token_sizes: Optional[Tensor]) -> bool:
+    """True when the HOST can tell without a device sync that every sequence holds at least one row."""
+    if token_sizes is None:
+        return False
+    hit = _memo_get(token_sizes, 'min')
+    if hit is None:
+        if token_sizes.is_cuda and _memo_get(token_sizes, 'host') is None:
+            return False
+        h = host_lens(token_sizes)
+        hit = _memo_put(token_sizes, 'min', int(h.detach().numpy().min()) if h.numel() else 1)
+    return hit > 0
 
 
 # ------------------------------------------------------------------ PackedSequence metadata
@@ -364,7 +386,7 @@ def known_max_len(token_sizes: Optional[Tensor]) -> Optional[int]:
 
 class Lay:
     """A rua_layout plus the tensors its pointers borrow (kept alive with it)."""
-    __slots__ = ('c', 'keep', 'kind', 'n_rows', 'B', 'max_len', 'heavy_tail')
+    __slots__ = ('c', 'keep', 'kind', 'n_rows', 'B', 'max_len', 'heavy_tail', '_no_empty')
 
     def __init__(self, keep: List[Optional[Tensor]], max_len: Optional[int] = None, **fields):
         self.c = L.RuaLayout(**fields)
@@ -374,9 +396,17 @@ class Lay:
         self.B = fields['B']
         self.max_len = max_len      # longest sequence, when the host knows it for free
         self.heavy_tail = False     # the buckets of a scatter_*: sizes counted on the device, ONE hot bucket is ordinary
+        self._no_empty = False      # bool, or a callable that decides on first use (only max / min / logsumexp ask)
 
     def ref(self):
         return ctypes.byref(self.c)
+
+    @property
+    def no_empty(self) -> bool:
+        """The HOST can prove, without a device sync, that every sequence holds at least one row (RUA_OP_NO_EMPTY)."""
+        if callable(self._no_empty):
+            self._no_empty = bool(self._no_empty())
+        return self._no_empty
 
 
 def lay_cat(lens: Optional[Tensor], B: int, n_rows: int, len_add: int = 0) -> Lay:
@@ -387,8 +417,12 @@ def lay_cat(lens: Optional[Tensor], B: int, n_rows: int, len_add: int = 0) -> La
     off = dev_off(lens)
     mx = known_max_len(lens)
     longest = None if mx is None else mx + len_add
-    return Lay([lens, off], max_len=longest, kind=L.CAT, n_rows=n_rows, B=B, lens=L.ptr(lens), len_add=len_add,
-               off=L.ptr(off), T_log=longest or 0)           # (T_log of a CAT layout: the longest sequence, 0 = unknown)
+    # (bsz of a CAT layout: the device's own count of empty sequences, when the offsets came from dev_off's scan)
+    ne = dev_n_empty(lens) if len_add == 0 else None
+    lay = Lay([lens, off, ne], max_len=longest, kind=L.CAT, n_rows=n_rows, B=B, lens=L.ptr(lens), len_add=len_add,
+              off=L.ptr(off), T_log=longest or 0, bsz=L.ptr(ne))   # (T_log of a CAT layout: the longest sequence, 0 = unknown)
+    lay._no_empty = (lambda: known_no_empty(lens)) if len_add >= 0 else False
+    return lay
 
 
 def lay_padded(kind: int, lens: Optional[Tensor], B: int, T_phys: int, T_log: int, len_add: int = 0,
@@ -404,7 +438,9 @@ def lay_padded(kind: int, lens: Optional[Tensor], B: int, T_phys: int, T_log: in
             keep.append(off)
             f['off'] = L.ptr(off)
     mx = len_add if lens is None else known_max_len(lens)
-    return Lay(keep, max_len=mx if lens is None or mx is None else mx + len_add, **f)
+    lay = Lay(keep, max_len=mx if lens is None or mx is None else mx + len_add, **f)
+    lay._no_empty = (len_add > 0) if lens is None else ((lambda: known_no_empty(lens)) if len_add >= 0 else False)
+    return lay
 
 
 NARROW_ROW_BYTES = 64      # rows up to this get the tile table (rua_move.hip: TILE_MAX_ROW_BYTES)
@@ -457,7 +493,9 @@ def lay_pack_steps(p, row_bytes: int, shift: int) -> Optional['Lay']:
     fields = {name: getattr(lay.c, name) for name, _ in L.RuaLayout._fields_}
     fields.update(bsz=L.ptr(t.bsz), tile_start=L.ptr(t.tile_start), n_tchunks=t.n_tchunks, n_tiles=t.n_tiles,
                   tile_t_log2=(trl << 8) | TILE_STEP_ROWS)
-    return Lay(list(lay.keep) + [t.bsz, t.tile_start], max_len=lay.max_len, **fields)
+    out = Lay(list(lay.keep) + [t.bsz, t.tile_start], max_len=lay.max_len, **fields)
+    out._no_empty = lay._no_empty
+    return out
 
 
 def tile_line_rows(row_bytes: int) -> int:
@@ -532,9 +570,12 @@ def lay_pack(p, lens: Optional[Tensor] = None, len_add: int = 0, boff: Optional[
             keep += [t.bsz, t.tile_start]
             extra.update(bsz=L.ptr(t.bsz), tile_start=L.ptr(t.tile_start), n_tchunks=t.n_tchunks, n_tiles=t.n_tiles,
                          tile_t_log2=t.code)
-    return Lay(keep, max_len=T, kind=L.PACK, n_rows=n_rows, B=pack_nseq(p),
-               lens=L.ptr(lens), len_add=len_add, boff=L.ptr(boff), T=T, sorted=L.ptr(p.sorted_indices),
-               unsorted=L.ptr(p.unsorted_indices), **extra)
+    lay = Lay(keep, max_len=T, kind=L.PACK, n_rows=n_rows, B=pack_nseq(p),
+              lens=L.ptr(lens), len_add=len_add, boff=L.ptr(boff), T=T, sorted=L.ptr(p.sorted_indices),
+              unsorted=L.ptr(p.unsorted_indices), **extra)
+    # batch_sizes[0] counts the sequences that hold a row (a host tensor): all of them, unless some are empty
+    lay._no_empty = len_add == 0 and T == p.batch_sizes.numel() and T > 0 and pack_B(p) == pack_nseq(p)
+    return lay
 
 
 class _StagingRing:

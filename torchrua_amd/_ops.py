@@ -230,7 +230,7 @@ def launch_reduce(lay: M.Lay, data: Tensor, op: int, out: Optional[Tensor] = Non
         _scratch_pair.acquire()
     try:
         L.check(lib.rua_segment_reduce(lay.ref(), L.ptr(perm), L.ptr(data), L.ptr(out), H, L.DTYPES[data.dtype],
-                                       op | op_bits | short,
+                                       op | op_bits | short | (L.OP_NO_EMPTY if extreme is not None and lay.no_empty else 0),
                                        include_self,
                                        _bits(_EMPTY[op], data.dtype), L.ptr(extreme), split, L.ptr(ws), L.ptr(ties_out),
                                        L.stream_ptr(dev)), 'rua_segment_reduce')

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(RUA_BLOCK) void scan_spine_kernel(int64_t* __restri
     if (i < nb) part[i] = carry + ex;
     carry += tot;
   }
-  if (threadIdx.x == 0 && total) *total = carry;
+  // (total[1]: the apply pass counts the inputs that are <= 0 into it — see rua_exclusive_scan_i64)
+  if (threadIdx.x == 0 && total) { total[0] = carry; total[1] = 0; }
 }
 
 // pass C: scan inside the tile, offset by the tile prefix.  Thread k owns SCAN_ITEMS
@@ -84,14 +85,28 @@ __global__ __launch_bounds__(RUA_BLOCK) void scan_spine_kernel(int64_t* __restri
 __global__ __launch_bounds__(RUA_BLOCK) void scan_apply_kernel(const int64_t* __restrict__ in, int64_t n,
                                                                const int64_t* __restrict__ part,
                                                                int64_t* __restrict__ out,
-                                                               int64_t* __restrict__ total_single) {
+                                                               int64_t* __restrict__ total_single,
+                                                               unsigned long long* __restrict__ nonpos) {
   const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
   int64_t v[SCAN_ITEMS];
   int64_t s = 0;
+  int np = 0;                                   // inputs <= 0 (a length vector: the EMPTY sequences)
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; ++k) {
     v[k] = (base + k < n) ? in[base + k] : 0;
     s += v[k];
+    np += (base + k < n && v[k] <= 0) ? 1 : 0;
+  }
+  if (total_single || nonpos) {                  // (block-uniform)
+    __shared__ int s_np;
+    if (threadIdx.x == 0) s_np = 0;
+    __syncthreads();
+    if (np) atomicAdd(&s_np, np);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (total_single) total_single[1] = s_np;                      // one tile: this block is the whole input
+      else if (s_np) atomicAdd(nonpos, (unsigned long long)s_np);    // many tiles: the spine pass zeroed the word
+    }
   }
   int64_t tot;
   int64_t run = block_exclusive_scan(s, &tot) + (part ? part[blockIdx.x] : 0);
@@ -100,7 +115,7 @@ __global__ __launch_bounds__(RUA_BLOCK) void scan_apply_kernel(const int64_t* __
     if (base + k < n) out[base + k] = run;
     run += v[k];
   }
-  if (total_single && threadIdx.x == 0) *total_single = tot;
+  if (total_single && threadIdx.x == 0) total_single[0] = tot;
 }
 
 // ------------------------------------------------------------------ PackedSequence metadata
@@ -507,21 +522,21 @@ int rua_exclusive_scan_i64(const int64_t* in, int64_t* out, int64_t* total, int6
   if (n < 0 || (n > 0 && (!in || !out))) return RUA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (n == 0) {
-    if (total) return (int)hipMemsetAsync(total, 0, sizeof(int64_t), s);
+    if (total) return (int)hipMemsetAsync(total, 0, 2 * sizeof(int64_t), s);
     return 0;
   }
   const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   if (nb > 0x7fffffffLL) return RUA_ERANGE;
   if (nb == 1) {
     hipLaunchKernelGGL(scan_apply_kernel, dim3(1), dim3(RUA_BLOCK), 0, s, in, n, (const int64_t*)nullptr, out,
-                       total);
+                       total, (unsigned long long*)nullptr);
     return (int)hipGetLastError();
   }
   if (!ws) return RUA_EINVAL;
   hipLaunchKernelGGL(scan_partials_kernel, dim3((unsigned)nb), dim3(RUA_BLOCK), 0, s, in, n, ws);
   hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(RUA_BLOCK), 0, s, ws, nb, total);
   hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(RUA_BLOCK), 0, s, in, n, (const int64_t*)ws, out,
-                     (int64_t*)nullptr);
+                     (int64_t*)nullptr, total ? (unsigned long long*)(total + 1) : (unsigned long long*)nullptr);
   return (int)hipGetLastError();
 }
 

@@ -114,7 +114,7 @@ int rua_segment_reduce(const rua_layout* lay, const int64_t* perm, const void* d
   if (lay->B == 0 || H == 0) return 0;
   if (!out || (lay->n_rows > 0 && !data)) return RUA_EINVAL;
   const bool clean = (op & RUA_OP_SCRATCH_CLEAN) != 0;
-  const int hints = (op & RUA_OP_SHORT_SEQS) ? 2 : 0;     // dispatch_reduce's hints
+  const int hints = ((op & RUA_OP_NO_EMPTY) ? 1 : 0) | ((op & RUA_OP_SHORT_SEQS) ? 2 : 0);     // dispatch_reduce's hints
   op &= 0xff;
   if (ties && op != RUA_MAX && op != RUA_MIN) return RUA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
@@ -146,7 +146,7 @@ int rua_pack_reduce(const rua_layout* src, const rua_layout* pack, const void* d
   if (!out || !pack_data || !data) return RUA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const bool clean = (op & RUA_OP_SCRATCH_CLEAN) != 0;
-  const int hints = 0;
+  const int hints = (op & RUA_OP_NO_EMPTY) ? 1 : 0;
   op &= 0xff;
   if (extreme && !clean && (op == RUA_MAX || op == RUA_MIN || op == RUA_LOGSUMEXP))
     hipLaunchKernelGGL(extreme_init_entry_kernel, dim3(1), dim3(256), 0, s, (unsigned long long*)extreme,

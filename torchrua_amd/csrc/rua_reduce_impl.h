@@ -212,7 +212,8 @@ template <typename T, int EPL, int OP, bool NT, bool COPY, int CPW = 1, bool RAN
 __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, int64_t t_hi,
                                           const T* __restrict__ data, int64_t H,
                                           Fold<typename elem<T>::acc, EPL * CPW>& f, const rua_layout& CD,
-                                          T* __restrict__ copy, int lane, int team_w = 0, int team_n = 1) {
+                                          T* __restrict__ copy, int lane, int team_w = 0, int team_n = 1,
+                                          bool track = true) {
   using A = typename elem<T>::acc;
   constexpr int UT = CPW == 1 ? UNROLL_T : UNROLL_T / 2;     // rows in flight (x CPW loads each)
   constexpr int CW = RUA_WAVE * EPL;                          // elements per 64-lane column chunk
@@ -311,7 +312,8 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
           // column first and ONE link into f.opp — a shorter dependency chain — was measured and is slower: cfg2
           // reduce_logsumexp(p) 112 -> 125 us; this loop is the one reduction where the ALU shows, and the tracking costs
           // it 8-10 % at cfg3, where a wave lives for 32 rows: profiles/r05_initial_ab.txt)
-          if (all_there) {
+          if (!track) {
+          } else if (all_there) {
 #pragma unroll
             for (int u = 0; u < UT; ++u) f.opp = nmin(f.opp, x[u]);
           } else {
@@ -349,7 +351,7 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
             if (CPW > 1 && col + c * CW >= H) continue;
             const A x = elem<T>::up(p[u][c].v[e]);
             m[ce] = MX ? nmax(m[ce], x) : nmin(m[ce], x);
-            f.opp = MX ? nmin(f.opp, x) : nmax(f.opp, x);
+            if (track) f.opp = MX ? nmin(f.opp, x) : nmax(f.opp, x);
           }
         }
         bool any_nan = false;
@@ -400,8 +402,8 @@ __device__ __forceinline__ void fold_rows(const Unit<T, EPL>& U, int64_t t_lo, i
             const A x = elem<T>::up(p[u][c].v[e]);
             if (OP == RUA_SUM || OP == RUA_MEAN) f.acc[ce] += x;
             else if (OP == RUA_PROD) f.acc[ce] *= x;
-            else if (OP == RUA_MAX) { f.acc[ce] = nmax(f.acc[ce], x); f.opp = nmin(f.opp, x); }   // v_maximum3_f32: NaN-propagating like torch
-            else if (OP == RUA_MIN) { f.acc[ce] = nmin(f.acc[ce], x); f.opp = nmax(f.opp, x); }
+            else if (OP == RUA_MAX) { f.acc[ce] = nmax(f.acc[ce], x); if (track) f.opp = nmin(f.opp, x); }   // v_maximum3_f32: NaN-propagating like torch
+            else if (OP == RUA_MIN) { f.acc[ce] = nmin(f.acc[ce], x); if (track) f.opp = nmax(f.opp, x); }
           }
         }
       }
@@ -525,9 +527,23 @@ __device__ __forceinline__ int extreme_slot() {
   return (int)(((unsigned)blockIdx.x * 17u + (threadIdx.x >> 6) * 5u) & (unsigned)(EXTREME_SLOTS - 1));
 }
 
+// Does this launch need the global extreme at all?  Only if some sequence may be EMPTY.  The caller can rule that out
+// (RUA_OP_NO_EMPTY: lengths it holds on the host; a PackedSequence, whose batch_sizes live there), and so can the device:
+// a CAT layout may carry, in `bsz`, a pointer to the number of lengths <= 0 as rua_exclusive_scan_i64 counted them while
+// it made `off` (total[1]) — one uniform load per wave, of a word an earlier launch wrote.  Then the hot loops leave
+// Fold::opp alone and no wave sends its atomic: logsumexp, the one loop where the ALU shows, got 8-10 % back at cfg3,
+// where a wave lives for 32 rows (profiles/r05_initial_ab.txt).  A NaN needs no extreme (the flag decides everything).
+template <int OP>
+__device__ __forceinline__ bool track_initial(const rua_layout& L, const unsigned long long* __restrict__ extreme,
+                                              int no_empty) {
+  if (!(op_is_max(OP) || op_is_min(OP) || OP == RUA_LOGSUMEXP) || !extreme || no_empty) return false;
+  if (L.kind == RUA_CAT && L.bsz) return L.bsz[0] != 0;
+  return true;
+}
+
 template <typename A, int EPL, int OP>
 __device__ __forceinline__ void fold_flags(const Fold<A, EPL>& f, unsigned long long* __restrict__ extreme,
-                                           int lane, bool empty_unit) {
+                                           int lane, bool empty_unit, bool track = true) {
   if (!(op_is_max(OP) || op_is_min(OP) || OP == RUA_LOGSUMEXP) || !extreme) return;
   bool nan = false;
 #pragma unroll
@@ -542,7 +558,7 @@ __device__ __forceinline__ void fold_flags(const Fold<A, EPL>& f, unsigned long 
   if (lane != 0) return;
   // (a wave that read nothing still holds the start value: nothing to hand over; a NaN raised the poison flag and
   // decides everything)
-  if (opp == opp && opp != (op_is_min(OP) ? -acc_inf<A>() : acc_inf<A>())) {
+  if (track && opp == opp && opp != (op_is_min(OP) ? -acc_inf<A>() : acc_inf<A>())) {
     const unsigned long long bits = (unsigned long long)ordered_bits(opp);
     atomicMax(&extreme[extreme_slot()], op_is_min(OP) ? bits : ~bits);
   }
@@ -581,7 +597,8 @@ __global__ __launch_bounds__(RUA_WAVE * WPB) void seg_reduce_kernel(rua_layout L
                                                               int64_t H, int lp_log2, int64_t n_chunks,
                                                               int include_self, T empty_val,
                                                               unsigned long long* __restrict__ extreme,
-                                                              rua_layout CD, T* __restrict__ copy, SplitWs W) {
+                                                              rua_layout CD, T* __restrict__ copy, SplitWs W,
+                                                              int no_empty) {
   using A = typename elem<T>::acc;
   // ONE wave per workgroup: sequences differ in length, and a multi-wave workgroup would hold
   // its CU slots until its longest sequence is done.  (WPB > 1: that many INDEPENDENT waves per workgroup, each with a
@@ -594,6 +611,7 @@ __global__ __launch_bounds__(RUA_WAVE * WPB) void seg_reduce_kernel(rua_layout L
   const Unit<T, EPL> U = make_unit<T, EPL, COPY, CPW>(L, CD, perm, q, wid - q * n_chunks, H, lp_log2, lane);
   Fold<A, NE> f;
   fold_init<A, NE, OP>(f);
+  const bool track = track_initial<OP>(L, extreme, no_empty);
 
   if (SPLIT && U.len > W.split) {
     // long sequence: this wave takes part 0 and publishes the rest
@@ -616,15 +634,15 @@ __global__ __launch_bounds__(RUA_WAVE * WPB) void seg_reduce_kernel(rua_layout L
       int64_t* e = W.items + (ibase + p - 1) * 4;
       e[0] = q; e[1] = U.chunk; e[2] = p; e[3] = pbase + p;
     }
-    fold_rows<T, EPL, OP, NT, COPY, CPW>(U, 0, W.split, data, H, f, CD, copy, lane);
+    fold_rows<T, EPL, OP, NT, COPY, CPW>(U, 0, W.split, data, H, f, CD, copy, lane, 0, 1, track);
     fold_wave<A, NE, OP>(f, lp_log2);
     store_partial<A, NE, OP>(W.partials, pbase, lane, f);
   } else {
-    fold_rows<T, EPL, OP, NT, COPY, CPW>(U, 0, U.len, data, H, f, CD, copy, lane);
+    fold_rows<T, EPL, OP, NT, COPY, CPW>(U, 0, U.len, data, H, f, CD, copy, lane, 0, 1, track);
     fold_wave<A, NE, OP>(f, lp_log2);
     fold_store<T, EPL, OP, CPW>(U, f, out, H, include_self, empty_val, (A*)W.ties);
   }
-  fold_flags<A, NE, OP>(f, extreme, lane, U.len <= 0);
+  fold_flags<A, NE, OP>(f, extreme, lane, U.len <= 0, track);
 }
 
 // Few but long sequences (units <= the wave slots of the chip, hundreds of rows each): with one wave per sequence
@@ -637,7 +655,7 @@ template <typename T, int EPL, int OP, bool NT>
 __global__ __launch_bounds__(RUA_WAVE * TEAM_MAX) void seg_reduce_team_kernel(
     rua_layout L, const int64_t* __restrict__ perm, const T* __restrict__ data, T* __restrict__ out, int64_t H,
     int lp_log2, int64_t n_chunks, int include_self, T empty_val, unsigned long long* __restrict__ extreme,
-    typename elem<T>::acc* __restrict__ ties) {
+    typename elem<T>::acc* __restrict__ ties, int no_empty) {
   using A = typename elem<T>::acc;
   __shared__ A s_acc[TEAM_MAX][RUA_WAVE * EPL];
   __shared__ A s_aux[TEAM_MAX][RUA_WAVE * EPL];
@@ -648,9 +666,10 @@ __global__ __launch_bounds__(RUA_WAVE * TEAM_MAX) void seg_reduce_team_kernel(
   const Unit<T, EPL> U = make_unit<T, EPL, false, 1>(L, L, perm, q, wid - q * n_chunks, H, lp_log2, lane);
   Fold<A, EPL> f;
   fold_init<A, EPL, OP>(f);
-  fold_rows<T, EPL, OP, NT, false, 1>(U, 0, U.len, data, H, f, L, nullptr, lane, wave, team);
+  const bool track = track_initial<OP>(L, extreme, no_empty);
+  fold_rows<T, EPL, OP, NT, false, 1>(U, 0, U.len, data, H, f, L, nullptr, lane, wave, team, track);
   fold_wave<A, EPL, OP>(f, lp_log2);
-  fold_flags<A, EPL, OP>(f, extreme, lane, wave == 0 && U.len <= 0);
+  fold_flags<A, EPL, OP>(f, extreme, lane, wave == 0 && U.len <= 0, track);
   if (wave > 0) {
 #pragma unroll
     for (int k = 0; k < EPL; ++k) { s_acc[wave][lane * EPL + k] = f.acc[k]; s_aux[wave][lane * EPL + k] = f.aux[k]; }
@@ -678,10 +697,11 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_ranks_kernel(rua_layout L
                                                                     int include_self, T empty_val,
                                                                     unsigned long long* __restrict__ extreme,
                                                                     typename elem<T>::acc* __restrict__ ties, int glog,
-                                                                    SplitWs W) {
+                                                                    SplitWs W, int no_empty) {
   using A = typename elem<T>::acc;
   const int lane = threadIdx.x;
   const Unit<T, EPL> U = make_unit<T, EPL, false, 1, true>(L, L, nullptr, blockIdx.x, 0, H, lp_log2, lane, glog);
+  const bool track = track_initial<OP>(L, extreme, no_empty);
   int64_t t_hi = U.len;                       // the wave walks to its longest sequence
 #pragma unroll
   for (int d = RUA_WAVE / 2; d > 0; d >>= 1) {
@@ -721,25 +741,25 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_ranks_kernel(rua_layout L
             int64_t* e = W.items + (ibase + pp - 1) * 4;
             e[0] = q; e[1] = 0; e[2] = pp; e[3] = pbase + pp;
           }
-          fold_rows<T, EPL, OP, NT, false, 1, false>(V, 0, W.split, data, H, fv, L, nullptr, lane);
+          fold_rows<T, EPL, OP, NT, false, 1, false>(V, 0, W.split, data, H, fv, L, nullptr, lane, 0, 1, track);
           fold_wave<A, EPL, OP, false>(fv, lp_log2);
           store_partial<A, EPL, OP>(W.partials, pbase, lane, fv);
         } else {
-          fold_rows<T, EPL, OP, NT, false, 1, false>(V, 0, V.len, data, H, fv, L, nullptr, lane);
+          fold_rows<T, EPL, OP, NT, false, 1, false>(V, 0, V.len, data, H, fv, L, nullptr, lane, 0, 1, track);
           fold_wave<A, EPL, OP, false>(fv, lp_log2);
           fold_store<T, EPL, OP, 1, false>(V, fv, out, H, include_self, empty_val, ties);
         }
-        fold_flags<A, EPL, OP>(fv, extreme, lane, V.len <= 0);
+        fold_flags<A, EPL, OP>(fv, extreme, lane, V.len <= 0, track);
       }
       return;
     }
   }
   Fold<A, EPL> f;
   fold_init<A, EPL, OP>(f);
-  fold_rows<T, EPL, OP, NT, false, 1, true>(U, 0, t_hi, data, H, f, L, nullptr, lane);
+  fold_rows<T, EPL, OP, NT, false, 1, true>(U, 0, t_hi, data, H, f, L, nullptr, lane, 0, 1, track);
   fold_wave<A, EPL, OP, true>(f, lp_log2, glog);
   fold_store<T, EPL, OP, 1, true>(U, f, out, H, include_self, empty_val, ties);
-  fold_flags<A, EPL, OP>(f, extreme, lane, U.live && U.len <= 0);
+  fold_flags<A, EPL, OP>(f, extreme, lane, U.live && U.len <= 0, track);
 }
 
 // the published parts 1.. of long sequences
@@ -748,10 +768,12 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_tail_kernel(rua_layout L,
                                                                    const T* __restrict__ data, int64_t H,
                                                                    int lp_log2,
                                                                    unsigned long long* __restrict__ extreme,
-                                                                   rua_layout CD, T* __restrict__ copy, SplitWs W) {
+                                                                   rua_layout CD, T* __restrict__ copy, SplitWs W,
+                                                                   int no_empty) {
   using A = typename elem<T>::acc;
   const int lane = threadIdx.x;
   constexpr int NE = EPL * CPW;
+  const bool track = track_initial<OP>(L, extreme, no_empty);
   const int64_t n_items = (int64_t)(W.ctr[0] & 0xffffffffull);
   // the grid is capped (SPLIT_GRID_CAP): every workgroup strides over the published items
   for (int64_t i = blockIdx.x; i < n_items; i += gridDim.x) {
@@ -761,10 +783,10 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_tail_kernel(rua_layout L,
     const int64_t t_hi = (t_lo + W.split < U.len) ? t_lo + W.split : U.len;
     Fold<A, NE> f;
     fold_init<A, NE, OP>(f);
-    fold_rows<T, EPL, OP, NT, COPY, CPW>(U, t_lo, t_hi, data, H, f, CD, copy, lane);
+    fold_rows<T, EPL, OP, NT, COPY, CPW>(U, t_lo, t_hi, data, H, f, CD, copy, lane, 0, 1, track);
     fold_wave<A, NE, OP>(f, lp_log2);
     store_partial<A, NE, OP>(W.partials, e[3], lane, f);
-    fold_flags<A, NE, OP>(f, extreme, lane, false);
+    fold_flags<A, NE, OP>(f, extreme, lane, false, track);
   }
 }
 
@@ -776,7 +798,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_tail_kernel(rua_layout L,
 //           [w*per, (w+1)*per) in order, then wave 0 folds the 16 range results in wave order.
 // Either association depends only on the part count, so the result is bitwise reproducible.
 constexpr int COMBINE_WAVES_MAX = 16;
-constexpr int REDUCE_HINT_SHORT_SEQS = 2;    // dispatch_reduce's `hints`
+constexpr int REDUCE_HINT_NO_EMPTY = 1, REDUCE_HINT_SHORT_SEQS = 2;    // dispatch_reduce's `hints`
 constexpr int64_t RANKS_MIN_WAVES = 4096;   // adjacent-rank waves (RANKS) only when B / ranks-per-wave still fills the chip
 constexpr int COMBINE_SOLO = 32;
 constexpr int64_t COMBINE_GRID = 512;   // 2 workgroups per CU
@@ -1604,7 +1626,7 @@ template <typename T, int EPL, bool NT, bool COPY, int CPW>
 static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout& L, const int64_t* perm,
                          const void* data, void* out, int64_t H, int lp_log2, int64_t n_chunks, int include_self,
                          uint64_t empty_bits, void* extreme, const rua_layout& CD, void* copy, int64_t split,
-                         void* ws, void* ties) {
+                         void* ws, void* ties, int no_empty) {
   using A = typename elem<T>::acc;
   T ev;
   __builtin_memcpy(&ev, &empty_bits, sizeof(T));
@@ -1631,19 +1653,19 @@ static int launch_reduce(int op, unsigned grid, hipStream_t s, const rua_layout&
 #define RUA_LAUNCH(OP)                                                                                              \
   if (do_split) {                                                                                                   \
     hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY, true, CPW>), g, b, 0, s, L, perm, (const T*)data,   \
-                       (T*)out, H, lp_log2, n_chunks, include_self, ev, ext, CD, (T*)copy, W);                      \
+                       (T*)out, H, lp_log2, n_chunks, include_self, ev, ext, CD, (T*)copy, W, no_empty);            \
     hipLaunchKernelGGL((seg_reduce_tail_kernel<T, EPL, OP, NT, COPY, CPW>), dim3(split_grid(max_u)), b, 0, s, L, perm, \
-                       (const T*)data, H, lp_log2, ext, CD, (T*)copy, W);                                           \
+                       (const T*)data, H, lp_log2, ext, CD, (T*)copy, W, no_empty);                                 \
     hipLaunchKernelGGL((seg_reduce_combine_kernel<T, EPL, OP, CPW>),                                                \
                        dim3((unsigned)(max_u < COMBINE_GRID ? max_u : COMBINE_GRID)),                               \
                        dim3(RUA_WAVE * (COMBINE_WAVES_MAX / CPW)), 0, s, L, perm, (T*)out,                          \
                        H, lp_log2, include_self, ev, CD, COPY ? 1 : 0, W);                                          \
   } else if (wpb == 2) {                                                                                            \
     hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY, false, CPW, 2>), dim3((grid + 1) / 2), dim3(RUA_WAVE * 2), \
-                       0, s, L, perm, (const T*)data, (T*)out, H, lp_log2, n_chunks, include_self, ev, ext, CD, (T*)copy, W); \
+                       0, s, L, perm, (const T*)data, (T*)out, H, lp_log2, n_chunks, include_self, ev, ext, CD, (T*)copy, W, no_empty); \
   } else {                                                                                                          \
     hipLaunchKernelGGL((seg_reduce_kernel<T, EPL, OP, NT, COPY, false, CPW>), g, b, 0, s, L, perm, (const T*)data,  \
-                       (T*)out, H, lp_log2, n_chunks, include_self, ev, ext, CD, (T*)copy, W);                      \
+                       (T*)out, H, lp_log2, n_chunks, include_self, ev, ext, CD, (T*)copy, W, no_empty);            \
   }
   switch (op) {
     case RUA_SUM: RUA_LAUNCH(RUA_SUM); break;
@@ -1666,7 +1688,7 @@ template <typename T>
 static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, const int64_t* perm, const void* data,
                                 void* out, int64_t H, int include_self, uint64_t empty_bits, void* extreme,
                                 int64_t split, void* ws, const rua_layout* CD = nullptr, void* copy = nullptr,
-                                void* ties = nullptr, bool short_seqs = false) {
+                                void* ties = nullptr, bool short_seqs = false, int no_empty = 0) {
   constexpr int FULL = 16 / sizeof(T);
   constexpr int HALF = FULL >= 4 ? FULL / 2 : 1;      // 8-byte loads: hidden sizes that are a multiple of 8 bytes only
   const uintptr_t fptrs = (uintptr_t)data | (uintptr_t)out | (uintptr_t)copy | (uintptr_t)ties;
@@ -1753,9 +1775,9 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
   do { if (ranks_split) {                                                                                               \
     if constexpr (EPLV == FULL) {                                                                                  \
       hipLaunchKernelGGL((seg_reduce_ranks_kernel<T, EPLV, OPV, NTV, true>), gg, bb, 0, s, L, (const T*)data, (T*)out, H, \
-                         lp_log2, include_self, ev, ext, (typename elem<T>::acc*)ties, glog, W);                   \
+                         lp_log2, include_self, ev, ext, (typename elem<T>::acc*)ties, glog, W, no_empty);         \
       hipLaunchKernelGGL((seg_reduce_tail_kernel<T, EPLV, OPV, NTV, false, 1>), dim3(split_grid(max_u)), bb, 0, s, L, \
-                         (const int64_t*)nullptr, (const T*)data, H, lp_log2, ext, L, (T*)nullptr, W);             \
+                         (const int64_t*)nullptr, (const T*)data, H, lp_log2, ext, L, (T*)nullptr, W, no_empty);   \
       hipLaunchKernelGGL((seg_reduce_combine_kernel<T, EPLV, OPV, 1>),                                             \
                          dim3((unsigned)(max_u < COMBINE_GRID ? max_u : COMBINE_GRID)),                            \
                          dim3(RUA_WAVE * COMBINE_WAVES_MAX), 0, s, L, (const int64_t*)nullptr, (T*)out, H, lp_log2, \
@@ -1763,7 +1785,7 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
     }                                                                                                              \
   } else                                                                                                           \
   hipLaunchKernelGGL((seg_reduce_ranks_kernel<T, EPLV, OPV, NTV>), gg, bb, 0, s, L, (const T*)data, (T*)out, H,    \
-                     lp_log2, include_self, ev, ext, (typename elem<T>::acc*)ties, glog, W); } while (0)
+                     lp_log2, include_self, ev, ext, (typename elem<T>::acc*)ties, glog, W, no_empty); } while (0)
 #define RUA_RANKS_OP(EPLV, NTV)                                  \
   switch (op) {                                                  \
     case RUA_SUM: RUA_RANKS(EPLV, NTV, RUA_SUM); break;          \
@@ -1792,7 +1814,7 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
       using A = typename elem<T>::acc;
 #define RUA_TEAM(NTV, OPV)                                                                                           \
   hipLaunchKernelGGL((seg_reduce_team_kernel<T, FULL, OPV, NTV>), gg, bb, 0, s, L, perm, (const T*)data, (T*)out, H, \
-                     lp_log2, n_chunks, include_self, ev, ext, (A*)ties)
+                     lp_log2, n_chunks, include_self, ev, ext, (A*)ties, no_empty)
 #define RUA_TEAM_OP(NTV)                                                                           \
   switch (op) {                                                                                    \
     case RUA_SUM: RUA_TEAM(NTV, RUA_SUM); break;                                                   \
@@ -1811,7 +1833,7 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
   }
 #define RUA_GO(EPLV, NTV, COPYV, CPWV)                                                                             \
   return launch_reduce<T, EPLV, NTV, COPYV, CPWV>(op, g, s, L, perm, data, out, H, lp_log2, n_chunks, include_self, \
-                                                  empty_bits, extreme, cd, copy, split, ws, ties)
+                                                  empty_bits, extreme, cd, copy, split, ws, ties, no_empty)
   if (copy) {
     if (wide) { if (nt) RUA_GO(FULL, true, true, 4); else RUA_GO(FULL, false, true, 4); }      // (copy: vec_ok)
     if (nt) RUA_GO(FULL, true, true, 1); else RUA_GO(FULL, false, true, 1);
@@ -1833,7 +1855,7 @@ static int dispatch_reduce(int op, hipStream_t s, const rua_layout& L, const int
                            int64_t split, void* ws, const rua_layout* CD = nullptr, void* copy = nullptr,
                            void* ties = nullptr, int hints = 0) {
   return dispatch_reduce_main<T>(op, s, L, perm, data, out, H, include_self, empty_bits, extreme, split, ws, CD, copy,
-                                 ties, (hints & REDUCE_HINT_SHORT_SEQS) != 0);
+                                 ties, (hints & REDUCE_HINT_SHORT_SEQS) != 0, (hints & REDUCE_HINT_NO_EMPTY) ? 1 : 0);
 }
 
 template <typename T, int EPL>

@@ -22,9 +22,10 @@ def major_sizes_to_ptr(sizes: Tensor) -> Tuple[Tensor, Tensor]:
     sizes = M._as_lens(sizes)
     off, total = M.exclusive_scan(sizes, want_total=True)
     M._memo_put(sizes, 'off', off)
+    M._memo_put(sizes, 'n_empty_dev', total[1:2])
     n = M._memo_get(sizes, 'sum')
     if n is None:
-        n = int(total.item())     # the expansion's length is data-dependent: one sync (the reference's
+        n = int(total[0].item())  # the expansion's length is data-dependent: one sync (the reference's
         M._memo_put(sizes, 'sum', n)  # repeat_interleave syncs here too)
     lay = M.lay_cat(sizes, sizes.numel(), n)
     major = torch.empty(n, dtype=torch.long, device=dev)
