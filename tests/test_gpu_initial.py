@@ -108,3 +108,35 @@ def test_the_differentiable_forward_tracks_it_too():
     torch.segment_reduce(xc, 'max', lengths=lens, unsafe=True, initial=float(data.min())).sum().backward()
     torch.testing.assert_close(x.grad.cpu(), xc.grad)
     assert _scratch_is_clean()
+
+
+def test_the_scan_counts_the_empty_sequences_and_the_reduce_believes_it():
+    """rua_exclusive_scan_i64 leaves the number of inputs <= 0 in total[1] (one tile, many tiles); a CAT layout built from
+    device-only lengths carries that word (rua_layout::bsz) and max / min / logsumexp skip the tracking of the global
+    extreme when it reads 0.  The word follows the lengths: writing a zero into them in place (a version bump) brings a
+    fresh scan, a fresh count and the tracking back."""
+    from torchrua_amd import _meta as M
+    g = torch.Generator().manual_seed(21)
+    for n in (5, 2048, 2049, 70_001):
+        x = torch.randint(-2, 6, (n,), generator=g)
+        off, total = M.exclusive_scan(x.to(DEV), want_total=True)
+        assert total.cpu().tolist() == [int(x.sum()), int((x <= 0).sum())], n
+        assert torch.equal(off.cpu(), torch.cumsum(x, 0) - x)
+    lens = torch.randint(1, 30, (3000,), generator=g)
+    data = torch.randn(int(lens.sum()), 32, generator=g)
+    data[:5] -= 50.0                                  # the global minimum sits in rows every variant below still reads
+    dd, ld = data.to(DEV), lens.to(DEV)
+    out = ta.segment_logsumexp(dd, ld)
+    assert int(M.dev_n_empty(ld)) == 0                # nothing empty: this call did not track
+    np.testing.assert_allclose(out.cpu().numpy(), orc.segment_logsumexp(data.numpy(), lens.numpy()), rtol=2e-5, atol=2e-5)
+    ld[1234] = 0                                      # in place: lengths now sum to less than the payload holds
+    lens2 = lens.clone()
+    lens2[1234] = 0
+    n2 = int(lens2.sum())
+    for name in ('max', 'logsumexp'):
+        got = getattr(ta, f'segment_{name}')(dd, ld).cpu().numpy()
+        assert int(M.dev_n_empty(ld)) == 1
+        ref = getattr(orc, f'segment_{name}')(data[:n2].numpy(), lens2.numpy())
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5, err_msg=name)
+        assert np.all(got[1234] == data.min().item())
+    assert _scratch_is_clean()
