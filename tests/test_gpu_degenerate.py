@@ -178,6 +178,20 @@ def test_short_sequences_side_by_side(H, dtype):
     lens2[77] = 10_000
     data2 = torch.zeros(int(lens2.sum()), H, dtype=dtype, device=DEV)
     assert O.short_seqs_hint(describe(ta.with_host_sizes(data2, lens2)), H * data.element_size()) == 0
+    # [r5] ... but not the side-by-side form: with nobody's word about the longest sequence every wave checks its own
+    # lengths and walks them one after the other when they are far apart.  Device-only lengths and host-known lengths
+    # without the hint, the 10 000-row sequence among them, against the oracle's sequential folds
+    import numpy as np
+    from helpers import orc
+    d2 = (torch.randn(int(lens2.sum()), H, generator=g) * 0.5).to(dtype)
+    f = d2.float().numpy()
+    ulp = {torch.float32: 0.0, torch.bfloat16: 2.0 ** -8}[dtype]
+    for z in (ta.C(d2.to(DEV), lens2.to(DEV)), ta.with_host_sizes(d2.to(DEV), lens2)):
+        for name in ('sum', 'max', 'logsumexp'):
+            ref = getattr(orc, f'segment_{name}')(f, lens2.numpy()).astype(np.float64)
+            got = getattr(ta, f'reduce_{name}')(z).double().cpu().numpy()
+            scale = float(np.abs(f).max()) * (10_000 if name == 'sum' else 1)
+            np.testing.assert_allclose(got, ref, rtol=2e-5 + ulp, atol=2e-5 * scale + ulp + 1e-6, err_msg=name)
 
 
 @pytest.mark.parametrize('H,dtype,skip', [(8, torch.bfloat16, 1), (16, torch.bfloat16, 3), (8, torch.float32, 2), (16, torch.float32, 1)])

@@ -697,7 +697,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_ranks_kernel(rua_layout L
                                                                     int include_self, T empty_val,
                                                                     unsigned long long* __restrict__ extreme,
                                                                     typename elem<T>::acc* __restrict__ ties, int glog,
-                                                                    SplitWs W, int no_empty) {
+                                                                    SplitWs W, int no_empty, int check) {
   using A = typename elem<T>::acc;
   const int lane = threadIdx.x;
   const Unit<T, EPL> U = make_unit<T, EPL, false, 1, true>(L, L, nullptr, blockIdx.x, 0, H, lp_log2, lane, glog);
@@ -708,11 +708,14 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_ranks_kernel(rua_layout L
     const int64_t o = __shfl_xor(t_hi, d, RUA_WAVE);
     t_hi = o > t_hi ? o : t_hi;
   }
-  if (glog > 0) {
+  if (glog > 0 || check) {
     // Several row slots per sequence (a CattedSequence at rows of <= 32 bytes, a few sequences per wave): the wave checks
     // its OWN lengths — the lengths may live on the device only, nobody vouched for them — and when they are far apart
     // (the longest beyond twice the wave's average + 64 rows: one giant sequence next to short ones would be walked by
     // a quarter of the lanes) it takes its sequences one after the other with every row slot, as seg_reduce_kernel does.
+    // ([r5] `check`: the same for every row slot its own sequence — a batch of SHORT sequences, which the host can tell
+    // from rows / sequences alone — when nobody vouched for the longest one: 1 M sequences of U(1,8) rows of 64 bytes with
+    // device-only lengths 0.72 -> 0.09 ms, where one wave per sequence is bound by the rate of workgroup dispatch)
     const int per_wave = RUA_WAVE >> (lp_log2 + glog);
     int64_t total = (U.rsub == 0 && (lane & ((1 << lp_log2) - 1)) == 0 && U.live) ? U.len : 0;   // one lane per sequence
 #pragma unroll
@@ -1732,16 +1735,17 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
   if (cat_ranks) {
     const int64_t side = RUA_WAVE >> lp_log2;     // sequences side by side with one row slot each
     const int64_t short_avg = 4 * side < 16 ? 16 : (4 * side > 64 ? 64 : 4 * side);
-    if (!short_seqs || L.n_rows > short_avg * L.B) {   // no word about the lengths, or longer than that on average:
+    if (L.n_rows > short_avg * L.B) {             // longer than that on average:
       if (lp_log2 <= 1) glog = 4 - lp_log2;       // FOUR sequences per wave at rows of <= 32 bytes (16 / 8 rows of each
       else cat_ranks = false;                     // per instruction; the wave checks its own lengths), else one wave each
-    }
+    }                                             // (short on average, no word about the longest: the waves check, `check`)
     // ([r5] a batch too small to fill the chip with every row slot its own sequence — 200 000 sequences are 3 125 such
     // waves — still fills it four to a wave at rows of <= 32 bytes: 154 -> 54 us for 200 000 x U(1,32) rows of 16 bytes)
     if (cat_ranks && glog == 0 && lp_log2 <= 1 && (L.B >> (6 - lp_log2)) < RANKS_MIN_WAVES) glog = 4 - lp_log2;
   }
   // ([r5] with the long-sequence split armed — lengths nobody vouches for — the four-per-wave form splits by itself)
-  const bool ranks_split = split > 0 && ws && cat_ranks && glog > 0 && vec_ok && split_max_extra(L.n_rows, split) > 0;
+  const int ranks_check = (cat_ranks && !short_seqs) ? 1 : 0;
+  const bool ranks_split = split > 0 && ws && cat_ranks && (glog > 0 || ranks_check) && vec_ok && split_max_extra(L.n_rows, split) > 0;
   if (((L.kind == RUA_PACK && L.sorted) || cat_ranks) && !copy && !perm && lp_log2 < 6 && (!(split > 0 && ws) || ranks_split) &&
       (L.B >> (6 - lp_log2 - glog)) >= RANKS_MIN_WAVES) {
     // narrow rows of a PackedSequence: adjacent ranks share a wave instruction
@@ -1775,7 +1779,7 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
   do { if (ranks_split) {                                                                                               \
     if constexpr (EPLV == FULL) {                                                                                  \
       hipLaunchKernelGGL((seg_reduce_ranks_kernel<T, EPLV, OPV, NTV, true>), gg, bb, 0, s, L, (const T*)data, (T*)out, H, \
-                         lp_log2, include_self, ev, ext, (typename elem<T>::acc*)ties, glog, W, no_empty);         \
+                         lp_log2, include_self, ev, ext, (typename elem<T>::acc*)ties, glog, W, no_empty, ranks_check); \
       hipLaunchKernelGGL((seg_reduce_tail_kernel<T, EPLV, OPV, NTV, false, 1>), dim3(split_grid(max_u)), bb, 0, s, L, \
                          (const int64_t*)nullptr, (const T*)data, H, lp_log2, ext, L, (T*)nullptr, W, no_empty);   \
       hipLaunchKernelGGL((seg_reduce_combine_kernel<T, EPLV, OPV, 1>),                                             \
@@ -1785,7 +1789,7 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
     }                                                                                                              \
   } else                                                                                                           \
   hipLaunchKernelGGL((seg_reduce_ranks_kernel<T, EPLV, OPV, NTV>), gg, bb, 0, s, L, (const T*)data, (T*)out, H,    \
-                     lp_log2, include_self, ev, ext, (typename elem<T>::acc*)ties, glog, W, no_empty); } while (0)
+                     lp_log2, include_self, ev, ext, (typename elem<T>::acc*)ties, glog, W, no_empty, ranks_check); } while (0)
 #define RUA_RANKS_OP(EPLV, NTV)                                  \
   switch (op) {                                                  \
     case RUA_SUM: RUA_RANKS(EPLV, NTV, RUA_SUM); break;          \
