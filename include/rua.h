@@ -234,7 +234,10 @@ enum rua_op {
  * are short (16 .. 64 rows on average by row width) every row slot of a wave then takes a sequence of its own — one
  * wave = one workgroup per sequence is bound by the workgroup dispatch rate there — and the wave walks to the longest of
  * them, hence the word.  (At rows of <= 32 bytes four sequences share a wave with or without it: that form checks its
- * own lengths, wave by wave.)  A hint: results do not depend on it (sums to rounding: the fold's association changes). */
+ * own lengths, wave by wave.  Since ABI 6 so does every-row-slot-its-own-sequence when the word is NOT given — a batch
+ * is short on average whatever the caller knows: rows / sequences — and a wave whose lengths are far apart walks them
+ * one after the other; the word saves that check.)  A hint: results do not depend on it (sums to rounding: the fold's
+ * association changes). */
 #define RUA_OP_SHORT_SEQS    0x400
 int64_t rua_reduce_ws_bytes(int64_t n_rows, int64_t H, int32_t dtype, int64_t split_rows);
 /* Waves (1, 2 or 4) that share one sequence in rua_segment_reduce for an aligned payload of `row_bytes`-wide

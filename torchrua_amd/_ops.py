@@ -191,7 +191,8 @@ def short_seqs_hint(lay: M.Lay, row_bytes: int) -> int:
     launcher gives every row slot of a wave a sequence of its own up to 16 .. 64 rows on average by row width
     (profiles/r04_cat_ranks_ab.txt).  The wave walks to the longest of its sequences, hence the bound — and no hint at
     all when the lengths live on the device only.  (Four sequences per wave at rows of <= 32 bytes need no hint: that
-    form checks its own lengths, wave by wave.)"""
+    form checks its own lengths, wave by wave — and so, since round 5, does every-row-slot-its-own-sequence when the hint
+    is withheld: the hint only saves the waves that check.)"""
     if lay.kind != L.CAT or lay.max_len is None or lay.B <= 0 or not 0 < row_bytes <= 512:
         return 0
     avg = lay.n_rows / lay.B
