@@ -803,6 +803,7 @@ __global__ __launch_bounds__(RUA_WAVE) void seg_reduce_tail_kernel(rua_layout L,
 constexpr int COMBINE_WAVES_MAX = 16;
 constexpr int REDUCE_HINT_NO_EMPTY = 1, REDUCE_HINT_SHORT_SEQS = 2;    // dispatch_reduce's `hints`
 constexpr int64_t RANKS_MIN_WAVES = 4096;   // adjacent-rank waves (RANKS) only when B / ranks-per-wave still fills the chip
+constexpr int64_t RANKS_MIN_WAVES_SHORT = 512;   // ... of SHORT sequences (dispatch_reduce_main)
 constexpr int COMBINE_SOLO = 32;
 constexpr int64_t COMBINE_GRID = 512;   // 2 workgroups per CU
 
@@ -1739,15 +1740,21 @@ static int dispatch_reduce_main(int op, hipStream_t s, const rua_layout& L, cons
       if (lp_log2 <= 1) glog = 4 - lp_log2;       // FOUR sequences per wave at rows of <= 32 bytes (16 / 8 rows of each
       else cat_ranks = false;                     // per instruction; the wave checks its own lengths), else one wave each
     }                                             // (short on average, no word about the longest: the waves check, `check`)
-    // ([r5] a batch too small to fill the chip with every row slot its own sequence — 200 000 sequences are 3 125 such
-    // waves — still fills it four to a wave at rows of <= 32 bytes: 154 -> 54 us for 200 000 x U(1,32) rows of 16 bytes)
-    if (cat_ranks && glog == 0 && lp_log2 <= 1 && (L.B >> (6 - lp_log2)) < RANKS_MIN_WAVES) glog = 4 - lp_log2;
+    // ([r5] a batch too small to fill the chip with every row slot its own sequence still fills it four to a wave at
+    // rows of <= 32 bytes)
+    if (cat_ranks && glog == 0 && lp_log2 <= 1 && (L.B >> (6 - lp_log2)) < RANKS_MIN_WAVES_SHORT) glog = 4 - lp_log2;
   }
+  // How many side-by-side waves are enough: RANKS_MIN_WAVES when the sequences may be long (a wave then walks hundreds of
+  // steps one after the other, and only plenty of them keep the chip busy); a few hundred when they are SHORT — a
+  // CattedSequence that is short on average, a PackedSequence of at most 128 time steps — where the alternative is one
+  // wave per sequence at one row per instruction: 200 000 x U(1,32) rows of 16 bytes are 3 125 waves of 64 sequences
+  const bool short_form = (cat_ranks && glog == 0) || (L.kind == RUA_PACK && L.T > 0 && L.T <= 128);
+  const int64_t ranks_min_waves = short_form ? RANKS_MIN_WAVES_SHORT : RANKS_MIN_WAVES;
   // ([r5] with the long-sequence split armed — lengths nobody vouches for — the four-per-wave form splits by itself)
   const int ranks_check = (cat_ranks && !short_seqs) ? 1 : 0;
   const bool ranks_split = split > 0 && ws && cat_ranks && (glog > 0 || ranks_check) && vec_ok && split_max_extra(L.n_rows, split) > 0;
   if (((L.kind == RUA_PACK && L.sorted) || cat_ranks) && !copy && !perm && lp_log2 < 6 && (!(split > 0 && ws) || ranks_split) &&
-      (L.B >> (6 - lp_log2 - glog)) >= RANKS_MIN_WAVES) {
+      (L.B >> (6 - lp_log2 - glog)) >= ranks_min_waves) {
     // narrow rows of a PackedSequence: adjacent ranks share a wave instruction
     // (tried for a CattedSequence with 32-byte rows too — groups = adjacent sequences: 4.0 -> 2.8 TB/s at U(8,512),
     // unsorted neighbours differ too much in length — so C keeps one wave per sequence, EXCEPT for batches of short
