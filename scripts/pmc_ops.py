@@ -61,6 +61,7 @@ def groups():
         ten = torch.zeros(B, H, dtype=torch.bfloat16, device=dev)
         yield 'ns.scatter_sum(shuffled)', N * H * e + B * H * e + 2 * N * 8, lambda: ta.scatter_sum(ten, shuffled, data)
         yield 'ns.c.pack()', 2 * N * H * e, lambda: c.pack()
+        yield 'ns.p.cat()', 2 * N * H * e, lambda: p.cat()
         yield 'ns.c.left()', N * H * e + B * T * H * e, lambda: c.left()
         yield 'ns.p.left()', N * H * e + B * T * H * e, lambda: p.left()
         yield 'ns.c.roll(0)  [calib: streaming copy, 1 KiB rows]', 2 * N * H * e, lambda: c.roll(0)
